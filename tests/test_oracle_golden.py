@@ -1,0 +1,212 @@
+"""Pin the CPU oracle (oracle/) against fixtures produced by the real reference
+(tests/golden/make_golden.py).  CPU only."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import Golden, ROOT, load_pkg
+
+sys.path.insert(0, ROOT)
+from oracle import decafnet_ref as R  # noqa: E402
+from oracle import nms_oracle  # noqa: E402
+
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+def close(a, b, **kw):
+    kw = {**TOL, **kw}
+    assert a.shape == b.shape, (a.shape, b.shape)
+    torch.testing.assert_close(a, b, **kw)
+
+
+# ------------------------------------------------------------------ G1
+@pytest.fixture(scope='module')
+def ops():
+    return Golden('ops.npz')
+
+
+def test_masked_conv(ops):
+    x, mask = ops.t('x'), ops.t('mask')
+    w = ops.sub('conv_k3/w/')
+    y, m = R.masked_conv1d(x, mask, w['conv.weight'], None, 1, 1)
+    close(y, ops.t('conv_k3/y'))
+    w = ops.sub('conv_dw_s2/w/')
+    y, m = R.masked_conv1d(x, mask, w['conv.weight'], None, 2, 1, groups=x.size(1))
+    close(y, ops.t('conv_dw_s2/y'))
+    assert torch.equal(m, ops.t('conv_dw_s2/ymask'))
+    w = ops.sub('conv_1x1/w/')
+    y, _ = R.masked_conv1d(x, mask, w['conv.weight'], w['conv.bias'])
+    close(y, ops.t('conv_1x1/y'))
+
+
+def test_layer_norm(ops):
+    x = ops.t('x')
+    close(R.channel_layer_norm(x, ops.t('ln/w/weight'), ops.t('ln/w/bias')), ops.t('ln/y'))
+    close(R.channel_layer_norm(x), ops.t('ln_noaffine/y'))
+
+
+def test_max_pool(ops):
+    y, m = R.masked_max_pool1d(ops.t('x'), ops.t('mask'))
+    close(y, ops.t('maxpool/y'))
+    assert torch.equal(m, ops.t('maxpool/ymask'))
+
+
+def test_mha_global(ops):
+    sd = {'a.' + k: v for k, v in ops.sub('mha_global/w/').items()}
+    y = R.mha_global(sd, 'a', ops.t('x'), ops.t('kv'), ops.t('kv_mask'), 4)
+    close(y, ops.t('mha_global/y'))
+
+
+@pytest.mark.parametrize('w', [5, 9, 19])
+def test_mha_local(ops, w):
+    sd = {'a.' + k: v for k, v in ops.sub(f'mha_local{w}/w/').items()}
+    x = ops.t('x')
+    y = R.mha_local(sd, 'a', x, x, x, ops.t('mask'), 4, w)
+    close(y, ops.t(f'mha_local{w}/y'))
+
+
+@pytest.mark.parametrize('s', [0, 1, 2])
+def test_encoder(ops, s):
+    sd = {'e.' + k: v for k, v in ops.sub(f'enc_s{s}/w/').items()}
+    y, m = R.transformer_encoder(sd, 'e', ops.t('x'), ops.t('mask'), s, 4, 9 if s else 0)
+    close(y, ops.t(f'enc_s{s}/y'))
+    if s:
+        assert torch.equal(m, ops.t(f'enc_s{s}/ymask'))
+
+
+def test_decoder(ops):
+    sd = {'d.' + k: v for k, v in ops.sub('dec/w/').items()}
+    y, _ = R.transformer_decoder(sd, 'd', ops.t('x'), ops.t('mask'), ops.t('kv'), ops.t('kv_mask'), 4)
+    close(y, ops.t('dec/y'))
+
+
+def test_tcn(ops):
+    sd = {'r.' + k: v for k, v in ops.sub('tcn/w/').items()}
+    y = R.tcn_refine(sd, 'r', ops.t('tcn/x'), ops.t('mask'), 4)
+    close(y, ops.t('tcn/y'))
+
+
+# ------------------------------------------------------------------ G2
+def test_gate_cases():
+    g = Golden('gate.npz')
+    for i, c in enumerate(g.js('cases')):
+        correl, want = g.t(f'c{i}/correl'), g.t(f'c{i}/gate')
+        got = R.topk_block_gate(correl, c['vid_len'], c['sn'], c['sratio'])
+        full = torch.zeros(c['T'])
+        full[:c['vid_len']] = got
+        assert torch.equal(full.to(torch.uint8), want), c
+        # closed form used by the HIP kernel: sequential block means, stable rank, f32 nearest index
+        L, sn = c['vid_len'], c['sn']
+        n = (L + sn - 1) // sn
+        pooled = torch.empty(n)
+        for b in range(n):
+            seg = correl[b * sn:min((b + 1) * sn, L)]
+            acc = torch.zeros((), dtype=torch.float32)
+            for v in seg:
+                acc = acc + v
+            pooled[b] = acc / float(len(seg))
+        got2 = R.gate_reference_formula(pooled, L, c['sratio']) if n < 1200 and L < 20000 else None
+        if got2 is not None:
+            full2 = torch.zeros(c['T'])
+            full2[:L] = got2
+            assert torch.equal(full2.to(torch.uint8), want), ('closed form', c)
+
+
+# ------------------------------------------------------------------ G3
+@pytest.mark.parametrize('name', ['c1', 'pe', 'nomsf'])
+def test_end_to_end(name):
+    g = Golden(f'e2e_{name}.npz')
+    pkg = load_pkg()
+    meta, kw = g.js('meta'), g.js('opt_kwargs')
+    opt = pkg.config.make_opt(**kw)
+    shapes = g.js('shapes')
+    sd = pkg.synth.make_state_dict(shapes, meta['wseed'])
+    chk = torch.stack([sum(v.double().sum() for v in sd.values()), sum(v.double().abs().sum() for v in sd.values())])
+    torch.testing.assert_close(chk, g.t('weight_checksum'), rtol=1e-12, atol=0)
+    inp = pkg.synth.make_inputs(kw['D'], meta['T'], meta['vid_len'], meta['nq'], kw['text_in'], meta['lq'], meta['iseed'])
+    texts, tmasks = [], []
+    for q, tok in enumerate(inp['tokens']):
+        t, m = R.encode_text(sd, opt.model, tok[None], torch.ones(1, 1, tok.size(-1), dtype=torch.bool))
+        close(t, g.t(f'q{q}/text'))
+        assert torch.equal(m, g.t(f'q{q}/text_mask'))
+        texts.append(t)
+        tmasks.append(m)
+    logits, offsets, masks, inter = R.forward_eval(sd, opt.model, inp['vid'], inp['shallow_vid'], inp['vid_masks'],
+                                                   texts, inp['text_cls'], tmasks, return_intermediates=True)
+    for q in range(meta['nq']):
+        close(inter['per_query'][q]['vid_map'], g.t(f'q{q}/vid_map'), atol=2e-5)
+        close(inter['per_query'][q]['fused'], g.t(f'q{q}/fused'), atol=5e-5)
+        for l in range(kw['n_levels']):
+            close(logits[q][l], g.t(f'q{q}/l{l}/logits'), atol=1e-4, rtol=1e-4)
+            close(offsets[q][l], g.t(f'q{q}/l{l}/offsets'), atol=1e-4, rtol=1e-4)
+            assert torch.equal(masks[q][l], g.t(f'q{q}/l{l}/mask'))
+    pts = R.generate_points(kw['max_seq_len'] * 10, kw['n_levels'], 4, 0.5)
+    for l in range(kw['n_levels']):
+        want = g.t(f'points/l{l}')
+        assert torch.equal(pts[l][:len(want)], want)
+
+
+# ------------------------------------------------------------------ G4
+def test_postproc():
+    g = Golden('postproc.npz')
+    meta = g.js('meta')
+    L, T0 = meta['L'], meta['T0']
+    pts = R.generate_points(T0, L, 4, 0.5)
+    logits = [g.t(f'l{l}/logits') for l in range(L)]
+    offsets = [g.t(f'l{l}/offsets') for l in range(L)]
+    masks = [g.t(f'l{l}/mask') for l in range(L)]
+    segs, scores = R.collect_segments(pts, logits, offsets, masks)
+    close(segs, g.t('segs'), atol=0, rtol=0)
+    close(scores, g.t('scores'), atol=0, rtol=0)
+    for k, cfg in g.js('nms_cfgs').items():
+        s, c = R.batched_nms(segs.clone(), scores.clone(), **cfg)
+        close(s, g.t(f'{k}/segs'), atol=1e-4)
+        close(c, g.t(f'{k}/scores'), atol=1e-6)
+        sec = R.to_seconds(s, 1, 16, 32, 30.0, 1000.0)
+        close(sec, g.t(f'{k}/seconds'), atol=1e-4)
+
+
+# ------------------------------------------------------------------ G5
+def test_nms_known_answers():
+    g = Golden('nms_kat.npz')
+    for i, c in enumerate(g.js('cases')):
+        segs, scores = g.t(f'k{i}/segs'), g.t(f'k{i}/scores')
+        idx = nms_oracle.nms(segs, scores, c['iou_thresh'])
+        assert torch.equal(idx, g.t(f'k{i}/nms')), c
+        for method in (0, 1, 2):
+            dets = torch.full((len(segs), 3), -7.0)
+            idx = nms_oracle.softnms(segs, scores, dets, c['iou_thresh'], c['sigma'], c['min_score'], method)
+            assert torch.equal(idx, g.t(f'k{i}/soft{method}/idx')), (c, method)
+            want = g.t(f'k{i}/soft{method}/dets')
+            assert torch.equal(dets[:len(idx)], want), (c, method)
+
+
+def test_nms_vs_compiled_reference_random():
+    """When oracle/_ref holds the reference's own extension, fuzz the C oracle against it."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('oracle_build_ref', os.path.join(ROOT, 'oracle', 'build_ref.py'))
+    br = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(br)
+    ext = br.load_module()
+    if ext is None:
+        pytest.skip('oracle/_ref not built')
+    g = torch.Generator().manual_seed(99)
+    for trial in range(40):
+        n = int(torch.randint(1, 300, (1,), generator=g))
+        c = torch.rand(n, generator=g) * 100
+        ln = torch.rand(n, generator=g) * 30 + 0.1
+        segs = torch.stack((c - ln / 2, c + ln / 2), -1).contiguous()
+        scores = torch.rand(n, generator=g).contiguous()
+        if len(torch.unique(scores)) != n:
+            continue
+        thr = float(torch.rand(1, generator=g) * 0.8 + 0.05)
+        assert torch.equal(nms_oracle.nms(segs, scores, thr), ext.nms(segs, scores, iou_thresh=thr))
+        for method in (0, 1, 2):
+            d1, d2 = torch.zeros(n, 3), torch.zeros(n, 3)
+            i1 = nms_oracle.softnms(segs, scores, d1, thr, 0.5, 0.01, method)
+            i2 = ext.softnms(segs, scores, d2, iou_thresh=thr, sigma=0.5, min_score=0.01, method=method)
+            assert torch.equal(i1, i2)
+            assert torch.equal(d1[:len(i1)], d2[:len(i2)])
