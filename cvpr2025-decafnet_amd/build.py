@@ -1,0 +1,69 @@
+"""Build libdecafnet_hip.so (gfx950) in-tree with hipcc.
+
+    python -m build        # from inside the package directory, or
+    __graft_entry__.build()
+
+One translation unit per kernel family, compiled in parallel, linked into a single shared
+object that exports the C ABI of include/decafnet_hip.h.  The .so stays in the source tree
+(git-ignored) so that it travels with the working copy to the GPU machine.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OUT = os.path.join(HERE, 'libdecafnet_hip.so')
+SOURCES = ['engine.hip', 'gemm.hip', 'rowops.hip', 'attn.hip', 'score.hip', 'heads.hip', 'postproc.hip']
+ARCH = 'gfx950'
+FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
+
+
+def hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError('hipcc not found')
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    headers.append(os.path.join(os.path.dirname(HERE), 'include', 'decafnet_hip.h'))
+    objdir = os.path.join(HERE, 'build')
+    os.makedirs(objdir, exist_ok=True)
+    cc = hipcc()
+    jobs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, s.replace('.hip', '.o'))
+        if force or _stale(obj, [src] + headers):
+            jobs.append([cc] + FLAGS + ['-c', src, '-o', obj])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed:\n' + ' '.join(cmd) + '\n' + r.stdout + r.stderr)
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for err in ex.map(run, jobs):
+            if verbose and err.strip():
+                print(err)
+    objs = [os.path.join(objdir, s.replace('.hip', '.o')) for s in SOURCES]
+    if force or jobs or _stale(OUT, objs):
+        run([cc, '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', OUT] + objs)
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

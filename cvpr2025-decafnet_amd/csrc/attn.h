@@ -1,0 +1,27 @@
+// Attention cores (attn.hip): text->clip cross attention and sliding-window clip self attention.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dcf {
+
+struct XAttnArgs {
+  const float* Q;          // [B*T][C]  projected queries (one row per clip)
+  const float* K;          // [B*Lk][C] projected text keys   (zero padded to Lk)
+  const float* V;          // [B*Lk][C]
+  const uint8_t* kvmask;   // [B*Lk]    1 = valid key
+  float* O;                // [B*T][C]  context, heads concatenated along C
+  int B, T, Lk, C, heads;
+};
+
+struct LocalAttnArgs {
+  const float* Q; const float* K; const float* V;   // [B*T][C]
+  const uint8_t* mask;                               // [B*T]
+  float* O;                                          // [B*T][C]
+  int B, T, C, heads, window;                        // window odd
+};
+
+int launch_xattn(const XAttnArgs& a, hipStream_t st);
+int launch_local_attn(const LocalAttnArgs& a, hipStream_t st);
+
+}  // namespace dcf

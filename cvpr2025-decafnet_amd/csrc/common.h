@@ -1,0 +1,133 @@
+// Shared device/host helpers for the DeCafNet gfx950 kernels.
+//
+// Layout convention used by every kernel in this directory ("token-major"):
+//   an activation is a row-major matrix [rows][ld] of fp32, one row per clip position,
+//   rows ordered [batch b][position t]  (row = b * T + t), channels contiguous.
+// The reference keeps (bs, C, T) channel-major tensors; the only channel-major buffers we
+// touch are the user's inputs (vid, shallow_vid, text), which the first kernels transpose
+// on the fly.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DCF_WAVE 64
+
+namespace dcf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- wave-level reductions (64 lanes) -------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+// reduce within aligned groups of G lanes (G power of two <= 64)
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// NOTE: register arrays must use the native ext_vector type f32x4, never HIP's float4 struct:
+// struct copies lower to cross-address-space memcpy, which blocks SROA and spills to scratch.
+
+// ---- a row of up to 4*256 channels held by one wave: lane owns f32x4 chunks -----------
+// chunk j of lane l covers channels [256*j + 4*l, 256*j + 4*l + 4)
+template <int NCH>
+struct Row {
+  f32x4 v[NCH];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __device__ __forceinline__ void load(const float* __restrict__ p, int C, int lane) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      int c = 256 * j + 4 * lane;
+      v[j] = (c < C) ? *reinterpret_cast<const f32x4*>(p + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ p, int C, int lane) const {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      int c = 256 * j + 4 * lane;
+      if (c < C) *reinterpret_cast<f32x4*>(p + c) = v[j];
+    }
+  }
+  __device__ __forceinline__ float sum() const {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    return wave_sum(s);
+  }
+};
+
+// LayerNorm over the channels of a Row (biased variance, eps inside sqrt; two-pass like the
+// reference's channel LayerNorm, libs/modeling/blocks.py:125-131).  Inactive chunks hold 0
+// and are excluded from the statistics.
+template <int NCH>
+__device__ __forceinline__ void row_layernorm(Row<NCH>& r, int C, int lane, const float* __restrict__ w,
+                                              const float* __restrict__ b, float eps = 1e-5f) {
+  const float inv_c = 1.0f / (float)C;
+  float mean = r.sum() * inv_c;
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    int c = 256 * j + 4 * lane;
+    if (c < C) {
+      r.v[j].x -= mean; r.v[j].y -= mean; r.v[j].z -= mean; r.v[j].w -= mean;
+      sq += (r.v[j].x * r.v[j].x + r.v[j].y * r.v[j].y) + (r.v[j].z * r.v[j].z + r.v[j].w * r.v[j].w);
+    }
+  }
+  float var = wave_sum(sq) * inv_c;
+  float rs = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    int c = 256 * j + 4 * lane;
+    if (c < C) {
+      f32x4 x = r.v[j];
+      x.x *= rs; x.y *= rs; x.z *= rs; x.w *= rs;
+      if (w != nullptr) {
+        f32x4 ww = *reinterpret_cast<const f32x4*>(w + c);
+        f32x4 bb = *reinterpret_cast<const f32x4*>(b + c);
+        x.x = x.x * ww.x + bb.x; x.y = x.y * ww.y + bb.y; x.z = x.z * ww.z + bb.z; x.w = x.w * ww.w + bb.w;
+      }
+      r.v[j] = x;
+    }
+  }
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  // exact GELU (nn.GELU default), libs/modeling/blocks.py:531
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+}  // namespace dcf
+
+// ---- host-side error plumbing -----------------------------------------------------------
+namespace dcf {
+void set_error(const char* fmt, ...);
+}
+#define DCF_CHECK(cond, ...)            \
+  do {                                  \
+    if (!(cond)) {                      \
+      dcf::set_error(__VA_ARGS__);      \
+      return -1;                        \
+    }                                   \
+  } while (0)
+#define DCF_HIP(expr)                                                              \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess) {                                                        \
+      dcf::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return -1;                                                                   \
+    }                                                                              \
+  } while (0)

@@ -1,0 +1,842 @@
+// Runtime of the grounding forward: owns the parameter table (bound by reference state_dict
+// name), repacked convolution weights, the HBM workspace arena and the launch sequence of
+// PtTransformerEarlyFusionIterative._drop_forward_eval (libs/modeling/model.py:480-565).
+//
+// HBM layout of one batched forward (B queries of one video, T0 padded clips, S = sum_l T0/2^l):
+//   P1, P2      [T0][E]          query-independent halves of vid_map (W[:, :D].vid, W[:, D:].shallow)
+//   X, R0..R6   [B*T0][E]        token-major activations (level l uses the first B*T_l rows)
+//   H2          [B*T0][2E]       xattn projection (AdaLN scale | shift)
+//   HID         [B*T0][4E]       FFN hidden
+//   F           [B*S][E+32]      feature pyramid, rows ordered [level][query][t]; the last 32
+//                                columns receive the refined logits (model.py:462-467)
+//   HA, HB      [B*S][E+32]      head trunk ping-pong
+//   mask_all, nbr_all [B*S]      per-row validity / k3-neighbour flags for every level
+// Nothing here synchronises the host: vid_len, the gate and every mask stay on the device.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/decafnet_hip.h"
+#include "attn.h"
+#include "common.h"
+#include "gemm.h"
+#include "heads.h"
+#include "postproc.h"
+#include "rowops.h"
+#include "score.h"
+
+namespace dcf {
+
+static thread_local std::string g_err;
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+// ---- tiny utility kernels ------------------------------------------------------------------
+// dst[perm(i0,i1,i2)] = src[i0][i1][i2];  p0..p2 give the destination axis order
+__global__ void k_permute3(const float* __restrict__ src, float* __restrict__ dst, int d0, int d1, int d2, int p0, int p1,
+                           int p2) {
+  const int n = d0 * d1 * d2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int idx[3];
+  idx[0] = i / (d1 * d2);
+  idx[1] = (i / d2) % d1;
+  idx[2] = i % d2;
+  const int dims[3] = {d0, d1, d2};
+  const int perm[3] = {p0, p1, p2};
+  const int o = (idx[perm[0]] * dims[perm[1]] + idx[perm[1]]) * dims[perm[2]] + idx[perm[2]];
+  dst[o] = src[i];
+}
+
+// masks_out[b][off_l + t] = mask_all[start_l + b*T_l + t]
+__global__ void k_masks_out(const uint8_t* __restrict__ mask_all, uint8_t* __restrict__ out, const LevelTable* lt) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = lt->start[lt->n_levels];
+  if (r >= total) return;
+  int l = 0;
+  while (l + 1 < lt->n_levels && r >= lt->start[l + 1]) ++l;
+  const int rel = r - lt->start[l];
+  const int b = rel / lt->T[l], t = rel - b * lt->T[l];
+  out[(int64_t)b * lt->S + lt->off[l] + t] = mask_all[r];
+}
+
+struct Bound {
+  const float* p = nullptr;
+  std::vector<int64_t> shape;
+  int64_t numel() const {
+    int64_t n = 1;
+    for (auto s : shape) n *= s;
+    return n;
+  }
+};
+
+struct EncW {   // one TransformerEncoder of vid_net
+  const float *ln_attn_w, *ln_attn_b, *dw_q, *dw_k, *dw_v, *qn_w, *qn_b, *kn_w, *kn_b, *vn_w, *vn_b;
+  const float *wq, *bq, *wk, *bk, *wv, *bv, *wp, *bp, *ls_attn;
+  const float *ln_ffn_w, *ln_ffn_b, *fc_w, *fc_b, *pj_w, *pj_b, *ls_ffn;
+};
+struct DecW {   // one TransformerDecoder of the fusion
+  const float *ln_q_w, *ln_q_b, *ln_kv_w, *ln_kv_b, *dw, *qn_w, *qn_b;
+  const float *wq, *bq, *wk, *bk, *wv, *bv, *wp, *bp;
+  const float *ln_ffn_w, *ln_ffn_b, *fc_w, *fc_b, *pj_w, *pj_b, *ls_ffn;
+};
+struct HeadW {
+  std::vector<const float*> conv;            // packed [N][3][Cin]
+  std::vector<const float*> ln_w, ln_b;
+  const float* out_w;                        // packed [NO][3][Cin]
+  const float* out_b;
+};
+
+struct Plan {    // geometry for one (T0, B)
+  int T0 = 0, B = 0;
+  LevelTable lt{};
+  LevelTable* d_lt = nullptr;
+};
+
+}  // namespace dcf
+
+using namespace dcf;
+
+struct dcf_model {
+  dcf_config cfg{};
+  std::unordered_map<std::string, Bound> bound;
+  std::vector<float*> owned;                 // packed weights
+  bool finalized = false;
+  const float* pe = nullptr;
+  int64_t pe_T = 0;
+
+  // resolved weights
+  const float *vid_map_w = nullptr, *vid_map_b = nullptr;
+  std::vector<DecW> dec;
+  const float *fus_out_w = nullptr, *fus_out_b = nullptr;
+  const float *embd_fc_w = nullptr, *embd_fc_b = nullptr;
+  std::vector<const float*> embd_conv, embd_ln_w, embd_ln_b;
+  std::vector<EncW> stem, branch;
+  HeadW cls1, cls2, reg;
+  std::vector<float> reg_scales;             // host copy of reg_head.scales.{l}.scale
+  const float *tcn_in_w = nullptr, *tcn_in_b = nullptr, *tcn_out_w = nullptr, *tcn_out_b = nullptr;
+  std::vector<const float*> tcn_wd, tcn_bd, tcn_wp, tcn_bp, tcn_lnw, tcn_lnb;
+
+  // workspace
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  std::vector<Plan> plans;
+  TextMeta* h_meta = nullptr;                // pinned host
+  TextMeta* d_meta = nullptr;
+  // last-forward bookkeeping for dcf_debug_copy
+  struct {
+    float *correl = nullptr, *gate = nullptr, *vidmap = nullptr, *fused = nullptr, *F = nullptr;
+    int nq = 0, T0 = 0, B = 0, S = 0;
+  } dbg;
+  float* dbg_vidmap = nullptr;
+  float* dbg_fused = nullptr;
+  bool keep_debug = false;
+};
+
+namespace dcf {
+
+static int free_model(dcf_model* m) {
+  for (float* p : m->owned) (void)hipFree(p);
+  m->owned.clear();
+  for (auto& pl : m->plans) if (pl.d_lt) (void)hipFree(pl.d_lt);
+  m->plans.clear();
+  if (m->arena) (void)hipFree(m->arena);
+  if (m->h_meta) (void)hipHostFree(m->h_meta);
+  if (m->d_meta) (void)hipFree(m->d_meta);
+  return 0;
+}
+
+static int get(dcf_model* m, const std::string& name, std::initializer_list<int64_t> shape, const float** out) {
+  auto it = m->bound.find(name);
+  DCF_CHECK(it != m->bound.end(), "parameter '%s' is not bound", name.c_str());
+  const Bound& b = it->second;
+  int64_t want = 1;
+  for (auto s : shape) want *= s;
+  DCF_CHECK(b.numel() == want, "parameter '%s' has %lld elements, expected %lld", name.c_str(), (long long)b.numel(),
+            (long long)want);
+  *out = b.p;
+  return 0;
+}
+
+// repack a 3-d tensor [d0][d1][d2] with destination axis order (p0,p1,p2); result owned by the model
+static int pack3(dcf_model* m, const float* src, int d0, int d1, int d2, int p0, int p1, int p2, hipStream_t st,
+                 const float** out) {
+  float* dst = nullptr;
+  const size_t n = (size_t)d0 * d1 * d2;
+  DCF_HIP(hipMalloc(&dst, n * sizeof(float)));
+  m->owned.push_back(dst);
+  hipLaunchKernelGGL(k_permute3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, d0, d1, d2, p0, p1, p2);
+  DCF_HIP(hipGetLastError());
+  *out = dst;
+  return 0;
+}
+
+#define GET(name, shape, dst) do { if (get(m, (name), shape, &(dst))) return -1; } while (0)
+#define SH(...) std::initializer_list<int64_t>{__VA_ARGS__}
+
+static int resolve_encoder(dcf_model* m, const std::string& p, int E, hipStream_t st, EncW& w) {
+  const float* t;
+  GET(p + ".ln_attn.weight", SH(E), w.ln_attn_w); GET(p + ".ln_attn.bias", SH(E), w.ln_attn_b);
+  GET(p + ".attn.q_conv.conv.weight", SH(E, 3), t); if (pack3(m, t, 1, E, 3, 0, 2, 1, st, &w.dw_q)) return -1;
+  GET(p + ".attn.k_conv.conv.weight", SH(E, 3), t); if (pack3(m, t, 1, E, 3, 0, 2, 1, st, &w.dw_k)) return -1;
+  GET(p + ".attn.v_conv.conv.weight", SH(E, 3), t); if (pack3(m, t, 1, E, 3, 0, 2, 1, st, &w.dw_v)) return -1;
+  GET(p + ".attn.q_norm.weight", SH(E), w.qn_w); GET(p + ".attn.q_norm.bias", SH(E), w.qn_b);
+  GET(p + ".attn.k_norm.weight", SH(E), w.kn_w); GET(p + ".attn.k_norm.bias", SH(E), w.kn_b);
+  GET(p + ".attn.v_norm.weight", SH(E), w.vn_w); GET(p + ".attn.v_norm.bias", SH(E), w.vn_b);
+  GET(p + ".attn.attn.query.weight", SH(E, E), w.wq); GET(p + ".attn.attn.query.bias", SH(E), w.bq);
+  GET(p + ".attn.attn.key.weight", SH(E, E), w.wk); GET(p + ".attn.attn.key.bias", SH(E), w.bk);
+  GET(p + ".attn.attn.value.weight", SH(E, E), w.wv); GET(p + ".attn.attn.value.bias", SH(E), w.bv);
+  GET(p + ".attn.attn.proj.weight", SH(E, E), w.wp); GET(p + ".attn.attn.proj.bias", SH(E), w.bp);
+  GET(p + ".drop_path_attn.scale", SH(E), w.ls_attn);
+  GET(p + ".ln_ffn.weight", SH(E), w.ln_ffn_w); GET(p + ".ln_ffn.bias", SH(E), w.ln_ffn_b);
+  GET(p + ".ffn.fc.weight", SH(4 * E, E), w.fc_w); GET(p + ".ffn.fc.bias", SH(4 * E), w.fc_b);
+  GET(p + ".ffn.proj.weight", SH(E, 4 * E), w.pj_w); GET(p + ".ffn.proj.bias", SH(E), w.pj_b);
+  GET(p + ".drop_path_ffn.scale", SH(E), w.ls_ffn);
+  return 0;
+}
+
+static int resolve_head(dcf_model* m, const std::string& p, const std::string& out_name, int C, int NO, int layers,
+                        hipStream_t st, HeadW& h) {
+  const float* t;
+  for (int i = 0; i < layers; ++i) {
+    const std::string s = std::to_string(i);
+    GET(p + ".convs." + s + ".conv.weight", SH(C, C, 3), t);
+    const float* pk;
+    if (pack3(m, t, C, C, 3, 0, 2, 1, st, &pk)) return -1;      // (N, Cin, 3) -> [N][3][Cin]
+    h.conv.push_back(pk);
+    const float *lw, *lb;
+    GET(p + ".norms." + s + ".weight", SH(C), lw); GET(p + ".norms." + s + ".bias", SH(C), lb);
+    h.ln_w.push_back(lw); h.ln_b.push_back(lb);
+  }
+  GET(p + "." + out_name + ".conv.weight", SH(NO, C, 3), t);
+  if (pack3(m, t, NO, C, 3, 0, 2, 1, st, &h.out_w)) return -1;
+  GET(p + "." + out_name + ".conv.bias", SH(NO), h.out_b);
+  return 0;
+}
+
+static int finalize(dcf_model* m, hipStream_t st) {
+  const dcf_config& c = m->cfg;
+  const int E = c.E, D = c.D, TE = c.TE, L = c.n_levels;
+  const int Din = c.msf ? 2 * D : D;
+  for (float* p : m->owned) (void)hipFree(p);
+  m->owned.clear();
+  m->dec.clear(); m->stem.clear(); m->branch.clear();
+  m->embd_conv.clear(); m->embd_ln_w.clear(); m->embd_ln_b.clear();
+  m->cls1 = HeadW(); m->cls2 = HeadW(); m->reg = HeadW();
+  m->tcn_wd.clear(); m->tcn_bd.clear(); m->tcn_wp.clear(); m->tcn_bp.clear(); m->tcn_lnw.clear(); m->tcn_lnb.clear();
+  const float* t;
+
+  GET("vid_map.conv.weight", SH(E, Din), m->vid_map_w); GET("vid_map.conv.bias", SH(E), m->vid_map_b);
+  for (int i = 0; i < c.fusion_layers; ++i) {
+    const std::string p = "fusion.layers." + std::to_string(i);
+    DecW w{};
+    GET(p + ".ln_xattn_q.weight", SH(E), w.ln_q_w); GET(p + ".ln_xattn_q.bias", SH(E), w.ln_q_b);
+    GET(p + ".ln_xattn_kv.weight", SH(TE), w.ln_kv_w); GET(p + ".ln_xattn_kv.bias", SH(TE), w.ln_kv_b);
+    GET(p + ".xattn.q_conv.conv.weight", SH(E, 3), t); if (pack3(m, t, 1, E, 3, 0, 2, 1, st, &w.dw)) return -1;
+    GET(p + ".xattn.q_norm.weight", SH(E), w.qn_w); GET(p + ".xattn.q_norm.bias", SH(E), w.qn_b);
+    GET(p + ".xattn.xattn.query.weight", SH(E, E), w.wq); GET(p + ".xattn.xattn.query.bias", SH(E), w.bq);
+    GET(p + ".xattn.xattn.key.weight", SH(E, TE), w.wk); GET(p + ".xattn.xattn.key.bias", SH(E), w.bk);
+    GET(p + ".xattn.xattn.value.weight", SH(E, TE), w.wv); GET(p + ".xattn.xattn.value.bias", SH(E), w.bv);
+    GET(p + ".xattn.xattn.proj.weight", SH(2 * E, E), w.wp); GET(p + ".xattn.xattn.proj.bias", SH(2 * E), w.bp);
+    GET(p + ".ln_ffn.weight", SH(E), w.ln_ffn_w); GET(p + ".ln_ffn.bias", SH(E), w.ln_ffn_b);
+    GET(p + ".ffn.fc.weight", SH(4 * E, E), w.fc_w); GET(p + ".ffn.fc.bias", SH(4 * E), w.fc_b);
+    GET(p + ".ffn.proj.weight", SH(E, 4 * E), w.pj_w); GET(p + ".ffn.proj.bias", SH(E), w.pj_b);
+    GET(p + ".drop_path_ffn.scale", SH(E), w.ls_ffn);
+    m->dec.push_back(w);
+  }
+  GET("fusion.ln_out.weight", SH(E), m->fus_out_w); GET("fusion.ln_out.bias", SH(E), m->fus_out_b);
+  GET("vid_net.embd_fc.conv.weight", SH(E, E), m->embd_fc_w); GET("vid_net.embd_fc.conv.bias", SH(E), m->embd_fc_b);
+  for (int i = 0; i < c.n_embd_convs; ++i) {
+    const std::string s = std::to_string(i);
+    GET("vid_net.embd_convs." + s + ".conv.weight", SH(E, E, 3), t);
+    const float* pk;
+    if (pack3(m, t, E, E, 3, 0, 2, 1, st, &pk)) return -1;
+    m->embd_conv.push_back(pk);
+    const float *lw, *lb;
+    GET("vid_net.embd_norms." + s + ".weight", SH(E), lw); GET("vid_net.embd_norms." + s + ".bias", SH(E), lb);
+    m->embd_ln_w.push_back(lw); m->embd_ln_b.push_back(lb);
+  }
+  for (int i = 0; i < c.n_stem; ++i) {
+    EncW w{};
+    if (resolve_encoder(m, "vid_net.stem." + std::to_string(i), E, st, w)) return -1;
+    m->stem.push_back(w);
+  }
+  for (int i = 0; i < L; ++i) {
+    EncW w{};
+    if (resolve_encoder(m, "vid_net.branch." + std::to_string(i), E, st, w)) return -1;
+    m->branch.push_back(w);
+  }
+  if (resolve_head(m, "cls_head", "cls_head", E, 1, c.head_layers, st, m->cls1)) return -1;
+  if (resolve_head(m, "cls_head2", "cls_head", E + TCN_HID, 1, c.head_layers, st, m->cls2)) return -1;
+  if (resolve_head(m, "reg_head", "reg_head", E + TCN_HID, 2, c.head_layers, st, m->reg)) return -1;
+  m->reg_scales.assign(L, 1.f);
+  for (int l = 0; l < L; ++l) {
+    GET("reg_head.scales." + std::to_string(l) + ".scale", SH(1), t);
+    DCF_HIP(hipMemcpyAsync(&m->reg_scales[l], t, sizeof(float), hipMemcpyDeviceToHost, st));
+  }
+  // TCN (refine): in (32, L, 1) -> [L][32]; dilated (32,32,3) -> [3][ci][co]; 1x1 (32,32,1) -> [ci][co]
+  GET("refine.conv_1x1.weight", SH(TCN_HID, L), t); if (pack3(m, t, 1, TCN_HID, L, 0, 2, 1, st, &m->tcn_in_w)) return -1;
+  GET("refine.conv_1x1.bias", SH(TCN_HID), m->tcn_in_b);
+  for (int i = 0; i < L; ++i) {
+    const std::string p = "refine.layers." + std::to_string(i);
+    const float* pk;
+    GET(p + ".conv_dilated.weight", SH(TCN_HID, TCN_HID, 3), t);
+    if (pack3(m, t, TCN_HID, TCN_HID, 3, 2, 1, 0, st, &pk)) return -1;
+    m->tcn_wd.push_back(pk);
+    GET(p + ".conv_dilated.bias", SH(TCN_HID), t); m->tcn_bd.push_back(t);
+    GET(p + ".conv_1x1.weight", SH(TCN_HID, TCN_HID), t);
+    if (pack3(m, t, 1, TCN_HID, TCN_HID, 0, 2, 1, st, &pk)) return -1;
+    m->tcn_wp.push_back(pk);
+    GET(p + ".conv_1x1.bias", SH(TCN_HID), t); m->tcn_bp.push_back(t);
+    GET(p + ".norm.weight", SH(TCN_HID), t); m->tcn_lnw.push_back(t);
+    GET(p + ".norm.bias", SH(TCN_HID), t); m->tcn_lnb.push_back(t);
+  }
+  GET("refine.conv_out.weight", SH(TCN_HID, TCN_HID), t);
+  if (pack3(m, t, 1, TCN_HID, TCN_HID, 0, 2, 1, st, &m->tcn_out_w)) return -1;
+  GET("refine.conv_out.bias", SH(TCN_HID), m->tcn_out_b);
+  DCF_HIP(hipStreamSynchronize(st));
+  for (auto& pl : m->plans) if (pl.d_lt) (void)hipFree(pl.d_lt);
+  m->plans.clear();                           // reg scales live in the level tables
+  m->finalized = true;
+  return 0;
+}
+
+// ---- workspace ------------------------------------------------------------------------------
+struct Arena {
+  char* base;
+  size_t off = 0, cap;
+  bool dry;
+  template <typename T>
+  T* take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = dry ? nullptr : reinterpret_cast<T*>(base + off);
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+struct Buffers {
+  float *P1, *P2, *tn, *partial, *correl, *gate;
+  uint8_t *mask_all, *nbr_all, *kvmask;
+  float *X, *R[7], *H2, *HID, *F, *HA, *HB, *logits1, *tcnA, *tcnB, *kvn, *Kt, *Vt;
+};
+
+static void carve(Arena& a, const dcf_config& c, int T0, int B, int nq, int S, int Lk, Buffers& b) {
+  const size_t rows0 = (size_t)B * T0, rowsAll = (size_t)B * S;
+  const int E = c.E, EH = c.E + TCN_HID;
+  b.P1 = a.take<float>((size_t)T0 * E);
+  b.P2 = a.take<float>((size_t)T0 * E);
+  b.tn = a.take<float>((size_t)nq * c.D);
+  b.partial = a.take<float>((size_t)SCORE_SLICES * (nq + 1) * T0);
+  b.correl = a.take<float>((size_t)nq * T0);
+  b.gate = a.take<float>(rows0);
+  b.mask_all = a.take<uint8_t>(rowsAll);
+  b.nbr_all = a.take<uint8_t>(rowsAll);
+  b.kvmask = a.take<uint8_t>((size_t)B * Lk);
+  b.X = a.take<float>(rows0 * E);
+  for (int i = 0; i < 7; ++i) b.R[i] = a.take<float>(rows0 * E);
+  b.H2 = a.take<float>(rows0 * 2 * E);
+  b.HID = a.take<float>(rows0 * 4 * E);
+  b.F = a.take<float>(rowsAll * EH);
+  b.HA = a.take<float>(rowsAll * EH);
+  b.HB = a.take<float>(rowsAll * EH);
+  b.logits1 = a.take<float>(rowsAll);
+  b.tcnA = a.take<float>(rows0 * TCN_HID);
+  b.tcnB = a.take<float>(rows0 * TCN_HID);
+  b.kvn = a.take<float>((size_t)B * Lk * c.TE);
+  b.Kt = a.take<float>((size_t)B * Lk * E);
+  b.Vt = a.take<float>((size_t)B * Lk * E);
+}
+
+static int get_plan(dcf_model* m, int T0, int B, hipStream_t st, Plan** out) {
+  for (auto& p : m->plans)
+    if (p.T0 == T0 && p.B == B) { *out = &p; return 0; }
+  Plan p;
+  p.T0 = T0; p.B = B;
+  LevelTable& lt = p.lt;
+  lt.n_levels = m->cfg.n_levels; lt.B = B;
+  int acc = 0;
+  for (int l = 0; l < lt.n_levels; ++l) {
+    lt.T[l] = T0 >> l;
+    lt.off[l] = acc;
+    lt.start[l] = B * acc;
+    lt.scale[l] = m->reg_scales[l];
+    acc += lt.T[l];
+  }
+  lt.S = acc;
+  lt.start[lt.n_levels] = B * acc;
+  DCF_HIP(hipMalloc(&p.d_lt, sizeof(LevelTable)));
+  DCF_HIP(hipMemcpyAsync(p.d_lt, &p.lt, sizeof(LevelTable), hipMemcpyHostToDevice, st));
+  DCF_HIP(hipStreamSynchronize(st));          // p.lt is copied below; keep the source alive until done
+  m->plans.push_back(p);
+  *out = &m->plans.back();
+  return 0;
+}
+
+static GemmArgs gemm(const float* A, int64_t lda, const float* W, const float* bias, float* C, int64_t ldc, int M, int N,
+                     int K) {
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.W = W; g.ldw = 0; g.bias = bias; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+  return g;
+}
+
+#define TRY(x) do { if ((x) != 0) return -1; } while (0)
+
+// TransformerEncoder (vid_net) at one level.  Xin: [B*T_in][ldx]; output rows [B*T_out] at Xout (ld ldo).
+static int run_encoder(dcf_model* m, const EncW& w, Buffers& b, const float* Xin, int64_t ldx, const uint8_t* mask_in,
+                       const uint8_t* mask_out, int B, int T_in, int stride, float* Xout, int64_t ldo, hipStream_t st) {
+  const dcf_config& c = m->cfg;
+  const int E = c.E, To = T_in / stride, rows = B * To;
+  EncPreArgs ep{};
+  ep.X = Xin; ep.ldx = ldx; ep.mask_in = mask_in; ep.ln_w = w.ln_attn_w; ep.ln_b = w.ln_attn_b;
+  ep.dw_q = w.dw_q; ep.dw_k = w.dw_k; ep.dw_v = w.dw_v;
+  ep.qn_w = w.qn_w; ep.qn_b = w.qn_b; ep.kn_w = w.kn_w; ep.kn_b = w.kn_b; ep.vn_w = w.vn_w; ep.vn_b = w.vn_b;
+  ep.Qc = b.R[0]; ep.Kc = b.R[1]; ep.Vc = b.R[2]; ep.Skip = stride == 2 ? b.R[3] : nullptr;
+  ep.B = B; ep.T_in = T_in; ep.C = E;
+  TRY(launch_enc_pre(ep, stride, st));
+  GemmArgs g3[3] = {gemm(b.R[0], E, w.wq, w.bq, b.R[4], E, rows, E, E), gemm(b.R[1], E, w.wk, w.bk, b.R[5], E, rows, E, E),
+                    gemm(b.R[2], E, w.wv, w.bv, b.R[6], E, rows, E, E)};
+  TRY(launch_gemm(g3, 3, A_ROWS, st));
+  LocalAttnArgs la{b.R[4], b.R[5], b.R[6], mask_out, b.R[0], B, To, E, c.vid_heads, c.win};
+  TRY(launch_local_attn(la, st));
+  // x' = skip * mask + ls_attn * (proj(ctx) + b)                       (blocks.py:586)
+  GemmArgs gp = gemm(b.R[0], E, w.wp, w.bp, b.R[1], E, rows, E, E);
+  gp.flags = G_RES | G_RES_MASK; gp.rowmask = mask_out; gp.ls = w.ls_attn;
+  if (stride == 2) { gp.R = b.R[3]; gp.ldr = E; } else { gp.R = Xin; gp.ldr = ldx; }
+  TRY(launch_gemm(&gp, 1, A_ROWS, st));
+  LnArgs ln{}; ln.X = b.R[1]; ln.ldx = E; ln.Y = b.R[2]; ln.ldy = E; ln.w = w.ln_ffn_w; ln.b = w.ln_ffn_b; ln.rows = rows; ln.C = E;
+  TRY(launch_ln(ln, st));
+  GemmArgs gf = gemm(b.R[2], E, w.fc_w, w.fc_b, b.HID, 4 * E, rows, 4 * E, E);
+  gf.flags = G_GELU;
+  TRY(launch_gemm(&gf, 1, A_ROWS, st));
+  // out = x' + ls_ffn * ((ffn) * mask)                                  (blocks.py:589-590)
+  GemmArgs go = gemm(b.HID, 4 * E, w.pj_w, w.pj_b, Xout, ldo, rows, E, 4 * E);
+  go.flags = G_RES | G_OUT_MASK; go.rowmask = mask_out; go.ls = w.ls_ffn; go.R = b.R[1]; go.ldr = E;
+  TRY(launch_gemm(&go, 1, A_ROWS, st));
+  return 0;
+}
+
+// one head trunk (n x [k3 conv, LN, ReLU]) + output conv over the whole pyramid
+static int run_head(dcf_model* m, const HeadW& h, Buffers& b, const Plan& pl, int Cin, int NO, int mode, int query_major,
+                    float* out, hipStream_t st) {
+  const int rowsAll = pl.B * pl.lt.S;
+  const int ldf = m->cfg.E + TCN_HID;
+  const float* in = b.F;
+  int64_t ldin = ldf;
+  for (size_t i = 0; i < h.conv.size(); ++i) {
+    GemmArgs g = gemm(in, ldin, h.conv[i], nullptr, b.HA, Cin, rowsAll, Cin, 3 * Cin);
+    g.cin = Cin; g.nbr = b.nbr_all;
+    TRY(launch_gemm(&g, 1, A_ROWS_TAP3, st));
+    LnArgs ln{}; ln.X = b.HA; ln.ldx = Cin; ln.Y = b.HB; ln.ldy = Cin; ln.w = h.ln_w[i]; ln.b = h.ln_b[i];
+    ln.rows = rowsAll; ln.C = Cin; ln.relu = 1;
+    TRY(launch_ln(ln, st));
+    in = b.HB; ldin = Cin;
+  }
+  ConvOutArgs co{};
+  co.X = in; co.ldx = ldin; co.nbr = b.nbr_all; co.W = h.out_w; co.bias = h.out_b; co.lt = pl.d_lt; co.out = out;
+  co.rows = rowsAll; co.C = Cin; co.NO = NO; co.mode = mode; co.query_major = query_major;
+  TRY(launch_conv_out(co, st));
+  return 0;
+}
+
+static int forward(dcf_model* m, const float* vid, const float* shallow, const uint8_t* vid_mask, int T0, int nq,
+                   const float* const* text, const uint8_t* const* text_mask, const int32_t* text_len,
+                   const float* text_cls, float* logits_out, float* offsets_out, uint8_t* masks_out, hipStream_t st) {
+  const dcf_config& c = m->cfg;
+  const int E = c.E, D = c.D, L = c.n_levels;
+  DCF_CHECK(m->finalized, "dcf_forward_eval: model not finalized");
+  DCF_CHECK(T0 > 0 && nq > 0, "dcf_forward_eval: empty input");
+  DCF_CHECK(T0 % (1 << (L - 1)) == 0, "T=%d must be a multiple of 2^(levels-1)=%d", T0, 1 << (L - 1));
+  const int half = c.win / 2;
+  DCF_CHECK(half == 0 || (T0 >> (L - 1)) % half == 0, "T=%d: coarsest level must be a multiple of win//2=%d (blocks.py:216)", T0, half);
+  if (c.use_abs_pe) DCF_CHECK(m->pe && m->pe_T == T0, "position encoding for T=%d not set (dcf_model_set_pe)", T0);
+  const int Bmax = std::min(nq, c.max_batch > 0 ? c.max_batch : 8);
+  DCF_CHECK(Bmax <= DCF_MAX_BATCH, "max_batch %d > %d", Bmax, DCF_MAX_BATCH);
+  int Lk = 1;
+  for (int q = 0; q < nq; ++q) {
+    DCF_CHECK(text_len[q] >= 1 && text[q], "text %d is empty", q);
+    Lk = std::max(Lk, (int)text_len[q]);
+  }
+  int S = 0;
+  for (int l = 0; l < L; ++l) S += T0 >> l;
+
+  // ---- workspace
+  Buffers b{};
+  {
+    Arena dry{nullptr, 0, 0, true};
+    carve(dry, c, T0, Bmax, nq, S, Lk, b);
+    if (dry.off > m->arena_bytes) {
+      DCF_HIP(hipStreamSynchronize(st));
+      if (m->arena) DCF_HIP(hipFree(m->arena));
+      m->arena = nullptr; m->arena_bytes = 0;
+      DCF_HIP(hipMalloc(&m->arena, dry.off));
+      m->arena_bytes = dry.off;
+    }
+    Arena real{m->arena, 0, m->arena_bytes, false};
+    carve(real, c, T0, Bmax, nq, S, Lk, b);
+  }
+  if (!m->h_meta) {
+    DCF_HIP(hipHostMalloc(&m->h_meta, sizeof(TextMeta)));
+    DCF_HIP(hipMalloc(&m->d_meta, sizeof(TextMeta)));
+  }
+
+  // ---- per video: sidekick scores and the query-independent halves of vid_map
+  ScoreArgs sa{shallow, text_cls, b.tn, b.partial, b.correl, D, T0, nq, c.norm};
+  TRY(launch_sidekick(sa, st));
+  const int Din = c.msf ? 2 * D : D;
+  {
+    GemmArgs g = gemm(vid, T0, m->vid_map_w, nullptr, b.P1, E, T0, E, D);
+    g.ldw = Din;
+    TRY(launch_gemm(&g, 1, A_CHANMAJOR, st));
+    if (c.msf) {
+      GemmArgs g2 = gemm(shallow, T0, m->vid_map_w + D, nullptr, b.P2, E, T0, E, D);
+      g2.ldw = Din;
+      TRY(launch_gemm(&g2, 1, A_CHANMAJOR, st));
+    }
+  }
+
+  for (int q0 = 0; q0 < nq; q0 += Bmax) {
+    const int B = std::min(Bmax, nq - q0);
+    Plan* pl;
+    TRY(get_plan(m, T0, B, st, &pl));
+    const LevelTable& lt = pl->lt;
+    const int rows0 = B * T0, rowsAll = B * S;
+
+    // ---- gate + masks for every level
+    GateArgs ga{b.correl, vid_mask, b.gate, b.mask_all, T0, B, q0, c.sn, c.msf, (double)c.sratio};
+    TRY(launch_gate(ga, st));
+    for (int l = 1; l < L; ++l) TRY(launch_mask_down(b.mask_all + lt.start[l - 1], b.mask_all + lt.start[l], B * lt.T[l], st));
+    for (int l = 0; l < L; ++l) TRY(launch_rowflags(b.mask_all + lt.start[l], b.nbr_all + lt.start[l], lt.T[l], B * lt.T[l], st));
+    const uint8_t* mask0 = b.mask_all;
+
+    // ---- vid_map (model.py:543-555)
+    TRY(launch_vidmap_combine(b.P1, c.msf ? b.P2 : nullptr, m->vid_map_b, b.gate, mask0, b.X, T0, rows0, E, st));
+    if (m->keep_debug && m->dbg_vidmap) DCF_HIP(hipMemcpyAsync(m->dbg_vidmap, b.X, (size_t)rows0 * E * 4, hipMemcpyDeviceToDevice, st));
+
+    // ---- text side: pointers of this chunk
+    DCF_HIP(hipStreamSynchronize(st));        // h_meta is reused between chunks
+    for (int i = 0; i < B; ++i) {
+      m->h_meta->text[i] = text[q0 + i];
+      m->h_meta->text_mask[i] = text_mask ? text_mask[q0 + i] : nullptr;
+      m->h_meta->len[i] = text_len[q0 + i];
+    }
+    DCF_HIP(hipMemcpyAsync(m->d_meta, m->h_meta, sizeof(TextMeta), hipMemcpyHostToDevice, st));
+
+    // ---- fusion: XAttNFusion (fusion.py:56-66)
+    for (size_t li = 0; li < m->dec.size(); ++li) {
+      const DecW& w = m->dec[li];
+      DecPreArgs dp{b.X, E, mask0, w.ln_q_w, w.ln_q_b, w.dw, w.qn_w, w.qn_b, b.R[0], b.R[1], B, T0, E};
+      TRY(launch_dec_pre(dp, st));
+      GemmArgs gq = gemm(b.R[0], E, w.wq, w.bq, b.R[2], E, rows0, E, E);
+      TRY(launch_gemm(&gq, 1, A_ROWS, st));
+      TextLnArgs tl{m->d_meta, b.kvn, b.kvmask, w.ln_kv_w, w.ln_kv_b, Lk, c.TE};
+      TRY(launch_text_ln(tl, B, st));
+      GemmArgs gkv[2] = {gemm(b.kvn, c.TE, w.wk, w.bk, b.Kt, E, B * Lk, E, c.TE), gemm(b.kvn, c.TE, w.wv, w.bv, b.Vt, E, B * Lk, E, c.TE)};
+      TRY(launch_gemm(gkv, 2, A_ROWS, st));
+      XAttnArgs xa{b.R[2], b.Kt, b.Vt, b.kvmask, b.R[0], B, T0, Lk, E, c.fusion_heads};
+      TRY(launch_xattn(xa, st));
+      GemmArgs gh = gemm(b.R[0], E, w.wp, w.bp, b.H2, 2 * E, rows0, 2 * E, E);
+      TRY(launch_gemm(&gh, 1, A_ROWS, st));
+      TRY(launch_dec_mid(b.R[1], b.H2, w.ln_ffn_w, w.ln_ffn_b, b.R[2], b.R[0], rows0, E, st));
+      GemmArgs gf = gemm(b.R[0], E, w.fc_w, w.fc_b, b.HID, 4 * E, rows0, 4 * E, E);
+      gf.flags = G_GELU;
+      TRY(launch_gemm(&gf, 1, A_ROWS, st));
+      GemmArgs go = gemm(b.HID, 4 * E, w.pj_w, w.pj_b, b.X, E, rows0, E, 4 * E);
+      go.flags = G_RES | G_OUT_MASK; go.rowmask = mask0; go.ls = w.ls_ffn; go.R = b.R[2]; go.ldr = E;
+      TRY(launch_gemm(&go, 1, A_ROWS, st));
+    }
+    {
+      LnArgs ln{}; ln.X = b.X; ln.ldx = E; ln.Y = b.R[0]; ln.ldy = E; ln.w = m->fus_out_w; ln.b = m->fus_out_b; ln.rows = rows0; ln.C = E;
+      TRY(launch_ln(ln, st));
+      if (m->keep_debug && m->dbg_fused) DCF_HIP(hipMemcpyAsync(m->dbg_fused, b.R[0], (size_t)rows0 * E * 4, hipMemcpyDeviceToDevice, st));
+    }
+
+    // ---- vid_net: VideoTransformer.forward (video_net.py:123-164)
+    {
+      GemmArgs ge = gemm(b.R[0], E, m->embd_fc_w, m->embd_fc_b, b.X, E, rows0, E, E);
+      ge.flags = G_AMASK; ge.rowmask = mask0;
+      TRY(launch_gemm(&ge, 1, A_ROWS, st));
+      for (int i = 0; i < c.n_embd_convs; ++i) {
+        GemmArgs g = gemm(b.X, E, m->embd_conv[i], nullptr, b.R[0], E, rows0, E, 3 * E);
+        g.cin = E; g.nbr = b.nbr_all;
+        TRY(launch_gemm(&g, 1, A_ROWS_TAP3, st));
+        LnArgs ln{}; ln.X = b.R[0]; ln.ldx = E; ln.Y = b.X; ln.ldy = E; ln.w = m->embd_ln_w[i]; ln.b = m->embd_ln_b[i];
+        ln.rows = rows0; ln.C = E; ln.relu = 1;
+        if (c.use_abs_pe && i == c.n_embd_convs - 1) { ln.pe = m->pe; ln.mask = mask0; ln.T = T0; }
+        TRY(launch_ln(ln, st));
+      }
+      if (c.use_abs_pe && c.n_embd_convs == 0) {
+        LnArgs ln{}; ln.X = b.X; ln.ldx = E; ln.Y = b.X; ln.ldy = E; ln.rows = rows0; ln.C = E; ln.skip_ln = 1;
+        ln.pe = m->pe; ln.mask = mask0; ln.T = T0;
+        TRY(launch_ln(ln, st));
+      }
+      for (size_t i = 0; i < m->stem.size(); ++i) {
+        // stem layers work in place at level 0: out -> R[3] is free for stride 1, then copy back via swap of roles
+        TRY(run_encoder(m, m->stem[i], b, b.X, E, mask0, mask0, B, T0, 1, b.R[3], E, st));
+        DCF_HIP(hipMemcpyAsync(b.X, b.R[3], (size_t)rows0 * E * 4, hipMemcpyDeviceToDevice, st));
+      }
+      const int ldf = E + TCN_HID;
+      const float* xin = b.X;
+      int64_t ldx = E;
+      for (int l = 0; l < L; ++l) {
+        const int stride = l > 0 ? 2 : 1;
+        const uint8_t* mi = b.mask_all + lt.start[l > 0 ? l - 1 : 0];
+        const uint8_t* mo = b.mask_all + lt.start[l];
+        float* xo = b.F + (int64_t)lt.start[l] * ldf;
+        TRY(run_encoder(m, m->branch[l], b, xin, ldx, mi, mo, B, l > 0 ? lt.T[l - 1] : T0, stride, xo, ldf, st));
+        xin = xo; ldx = ldf;
+      }
+    }
+
+    // ---- heads: fuse_and_predict (model.py:442-471)
+    TRY(run_head(m, m->cls1, b, *pl, E, 1, 0, 0, b.logits1, st));
+    {
+      RefineArgs ra{};
+      ra.logits1 = b.logits1; ra.lt = pl->d_lt; ra.mask_all = b.mask_all;
+      ra.w_in = m->tcn_in_w; ra.b_in = m->tcn_in_b;
+      ra.host_w_dil = m->tcn_wd.data(); ra.host_b_dil = m->tcn_bd.data(); ra.host_w_pw = m->tcn_wp.data();
+      ra.host_b_pw = m->tcn_bp.data(); ra.host_ln_w = m->tcn_lnw.data(); ra.host_ln_b = m->tcn_lnb.data();
+      ra.w_out = m->tcn_out_w; ra.b_out = m->tcn_out_b;
+      ra.bufA = b.tcnA; ra.bufB = b.tcnB; ra.F = b.F; ra.ldf = E + TCN_HID; ra.E = E;
+      ra.B = B; ra.T0 = T0; ra.n_levels = L; ra.n_layers = L;
+      TRY(launch_refine(ra, lt, st));
+    }
+    TRY(run_head(m, m->cls2, b, *pl, E + TCN_HID, 1, 0, 1, logits_out + (int64_t)q0 * S, st));
+    TRY(run_head(m, m->reg, b, *pl, E + TCN_HID, 2, 1, 1, offsets_out + (int64_t)q0 * S * 2, st));
+    hipLaunchKernelGGL(k_masks_out, dim3((rowsAll + 255) / 256), dim3(256), 0, st, (const uint8_t*)b.mask_all,
+                       masks_out + (int64_t)q0 * S, (const LevelTable*)pl->d_lt);
+    DCF_HIP(hipGetLastError());
+
+    m->dbg.correl = b.correl; m->dbg.gate = b.gate; m->dbg.F = b.F;
+    m->dbg.nq = nq; m->dbg.T0 = T0; m->dbg.B = B; m->dbg.S = S;
+  }
+  return 0;
+}
+
+}  // namespace dcf
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+const char* dcf_last_error(void) { return dcf::g_err.c_str(); }
+int dcf_abi_version(void) { return 1; }
+
+int dcf_model_create(const dcf_config* cfg, dcf_model** out) {
+  DCF_CHECK(cfg && out, "dcf_model_create: null argument");
+  DCF_CHECK(cfg->E > 0 && cfg->E % 32 == 0 && cfg->E <= 992, "E=%d must be a positive multiple of 32 (<= 992)", cfg->E);
+  DCF_CHECK(cfg->D > 0 && cfg->D % 32 == 0, "D=%d must be a positive multiple of 32", cfg->D);
+  DCF_CHECK(cfg->TE > 0 && cfg->TE % 32 == 0, "TE=%d must be a positive multiple of 32", cfg->TE);
+  DCF_CHECK(cfg->n_levels >= 1 && cfg->n_levels <= DCF_MAX_LEVELS, "n_levels=%d out of range", cfg->n_levels);
+  DCF_CHECK(cfg->win > 0 && (cfg->win & 1), "mha_win_size=%d must be odd and > 0 (global self-attention over clips is not on the hot path)", cfg->win);
+  DCF_CHECK(cfg->fusion_layers >= 0 && cfg->head_layers >= 0 && cfg->n_embd_convs >= 0 && cfg->n_stem >= 0, "negative layer count");
+  DCF_CHECK(cfg->sn >= 1, "sn must be >= 1");
+  int ndev = 0;
+  DCF_HIP(hipGetDeviceCount(&ndev));
+  DCF_CHECK(ndev > 0, "no HIP device");
+  dcf_model* m = new dcf_model();
+  m->cfg = *cfg;
+  *out = m;
+  return 0;
+}
+
+void dcf_model_destroy(dcf_model* m) {
+  if (!m) return;
+  dcf::free_model(m);
+  delete m;
+}
+
+int dcf_model_bind(dcf_model* m, const char* name, const float* data, const int64_t* shape, int32_t ndim) {
+  DCF_CHECK(m && name && data, "dcf_model_bind: null argument");
+  dcf::Bound b;
+  b.p = data;
+  for (int i = 0; i < ndim; ++i) b.shape.push_back(shape[i]);
+  m->bound[name] = b;
+  m->finalized = false;
+  return 0;
+}
+
+int dcf_model_set_pe(dcf_model* m, const float* pe_tokens, int64_t T) {
+  DCF_CHECK(m, "dcf_model_set_pe: null model");
+  m->pe = pe_tokens;
+  m->pe_T = T;
+  return 0;
+}
+
+int dcf_model_finalize(dcf_model* m, void* stream) {
+  DCF_CHECK(m, "dcf_model_finalize: null model");
+  return dcf::finalize(m, (hipStream_t)stream);
+}
+
+int64_t dcf_points_per_query(const dcf_model* m, int64_t T) {
+  int64_t s = 0;
+  for (int l = 0; l < m->cfg.n_levels; ++l) s += T >> l;
+  return s;
+}
+
+int dcf_forward_eval(dcf_model* m, const float* vid, const float* shallow_vid, const uint8_t* vid_mask, int64_t T,
+                     int32_t nq, const float* const* text, const uint8_t* const* text_mask, const int32_t* text_len,
+                     const float* text_cls, float* logits_out, float* offsets_out, uint8_t* masks_out, void* stream) {
+  DCF_CHECK(m && vid && shallow_vid && vid_mask && text && text_len && text_cls && logits_out && offsets_out && masks_out,
+            "dcf_forward_eval: null argument");
+  DCF_CHECK(T < (1ll << 24), "T too large");
+  return dcf::forward(m, vid, shallow_vid, vid_mask, (int)T, nq, text, text_mask, text_len, text_cls, logits_out,
+                      offsets_out, masks_out, (hipStream_t)stream);
+}
+
+int dcf_debug_copy(dcf_model* m, int32_t what, float* dst, int64_t max_floats, void* stream) {
+  DCF_CHECK(m && dst, "dcf_debug_copy: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const float* src = nullptr;
+  int64_t n = 0;
+  const int E = m->cfg.E;
+  switch (what) {
+    case 0: src = m->dbg.correl; n = (int64_t)m->dbg.nq * m->dbg.T0; break;
+    case 1: src = m->dbg.gate; n = (int64_t)m->dbg.B * m->dbg.T0; break;
+    case 4: src = m->dbg.F; n = (int64_t)m->dbg.B * m->dbg.S * (E + dcf::TCN_HID); break;
+    case 2: case 3: {
+      // these buffers are overwritten during the forward: arm the capture, the NEXT forward fills dst
+      m->keep_debug = true;
+      if (what == 2) m->dbg_vidmap = dst; else m->dbg_fused = dst;
+      return 0;
+    }
+    default: DCF_CHECK(false, "dcf_debug_copy: unknown selector %d", what);
+  }
+  DCF_CHECK(src, "dcf_debug_copy: no forward has run yet");
+  DCF_CHECK(n <= max_floats, "dcf_debug_copy: destination too small (%lld > %lld)", (long long)n, (long long)max_floats);
+  DCF_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+// ---- post-processing -------------------------------------------------------------------------
+int dcf_collect_segments(const float* logits, const float* offsets, const uint8_t* masks, int32_t nq, int64_t T,
+                         int32_t n_levels, float pre_nms_thresh, int32_t pre_nms_topk, float seg_len_thresh,
+                         float* segs_out, float* scores_out, int32_t* counts_out, void* stream) {
+  DCF_CHECK(logits && offsets && masks && segs_out && scores_out && counts_out, "dcf_collect_segments: null argument");
+  DCF_CHECK(n_levels >= 1 && n_levels <= 16, "dcf_collect_segments: n_levels out of range");
+  dcf::CollectArgs a{};
+  a.logits = logits; a.offsets = offsets; a.masks = masks;
+  int acc = 0;
+  for (int l = 0; l < n_levels; ++l) { a.off[l] = acc; acc += (int)(T >> l); }
+  a.off[n_levels] = acc;
+  a.S = acc; a.n_levels = n_levels;
+  a.pre_nms_thresh = pre_nms_thresh; a.seg_len_thresh = seg_len_thresh; a.pre_nms_topk = pre_nms_topk;
+  a.segs = segs_out; a.scores = scores_out; a.counts = counts_out;
+  uint32_t* keys = nullptr;
+  DCF_HIP(hipMallocAsync((void**)&keys, (size_t)nq * acc * sizeof(uint32_t), (hipStream_t)stream));
+  a.keys = keys;
+  int rc = dcf::launch_collect(a, nq, (hipStream_t)stream);
+  DCF_HIP(hipFreeAsync(keys, (hipStream_t)stream));
+  return rc;
+}
+
+int dcf_nms_1d(const float* segs, const float* scores, const int32_t* counts, int32_t nq, int32_t n_max,
+               int32_t stride, float iou_thresh, int64_t* keep_out, int32_t* keep_counts_out, void* stream) {
+  DCF_CHECK(keep_out && keep_counts_out && (n_max == 0 || (segs && scores)), "dcf_nms_1d: null argument");
+  dcf::NmsArgs a{segs, scores, counts, n_max, stride, iou_thresh, (long long*)keep_out, keep_counts_out};
+  return dcf::launch_nms(a, nq, (hipStream_t)stream);
+}
+
+int dcf_softnms_1d(const float* segs, const float* scores, const int32_t* counts, int32_t nq, int32_t n_max,
+                   int32_t stride, float iou_thresh, float sigma, float min_score, int32_t method,
+                   int32_t max_iters, float* dets_out, int64_t* inds_out, int32_t* out_counts, void* stream) {
+  DCF_CHECK(dets_out && inds_out && out_counts && (n_max == 0 || (segs && scores)), "dcf_softnms_1d: null argument");
+  dcf::SoftNmsArgs a{segs, scores, counts, n_max, stride, iou_thresh, sigma, min_score, method, max_iters, dets_out,
+                     (long long*)inds_out, out_counts};
+  return dcf::launch_softnms(a, nq, (hipStream_t)stream);
+}
+
+int dcf_segment_voting(const float* nms_segs, int32_t nms_ld, const int32_t* n1_counts, int32_t n1_max,
+                       int32_t n1_stride, const float* all_segs, const float* all_scores,
+                       const int32_t* n2_counts, int32_t n2_max, int32_t n2_stride, float iou_thresh,
+                       int32_t nq, float* out, void* stream) {
+  DCF_CHECK(nms_segs && all_segs && all_scores && out, "dcf_segment_voting: null argument");
+  dcf::VotingArgs a{nms_segs, nms_ld, n1_counts, n1_max, n1_stride, all_segs, all_scores, n2_counts, n2_max, n2_stride,
+                    iou_thresh, out};
+  return dcf::launch_voting(a, nq, (hipStream_t)stream);
+}
+
+// ---- single operators ---------------------------------------------------------------------------
+int dcf_op_linear(const float* A, const float* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K,
+                  int32_t act, void* stream) {
+  dcf::GemmArgs g = dcf::gemm(A, K, W, bias, C, N, M, N, K);
+  g.flags = act == 1 ? dcf::G_GELU : act == 2 ? dcf::G_RELU : 0;
+  return dcf::launch_gemm(&g, 1, dcf::A_ROWS, (hipStream_t)stream);
+}
+
+int dcf_op_linear_cm(const float* A_cm, const float* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K,
+                     void* stream) {
+  dcf::GemmArgs g = dcf::gemm(A_cm, M, W, bias, C, N, M, N, K);
+  return dcf::launch_gemm(&g, 1, dcf::A_CHANMAJOR, (hipStream_t)stream);
+}
+
+int dcf_op_conv3(const float* X, const uint8_t* mask, const float* W_ock, float* Y, int32_t B, int32_t T, int32_t Cin,
+                 int32_t N, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int rows = B * T;
+  float* wp = nullptr;
+  uint8_t* nbr = nullptr;
+  DCF_HIP(hipMallocAsync((void**)&wp, (size_t)N * Cin * 3 * sizeof(float), st));
+  DCF_HIP(hipMallocAsync((void**)&nbr, (size_t)rows, st));
+  const int n = N * Cin * 3;
+  hipLaunchKernelGGL(dcf::k_permute3, dim3((n + 255) / 256), dim3(256), 0, st, W_ock, wp, N, Cin, 3, 0, 2, 1);
+  int rc = dcf::launch_rowflags(mask, nbr, T, rows, st);
+  if (rc == 0) {
+    dcf::GemmArgs g = dcf::gemm(X, Cin, wp, nullptr, Y, N, rows, N, 3 * Cin);
+    g.cin = Cin; g.nbr = nbr;
+    rc = dcf::launch_gemm(&g, 1, dcf::A_ROWS_TAP3, st);
+  }
+  DCF_HIP(hipFreeAsync(wp, st));
+  DCF_HIP(hipFreeAsync(nbr, st));
+  return rc;
+}
+
+int dcf_op_layernorm(const float* X, const float* w, const float* b, float* Y, int32_t rows, int32_t C, int32_t relu,
+                     void* stream) {
+  dcf::LnArgs a{};
+  a.X = X; a.ldx = C; a.Y = Y; a.ldy = C; a.w = w; a.b = b; a.rows = rows; a.C = C; a.relu = relu;
+  return dcf::launch_ln(a, (hipStream_t)stream);
+}
+
+int dcf_op_xattn(const float* Q, const float* K, const float* V, const uint8_t* kvmask, float* O, int32_t B, int32_t T,
+                 int32_t Lk, int32_t C, int32_t heads, void* stream) {
+  dcf::XAttnArgs a{Q, K, V, kvmask, O, B, T, Lk, C, heads};
+  return dcf::launch_xattn(a, (hipStream_t)stream);
+}
+
+int dcf_op_local_attn(const float* Q, const float* K, const float* V, const uint8_t* mask, float* O, int32_t B, int32_t T,
+                      int32_t C, int32_t heads, int32_t window, void* stream) {
+  dcf::LocalAttnArgs a{Q, K, V, mask, O, B, T, C, heads, window};
+  return dcf::launch_local_attn(a, (hipStream_t)stream);
+}
+
+int dcf_op_sidekick(const float* shallow, const float* text_cls, float* correl, int32_t D, int32_t T, int32_t nq,
+                    int32_t norm, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  float *tn = nullptr, *partial = nullptr;
+  DCF_HIP(hipMallocAsync((void**)&tn, (size_t)nq * D * sizeof(float), st));
+  DCF_HIP(hipMallocAsync((void**)&partial, (size_t)dcf::SCORE_SLICES * (nq + 1) * T * sizeof(float), st));
+  dcf::ScoreArgs a{shallow, text_cls, tn, partial, correl, D, T, nq, norm};
+  int rc = dcf::launch_sidekick(a, st);
+  DCF_HIP(hipFreeAsync(tn, st));
+  DCF_HIP(hipFreeAsync(partial, st));
+  return rc;
+}
+
+int dcf_op_gate(const float* correl, const uint8_t* vid_mask, float* gate, uint8_t* mask_out, int32_t T, int32_t nq,
+                int32_t sn, double sratio, int32_t msf, void* stream) {
+  dcf::GateArgs a{correl, vid_mask, gate, mask_out, T, nq, 0, sn, msf, sratio};
+  return dcf::launch_gate(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,44 @@
+// fp32 MFMA GEMM used for every dense 1x1 / k3 convolution of the grounding path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dcf {
+
+enum GemmAMode {
+  A_ROWS = 0,      // A[m][k] = X[m*lda + k]                       (token-major activation)
+  A_ROWS_TAP3 = 1, // A[m][tap*cin + c] = X[(m+tap-1)*lda + c] if neighbour usable else 0  (k3 conv, pad 1)
+  A_CHANMAJOR = 2, // A[m][k] = X[k*lda + m]                       (reference (C,T) input layout)
+};
+
+enum GemmFlags {
+  G_GELU = 1,       // exact erf GELU on (acc + bias)
+  G_RELU = 2,
+  G_RES = 4,        // C = R * (G_RES_MASK ? mask : 1) + ls[n] * h,   h = (acc + bias) * (G_OUT_MASK ? mask : 1)
+  G_RES_MASK = 8,
+  G_OUT_MASK = 16,
+  G_AMASK = 32,     // A_ROWS: multiply A rows by rowmask on load (MaskedConv1D's x * mask)
+};
+
+struct GemmArgs {
+  const float* A;
+  int64_t lda;
+  const float* W;      // [N][ldw], K contiguous (PyTorch Conv1d weight (N, K, 1); k3 weights are repacked [N][tap][cin])
+  int64_t ldw;         // row pitch of W in floats (0 = K)
+  const float* bias;   // [N] or nullptr
+  float* C;
+  int64_t ldc;
+  int M, N, K;
+  int cin;                 // A_ROWS_TAP3: channels per tap
+  const uint8_t* rowmask;  // [M] validity of row m (G_AMASK / G_RES_MASK / G_OUT_MASK)
+  const uint8_t* nbr;      // [M] A_ROWS_TAP3: bit0 self usable, bit1 left usable, bit2 right usable
+  const float* R;          // residual [M][ldr]
+  int64_t ldr;
+  const float* ls;         // [N] layer scale (G_RES); nullptr = 1
+  int flags;
+};
+
+// Launch up to 3 independent GEMMs of identical (M, N, K, mode) in one grid (blockIdx.z).
+int launch_gemm(const GemmArgs* g, int count, GemmAMode mode, hipStream_t stream);
+
+}  // namespace dcf

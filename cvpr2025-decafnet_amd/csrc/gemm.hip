@@ -1,0 +1,270 @@
+// fp32 GEMM on the gfx950 matrix cores: C[M][N] = A[M][K] * W[N][K]^T (+ fused epilogues).
+//
+// Why fp32 MFMA: the reference runs in fp32 with TF32 disabled (eval.py:38-41) and the parity
+// bar is 1e-3 on logits after ~60 chained layers, so the dense convolutions use
+// v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 157 TFLOP/s dense peak on MI355X).
+//
+// Tiling (64-wide wavefronts, 4 waves / workgroup):
+//   workgroup tile BM x BN = (WM*TM*32) x (WN*TN*32), K step 32.
+//   A and W tiles are staged in LDS as [row][36] floats (pitch 36 = 4*9 keeps every 16-lane
+//   ds_read_b128 group on 64 distinct banks).  Lane l = (r = l&31, h = l>>5) reads 4
+//   consecutive k values A[r][8*kk + 4*h .. +3] with ONE ds_read_b128 and feeds them to 4
+//   successive MFMAs; the k index inside an 8-chunk is therefore permuted identically for A
+//   and W, which leaves the dot product unchanged.
+//   The next K tile is prefetched global->registers while the current one is multiplied.
+#include "common.h"
+#include "gemm.h"
+
+namespace dcf {
+
+constexpr int BK = 32;
+constexpr int PITCH = 36;
+
+struct GemmBatch {
+  GemmArgs g[3];
+};
+
+template <int WM, int WN, int TM, int TN, int AMODE>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
+  constexpr int BM = WM * TM * 32;
+  constexpr int BN = WN * TN * 32;
+  constexpr int A_F4 = BM * BK / 4 / 256;  // f32x4 per thread for the A tile
+  constexpr int B_F4 = BN * BK / 4 / 256;
+  constexpr int APITCH_KM = BM + 4;         // A_CHANMAJOR: LDS tile is [k][m]
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert((BM * BK / 4) % 256 == 0 && (BN * BK / 4) % 256 == 0, "tile/threads mismatch");
+
+  extern __shared__ float smem[];
+  float* As = smem;                                                  // [BM][PITCH] or [BK][APITCH_KM]
+  float* Bs = smem + (AMODE == A_CHANMAJOR ? BK * APITCH_KM : BM * PITCH);  // [BN][PITCH]
+
+  // select by value (a dynamically indexed by-value kernarg array would be spilled to scratch)
+  const GemmArgs p = blockIdx.z == 0 ? batch.g[0] : (blockIdx.z == 1 ? batch.g[1] : batch.g[2]);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN;
+  const int wn = wave % WN;
+  const int r = lane & 31;
+  const int h = lane >> 5;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int M = p.M, K = p.K;
+  const int KT = K / BK;
+
+  f32x4 areg[A_F4];
+  f32x4 breg[B_F4];
+
+  auto load_tiles = [&](int kt) __attribute__((always_inline)) {
+    const int k0 = kt * BK;
+    // ---- W tile: rows n0..n0+BN, cols k0..k0+32 (always in range: N % BN == 0, K % 32 == 0)
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+      int idx = i * 256 + tid;
+      int row = idx >> 3, c4 = idx & 7;
+      breg[i] = *reinterpret_cast<const f32x4*>(p.W + (int64_t)(n0 + row) * p.ldw + k0 + c4 * 4);
+    }
+    // ---- A tile
+    if constexpr (AMODE == A_ROWS) {
+#pragma unroll
+      for (int i = 0; i < A_F4; ++i) {
+        int idx = i * 256 + tid;
+        int row = idx >> 3, c4 = idx & 7;
+        int m = m0 + row;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        bool ok = m < M;
+        if (ok && (p.flags & G_AMASK)) ok = p.rowmask[m] != 0;
+        if (ok) v = *reinterpret_cast<const f32x4*>(p.A + (int64_t)m * p.lda + k0 + c4 * 4);
+        areg[i] = v;
+      }
+    } else if constexpr (AMODE == A_ROWS_TAP3) {
+      const int tap = k0 / p.cin;           // cin % 32 == 0 so a K tile never straddles taps
+      const int c0 = k0 - tap * p.cin;
+#pragma unroll
+      for (int i = 0; i < A_F4; ++i) {
+        int idx = i * 256 + tid;
+        int row = idx >> 3, c4 = idx & 7;
+        int m = m0 + row;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (m < M) {
+          unsigned f = p.nbr[m];
+          bool ok = (tap == 0) ? (f & 2u) : (tap == 1) ? (f & 1u) : (f & 4u);
+          if (ok) v = *reinterpret_cast<const f32x4*>(p.A + (int64_t)(m + tap - 1) * p.lda + c0 + c4 * 4);
+        }
+        areg[i] = v;
+      }
+    } else {  // A_CHANMAJOR: 32 k-rows x BM m, f32x4 along m
+      constexpr int TPR = BM / 4;            // threads per k-row
+      const bool vec = (p.lda & 3) == 0;
+#pragma unroll
+      for (int i = 0; i < A_F4; ++i) {
+        int idx = i * 256 + tid;
+        int kr = idx / TPR, m4 = idx % TPR;
+        int m = m0 + m4 * 4;
+        const float* src = p.A + (int64_t)(k0 + kr) * p.lda + m;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (vec && m + 3 < M) {
+          v = *reinterpret_cast<const f32x4*>(src);
+        } else {
+          if (m + 0 < M) v.x = src[0];
+          if (m + 1 < M) v.y = src[1];
+          if (m + 2 < M) v.z = src[2];
+          if (m + 3 < M) v.w = src[3];
+        }
+        areg[i] = v;
+      }
+    }
+  };
+
+  auto store_tiles = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+      int idx = i * 256 + tid;
+      int row = idx >> 3, c4 = idx & 7;
+      *reinterpret_cast<f32x4*>(Bs + row * PITCH + c4 * 4) = breg[i];
+    }
+    if constexpr (AMODE == A_CHANMAJOR) {
+      constexpr int TPR = BM / 4;
+#pragma unroll
+      for (int i = 0; i < A_F4; ++i) {
+        int idx = i * 256 + tid;
+        int kr = idx / TPR, m4 = idx % TPR;
+        *reinterpret_cast<f32x4*>(As + kr * APITCH_KM + m4 * 4) = areg[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_F4; ++i) {
+        int idx = i * 256 + tid;
+        int row = idx >> 3, c4 = idx & 7;
+        *reinterpret_cast<f32x4*>(As + row * PITCH + c4 * 4) = areg[i];
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  load_tiles(0);
+  for (int kt = 0; kt < KT; ++kt) {
+    __syncthreads();
+    store_tiles();
+    __syncthreads();
+    load_tiles(kt + 1 < KT ? kt + 1 : kt);   // unconditional (last iteration re-reads its own tile)
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      f32x4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        int row = (wm * TM + i) * 32 + r;
+        if constexpr (AMODE == A_CHANMAJOR) {
+          const float* q = As + (kk * 8 + h * 4) * APITCH_KM + row;
+          a[i] = f32x4{q[0], q[APITCH_KM], q[2 * APITCH_KM], q[3 * APITCH_KM]};
+        } else {
+          a[i] = *reinterpret_cast<const f32x4*>(As + row * PITCH + kk * 8 + h * 4);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        int row = (wn * TN + j) * 32 + r;
+        b[j] = *reinterpret_cast<const f32x4*>(Bs + row * PITCH + kk * 8 + h * 4);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+
+  // ---- epilogue.  D layout of a 32x32 tile: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * h
+  const int flags = p.flags;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + (wn * TN + j) * 32 + r;
+    const float bias = p.bias ? p.bias[col] : 0.f;
+    const float ls = ((flags & G_RES) && p.ls) ? p.ls[col] : 1.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row < M) {
+          float v = acc[i][j][e] + bias;
+          if (flags & G_GELU) v = gelu_erf(v);
+          if (flags & G_RELU) v = fmaxf(v, 0.f);
+          if (flags & G_RES) {
+            float mk = 1.f;
+            if (flags & (G_RES_MASK | G_OUT_MASK)) mk = p.rowmask[row] ? 1.f : 0.f;
+            if (flags & G_OUT_MASK) v *= mk;
+            float res = p.R[(int64_t)row * p.ldr + col];
+            if (flags & G_RES_MASK) res *= mk;
+            v = res + ls * v;
+          }
+          p.C[(int64_t)row * p.ldc + col] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch_cfg(const GemmBatch& b, int count, GemmAMode mode, hipStream_t stream) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  const GemmArgs& p = b.g[0];
+  dim3 grid((p.M + BM - 1) / BM, p.N / BN, count);
+  size_t lds_rows = (size_t)(BM + BN) * PITCH * sizeof(float);
+  size_t lds_km = (size_t)(BK * (BM + 4) + BN * PITCH) * sizeof(float);
+  switch (mode) {
+    case A_ROWS:
+      hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, A_ROWS>), grid, dim3(256), lds_rows, stream, b);
+      break;
+    case A_ROWS_TAP3:
+      hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, A_ROWS_TAP3>), grid, dim3(256), lds_rows, stream, b);
+      break;
+    case A_CHANMAJOR:
+      hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, A_CHANMAJOR>), grid, dim3(256), lds_km, stream, b);
+      break;
+  }
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_gemm(const GemmArgs* g, int count, GemmAMode mode, hipStream_t stream) {
+  DCF_CHECK(count >= 1 && count <= 3, "launch_gemm: count %d out of range", count);
+  GemmBatch b;
+  for (int i = 0; i < 3; ++i) {
+    b.g[i] = g[i < count ? i : 0];
+    if (b.g[i].ldw == 0) b.g[i].ldw = b.g[i].K;
+  }
+  const GemmArgs& p = g[0];
+  for (int i = 0; i < count; ++i) {
+    DCF_CHECK(g[i].M == p.M && g[i].N == p.N && g[i].K == p.K, "launch_gemm: grouped shapes differ");
+    DCF_CHECK(g[i].A && g[i].W && g[i].C, "launch_gemm: null operand");
+    DCF_CHECK((g[i].lda % 4) == 0 || mode == A_CHANMAJOR, "launch_gemm: lda %% 4 != 0");
+    DCF_CHECK(b.g[i].ldw % 4 == 0 && b.g[i].ldw >= g[i].K, "launch_gemm: bad ldw");
+    if (mode == A_ROWS_TAP3) DCF_CHECK(g[i].nbr && g[i].cin % 32 == 0 && g[i].K == 3 * g[i].cin, "launch_gemm: bad tap3 args");
+    if (g[i].flags & (G_AMASK | G_RES_MASK | G_OUT_MASK)) DCF_CHECK(g[i].rowmask, "launch_gemm: rowmask missing");
+    if (g[i].flags & G_RES) DCF_CHECK(g[i].R, "launch_gemm: residual missing");
+  }
+  if (p.M <= 0) return 0;
+  DCF_CHECK(p.K > 0 && p.K % BK == 0, "launch_gemm: K=%d must be a positive multiple of 32", p.K);
+  DCF_CHECK(p.N > 0 && p.N % 32 == 0, "launch_gemm: N=%d must be a positive multiple of 32", p.N);
+  const int N = p.N;
+  if (N % 256 == 0) return launch_cfg<2, 2, 1, 4>(b, count, mode, stream);
+  if (N % 160 == 0) return launch_cfg<4, 1, 1, 5>(b, count, mode, stream);
+  if (N % 128 == 0) return launch_cfg<2, 2, 1, 2>(b, count, mode, stream);
+  if (N % 96 == 0) return launch_cfg<4, 1, 1, 3>(b, count, mode, stream);
+  if (N % 64 == 0) return launch_cfg<2, 2, 1, 1>(b, count, mode, stream);
+  return launch_cfg<4, 1, 1, 1>(b, count, mode, stream);
+}
+
+}  // namespace dcf

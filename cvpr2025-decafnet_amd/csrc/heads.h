@@ -1,0 +1,51 @@
+// Output convolutions of the heads and the iterative-refinement TCN (heads.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dcf {
+
+constexpr int DCF_MAX_LEVELS = 16;
+constexpr int TCN_HID = 32;     // TCN(arch[-1], 32, 32, ...) is hard-wired in libs/modeling/model.py:424
+
+// Pyramid geometry of one batched forward.  Rows of every pyramid-wide buffer are ordered
+// [level l][batch b][position t]:  row = start[l] + b * T[l] + t.   Lives in device memory.
+struct LevelTable {
+  int n_levels, B;
+  int S;                              // sum_l T[l]  (points per query)
+  int T[DCF_MAX_LEVELS];
+  int start[DCF_MAX_LEVELS + 1];      // start[l] = B * sum_{j<l} T[j]
+  int off[DCF_MAX_LEVELS];            // off[l] = sum_{j<l} T[j]  (offset inside one query's output)
+  float scale[DCF_MAX_LEVELS];        // reg_head.scales.{l}.scale
+};
+
+struct ConvOutArgs {
+  const float* X; int64_t ldx;        // [rows][ldx] activations (already LN+ReLU'd)
+  const uint8_t* nbr;                 // [rows] neighbour flags (MaskedConv1D masks its input)
+  const float* W;                     // [NO][3][C]
+  const float* bias;                  // [NO]
+  const LevelTable* lt;
+  float* out;
+  int rows, C, NO;
+  int mode;                           // 0: raw logits   1: relu(scale_l * y)  (RegHead, head.py:102-103)
+  int query_major;                    // 0: out[row*NO+o] (internal order)   1: out[(b*S + off_l + t)*NO + o]
+};
+int launch_conv_out(const ConvOutArgs& a, hipStream_t st);
+
+struct RefineArgs {
+  const float* logits1;               // [rows] first-pass logits, internal order
+  const LevelTable* lt;
+  const uint8_t* mask_all;            // [rows] per-level masks, internal order
+  // TCN weights (repacked): in [L][32], dil[i] [3][32][32] (tap, ci, co), pw[i] [32][32] (ci, co), out [32][32]
+  const float* w_in; const float* b_in;
+  const float* const* host_w_dil; const float* const* host_b_dil;   // HOST arrays [n_layers] of device pointers
+  const float* const* host_w_pw; const float* const* host_b_pw;
+  const float* const* host_ln_w; const float* const* host_ln_b;
+  const float* w_out; const float* b_out;
+  float* bufA; float* bufB;           // [B*T0][32] ping-pong
+  float* F; int64_t ldf; int E;       // pyramid feature buffer; refined logits go to columns [E, E+32)
+  int B, T0, n_levels, n_layers;
+};
+int launch_refine(const RefineArgs& a, const LevelTable& host_lt, hipStream_t st);
+
+}  // namespace dcf

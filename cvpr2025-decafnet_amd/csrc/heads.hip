@@ -1,0 +1,257 @@
+// Head output convolutions + the iterative refinement branch (libs/modeling/model.py:442-471,
+// libs/modeling/tcn.py, libs/modeling/head.py).  These are thin (1-2 output channels, or 32 hidden
+// channels) so they run on the vector ALUs; the 32-channel TCN keeps a whole row in the registers
+// of ONE lane (each lane reads its row as full 128-byte lines) and takes the weights through
+// wave-uniform scalar loads.
+#include "common.h"
+#include "heads.h"
+
+namespace dcf {
+
+__device__ __forceinline__ int find_level(const LevelTable* lt, int r) {
+  int l = 0;
+  while (l + 1 < lt->n_levels && r >= lt->start[l + 1]) ++l;
+  return l;
+}
+
+// ------------------------------------------------------------------------------------------
+// k3 conv to NO (1 or 2) channels over masked input; one wavefront per row.
+// ------------------------------------------------------------------------------------------
+template <int NCH, int NO>
+__global__ __launch_bounds__(256) void k_conv_out(ConvOutArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= p.rows) return;
+  const unsigned f = p.nbr[r];
+  const int C = p.C;
+  float acc[NO];
+#pragma unroll
+  for (int o = 0; o < NO; ++o) acc[o] = 0.f;
+#pragma unroll
+  for (int tap = 0; tap < 3; ++tap) {
+    const bool ok = tap == 0 ? (f & 2u) : tap == 1 ? (f & 1u) : (f & 4u);
+    if (!ok) continue;
+    Row<NCH> x;
+    x.load(p.X + (int64_t)(r + tap - 1) * p.ldx, C, lane);
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      const float* w = p.W + ((size_t)o * 3 + tap) * C;
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {
+        int c = 256 * j + 4 * lane;
+        if (c < C) {
+          f32x4 ww = *reinterpret_cast<const f32x4*>(w + c);
+          acc[o] += (x.v[j].x * ww.x + x.v[j].y * ww.y) + (x.v[j].z * ww.z + x.v[j].w * ww.w);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < NO; ++o) acc[o] = wave_sum(acc[o]);
+  if (lane == 0) {
+    const LevelTable* lt = p.lt;
+    const int l = find_level(lt, r);
+    int64_t dst = r;
+    if (p.query_major) {
+      const int rel = r - lt->start[l];
+      const int b = rel / lt->T[l], t = rel - b * lt->T[l];
+      dst = (int64_t)b * lt->S + lt->off[l] + t;
+    }
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      float y = acc[o] + p.bias[o];
+      if (p.mode == 1) y = fmaxf(y * lt->scale[l], 0.f);
+      p.out[dst * NO + o] = y;
+    }
+  }
+}
+
+int launch_conv_out(const ConvOutArgs& a, hipStream_t st) {
+  if (a.rows <= 0) return 0;
+  DCF_CHECK(a.NO == 1 || a.NO == 2, "conv_out: NO=%d unsupported", a.NO);
+  DCF_CHECK(a.C % 4 == 0 && a.C <= 1024, "conv_out: C=%d unsupported", a.C);
+  const int n = (a.C + 255) / 256;
+  dim3 grid((a.rows + 3) / 4), blk(256);
+#define CO(NCH_)                                                                          \
+  if (a.NO == 1) hipLaunchKernelGGL((k_conv_out<NCH_, 1>), grid, blk, 0, st, a);          \
+  else hipLaunchKernelGGL((k_conv_out<NCH_, 2>), grid, blk, 0, st, a)
+  switch (n) {
+    case 1: CO(1); break;
+    case 2: CO(2); break;
+    case 3: CO(3); break;
+    default: CO(4); break;
+  }
+#undef CO
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// refinement: stack the nearest-upsampled level logits (model.py:449-455) and map L -> 32
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_refine_in(RefineArgs p) {
+  const int r = blockIdx.x * 64 + threadIdx.x;          // level-0 row (b, t)
+  if (r >= p.B * p.T0) return;
+  const LevelTable* lt = p.lt;
+  const int b = r / p.T0, t = r - b * p.T0;
+  const float m0 = p.mask_all[r] ? 1.f : 0.f;           // level 0 occupies rows [0, B*T0)
+  float h[TCN_HID];
+#pragma unroll
+  for (int c = 0; c < TCN_HID; ++c) h[c] = p.b_in[c];
+  for (int l = 0; l < p.n_levels; ++l) {
+    // nearest source index floor(t * T_l / T_0) = t >> l  (T_0 = T_l * 2^l exactly)
+    float u = p.logits1[lt->start[l] + b * lt->T[l] + (t >> l)];
+    if (l > 0) u *= m0;
+#pragma unroll
+    for (int c = 0; c < TCN_HID; ++c) h[c] += p.w_in[l * TCN_HID + c] * u;
+  }
+  f32x4* dst = reinterpret_cast<f32x4*>(p.bufA + (int64_t)r * TCN_HID);
+#pragma unroll
+  for (int c = 0; c < TCN_HID / 4; ++c) dst[c] = f32x4{h[4 * c], h[4 * c + 1], h[4 * c + 2], h[4 * c + 3]};
+}
+
+__device__ __forceinline__ void load_row32(const float* __restrict__ src, float (&x)[TCN_HID]) {
+  const f32x4* s = reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+  for (int c = 0; c < TCN_HID / 4; ++c) {
+    f32x4 v = s[c];
+    x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
+  }
+}
+
+// DilatedResidualLayer.forward (tcn.py:21-38): relu(dilated k3) -> 1x1 -> (x + out) * mask -> LayerNorm(32)
+__global__ __launch_bounds__(64) void k_tcn_layer(const float* __restrict__ X, float* __restrict__ Y,
+                                                   const float* __restrict__ wd, const float* __restrict__ bd,
+                                                   const float* __restrict__ wp, const float* __restrict__ bp,
+                                                   const float* __restrict__ lnw, const float* __restrict__ lnb,
+                                                   const uint8_t* __restrict__ mask, int B, int T0, int dil) {
+  const int r = blockIdx.x * 64 + threadIdx.x;
+  if (r >= B * T0) return;
+  const int t = r % T0;
+  float x0[TCN_HID], h[TCN_HID];
+#pragma unroll
+  for (int c = 0; c < TCN_HID; ++c) h[c] = bd[c];
+#pragma unroll
+  for (int tap = 0; tap < 3; ++tap) {
+    const int tt = t + (tap - 1) * dil;
+    float xin[TCN_HID];
+    if (tt >= 0 && tt < T0) {
+      load_row32(X + (int64_t)(r + (tap - 1) * dil) * TCN_HID, xin);
+    } else {
+#pragma unroll
+      for (int c = 0; c < TCN_HID; ++c) xin[c] = 0.f;
+    }
+    if (tap == 1) {
+#pragma unroll
+      for (int c = 0; c < TCN_HID; ++c) x0[c] = xin[c];
+    }
+#pragma unroll
+    for (int ci = 0; ci < TCN_HID; ++ci) {
+      const float* w = wd + ((size_t)tap * TCN_HID + ci) * TCN_HID;
+#pragma unroll
+      for (int co = 0; co < TCN_HID; ++co) h[co] += w[co] * xin[ci];
+    }
+  }
+  float o[TCN_HID];
+#pragma unroll
+  for (int c = 0; c < TCN_HID; ++c) { o[c] = bp[c]; h[c] = fmaxf(h[c], 0.f); }
+#pragma unroll
+  for (int ci = 0; ci < TCN_HID; ++ci) {
+    const float* w = wp + (size_t)ci * TCN_HID;
+#pragma unroll
+    for (int co = 0; co < TCN_HID; ++co) o[co] += w[co] * h[ci];
+  }
+  const float m = mask[r] ? 1.f : 0.f;
+  float mean = 0.f;
+#pragma unroll
+  for (int c = 0; c < TCN_HID; ++c) { o[c] = (x0[c] + o[c]) * m; mean += o[c]; }
+  mean *= (1.0f / TCN_HID);
+  float var = 0.f;
+#pragma unroll
+  for (int c = 0; c < TCN_HID; ++c) { o[c] -= mean; var += o[c] * o[c]; }
+  const float rs = 1.0f / sqrtf(var * (1.0f / TCN_HID) + 1e-5f);
+  f32x4* dst = reinterpret_cast<f32x4*>(Y + (int64_t)r * TCN_HID);
+#pragma unroll
+  for (int c = 0; c < TCN_HID / 4; ++c) {
+    f32x4 v;
+    v.x = o[4 * c] * rs * lnw[4 * c] + lnb[4 * c];
+    v.y = o[4 * c + 1] * rs * lnw[4 * c + 1] + lnb[4 * c + 1];
+    v.z = o[4 * c + 2] * rs * lnw[4 * c + 2] + lnb[4 * c + 2];
+    v.w = o[4 * c + 3] * rs * lnw[4 * c + 3] + lnb[4 * c + 3];
+    dst[c] = v;
+  }
+}
+
+// conv_out (1x1, 32->32) * mask, written into columns [E, E+32) of the level-0 pyramid rows
+__global__ __launch_bounds__(64) void k_refine_out(const float* __restrict__ X, const float* __restrict__ w,
+                                                    const float* __restrict__ b, const uint8_t* __restrict__ mask,
+                                                    float* __restrict__ F, int64_t ldf, int E, int rows) {
+  const int r = blockIdx.x * 64 + threadIdx.x;
+  if (r >= rows) return;
+  float x[TCN_HID], o[TCN_HID];
+  load_row32(X + (int64_t)r * TCN_HID, x);
+#pragma unroll
+  for (int c = 0; c < TCN_HID; ++c) o[c] = b[c];
+#pragma unroll
+  for (int ci = 0; ci < TCN_HID; ++ci) {
+#pragma unroll
+    for (int co = 0; co < TCN_HID; ++co) o[co] += w[ci * TCN_HID + co] * x[ci];
+  }
+  const float m = mask[r] ? 1.f : 0.f;
+  f32x4* dst = reinterpret_cast<f32x4*>(F + (int64_t)r * ldf + E);
+#pragma unroll
+  for (int c = 0; c < TCN_HID / 4; ++c) dst[c] = f32x4{o[4 * c] * m, o[4 * c + 1] * m, o[4 * c + 2] * m, o[4 * c + 3] * m};
+}
+
+// masked_max_pool1d (blocks.py:31-47) of the 32 refined channels from level l-1 to level l:
+// out = max over the VALID window entries, 0 if the window has none (see DESIGN.md on the filler).
+__global__ __launch_bounds__(256) void k_refine_pool(float* __restrict__ F, int64_t ldf, int E,
+                                                      const uint8_t* __restrict__ mask_in, int64_t in_row0,
+                                                      int64_t out_row0, int B, int T_in) {
+  const int To = T_in / 2;
+  const int idx = blockIdx.x * 256 + threadIdx.x;       // (row_out, channel quad)
+  const int r = idx >> 3, cq = idx & 7;
+  if (r >= B * To) return;
+  const int b = r / To, i = r - b * To;
+  f32x4 best = {0.f, 0.f, 0.f, 0.f};
+  bool any = false;
+#pragma unroll
+  for (int d = -1; d <= 1; ++d) {
+    const int t = 2 * i + d;
+    if (t < 0 || t >= T_in) continue;
+    const int64_t rin = (int64_t)b * T_in + t;
+    if (!mask_in[rin]) continue;
+    f32x4 v = *reinterpret_cast<const f32x4*>(F + (in_row0 + rin) * ldf + E + cq * 4);
+    if (!any) best = v;
+    else { best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y); best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w); }
+    any = true;
+  }
+  *reinterpret_cast<f32x4*>(F + (out_row0 + r) * ldf + E + cq * 4) = best;
+}
+
+int launch_refine(const RefineArgs& a, const LevelTable& lt, hipStream_t st) {
+  const int rows0 = a.B * a.T0;
+  if (rows0 <= 0) return 0;
+  DCF_CHECK(a.ldf % 4 == 0 && a.E % 4 == 0, "refine: ldf/E must be multiples of 4");
+  dim3 g64((rows0 + 63) / 64), b64(64);
+  hipLaunchKernelGGL(k_refine_in, g64, b64, 0, st, a);
+  float* cur = a.bufA;
+  float* nxt = a.bufB;
+  for (int i = 0; i < a.n_layers; ++i) {
+    DCF_CHECK(a.host_w_dil && a.host_w_dil[i], "refine: missing TCN layer %d", i);
+    hipLaunchKernelGGL(k_tcn_layer, g64, b64, 0, st, (const float*)cur, nxt, a.host_w_dil[i], a.host_b_dil[i], a.host_w_pw[i],
+                       a.host_b_pw[i], a.host_ln_w[i], a.host_ln_b[i], a.mask_all, a.B, a.T0, 1 << i);
+    float* t = cur; cur = nxt; nxt = t;
+  }
+  hipLaunchKernelGGL(k_refine_out, g64, b64, 0, st, (const float*)cur, a.w_out, a.b_out, a.mask_all, a.F, a.ldf, a.E, rows0);
+  for (int l = 1; l < a.n_levels; ++l) {
+    const int Tin = lt.T[l - 1];
+    const int n = a.B * (Tin / 2) * 8;
+    hipLaunchKernelGGL(k_refine_pool, dim3((n + 255) / 256), dim3(256), 0, st, a.F, a.ldf, a.E,
+                       a.mask_all + lt.start[l - 1], (int64_t)lt.start[l - 1], (int64_t)lt.start[l], a.B, Tin);
+  }
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace dcf

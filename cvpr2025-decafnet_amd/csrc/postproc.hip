@@ -1,0 +1,423 @@
+// Proposal decoding and 1-D (soft-)NMS on the GPU.
+//
+//   collect : Evaluator._collect_segments (libs/worker_v2.py:1131-1187)
+//   nms     : nms_1d_cpu      (libs/nms/src/nms_cpu.cpp:20-63)
+//   softnms : softnms_1d_cpu  (libs/nms/src/nms_cpu.cpp:72-172)
+//   voting  : segment_voting  (libs/nms/nms.py:64-103)
+//
+// n <= a few thousand candidates per query, so each problem is latency bound; one 1024-thread
+// workgroup per query keeps everything (keys, segments, alive flags) in LDS and replaces the
+// reference's O(n^2) scalar loops by n short parallel steps.  Index-producing arithmetic (IoU,
+// thresholds, decay) uses exactly the reference's fp32 operation order so that the returned int64
+// indices are bit-identical; ties in the sorts are broken by the lower original index.
+#include "common.h"
+#include "postproc.h"
+
+namespace dcf {
+
+constexpr int NT = 1024;          // threads per workgroup
+constexpr int NW = NT / 64;
+
+// order-preserving map float -> uint32 (larger float => larger key), total order incl. negatives
+__device__ __forceinline__ uint32_t fkey(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// exclusive prefix sum of one int per thread over the workgroup; also returns the total
+__device__ __forceinline__ int block_exscan(int v, int* s_wave /* [NW+1] */, int& total) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    int n = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += n;
+  }
+  __syncthreads();
+  if (lane == 63) s_wave[w] = inc;
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int i = 0; i < NW; ++i) { int t = s_wave[i]; s_wave[i] = acc; acc += t; }
+    s_wave[NW] = acc;
+  }
+  __syncthreads();
+  total = s_wave[NW];
+  return s_wave[w] + inc - v;
+}
+
+// in-LDS bitonic sort, descending, of n_pad (power of two) 64-bit keys
+__device__ __forceinline__ void bitonic_desc(unsigned long long* key, int n_pad) {
+  for (int k = 2; k <= n_pad; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < n_pad; i += NT) {
+        int ixj = i ^ j;
+        if (ixj > i) {
+          unsigned long long a = key[i], b = key[ixj];
+          bool desc = (i & k) == 0;
+          if (desc ? (a < b) : (a > b)) { key[i] = b; key[ixj] = a; }
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ int next_pow2(int n) {
+  int p = 1;
+  while (p < n) p <<= 1;
+  return p;
+}
+
+// ------------------------------------------------------------------------------------------
+// collect segments
+// ------------------------------------------------------------------------------------------
+constexpr int CAND_CAP = 4096;    // >= pre_nms_topk
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(NT) void k_collect(CollectArgs p) {
+  __shared__ unsigned long long key[CAND_CAP];
+  __shared__ int hist[2048];
+  __shared__ int s_wave[NW + 1];
+  __shared__ uint32_t s_prefix;
+  __shared__ int s_need;
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const int S = p.S;
+  const float* logits = p.logits + (size_t)q * S;
+  const float* offs = p.offsets + (size_t)q * S * 2;
+  const uint8_t* mask = p.masks + (size_t)q * S;
+  uint32_t* skey = p.keys + (size_t)q * S;
+
+  // (1) score = sigmoid(logit) * mask, keep > thresh
+  int cnt = 0;
+  for (int i = tid; i < S; i += NT) {
+    float s = sigmoidf_(logits[i]) * (mask[i] ? 1.f : 0.f);
+    uint32_t k = (s > p.pre_nms_thresh) ? __float_as_uint(s) : 0u;   // positive floats order as uints
+    skey[i] = k;
+    cnt += k != 0;
+  }
+  int n_cand;
+  block_exscan(cnt, s_wave, n_cand);
+  const int K = min(min(n_cand, p.pre_nms_topk), CAND_CAP);
+
+  // (2) radix-select the K-th largest key: 11 + 11 + 10 bits
+  uint32_t prefix = 0, pmask = 0;
+  int need = K;                                   // how many still to take from the current bucket
+  if (K > 0) {
+    const int shifts[3] = {21, 10, 0};
+    const int bits[3] = {11, 11, 10};
+    for (int pass = 0; pass < 3; ++pass) {
+      const int nb = 1 << bits[pass];
+      for (int i = tid; i < nb; i += NT) hist[i] = 0;
+      __syncthreads();
+      for (int i = tid; i < S; i += NT) {
+        uint32_t k = skey[i];
+        if (k && (k & pmask) == prefix) atomicAdd(&hist[(k >> shifts[pass]) & (nb - 1)], 1);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int acc = 0, b = nb - 1;
+        for (; b > 0; --b) { if (acc + hist[b] >= need) break; acc += hist[b]; }
+        s_prefix = prefix | ((uint32_t)b << shifts[pass]);
+        s_need = need - acc;
+      }
+      __syncthreads();
+      prefix = s_prefix;
+      need = s_need;
+      pmask |= (uint32_t)(nb - 1) << shifts[pass];
+      __syncthreads();
+    }
+  }
+  const uint32_t kth = prefix;                    // exact K-th largest key; `need` ties are taken in index order
+
+  // (3) ordered compaction of {key > kth} (there are K - need of them) plus the first `need` {key == kth}
+  const int n_greater = K - need;
+  int run_g = 0, run_e = 0;
+  for (int c0 = 0; c0 < S && K > 0; c0 += NT) {
+    const int i = c0 + tid;
+    const uint32_t k = i < S ? skey[i] : 0u;
+    const int g = k > kth, e = (k == kth && k != 0);
+    int tg, te;
+    const int pg = block_exscan(g, s_wave, tg);
+    const int pe = block_exscan(e, s_wave, te);
+    if (g) key[run_g + pg] = ((unsigned long long)k << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i);
+    if (e && run_e + pe < need) key[n_greater + run_e + pe] = ((unsigned long long)k << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i);
+    run_g += tg;
+    run_e += te;
+  }
+  __syncthreads();
+  const int n_pad = next_pow2(max(K, 1));
+  for (int i = K + tid; i < n_pad; i += NT) key[i] = 0ull;
+  // (4) sort: score descending, ties by lower candidate index (stable argsort)
+  bitonic_desc(key, n_pad);
+
+  // (5) decode + length filter, order preserved
+  float* out_segs = p.segs + (size_t)q * p.pre_nms_topk * 2;
+  float* out_scores = p.scores + (size_t)q * p.pre_nms_topk;
+  int run = 0;
+  for (int c0 = 0; c0 < K; c0 += NT) {
+    const int j = c0 + tid;
+    int keep = 0;
+    float left = 0.f, right = 0.f, sc = 0.f;
+    if (j < K) {
+      const unsigned long long kk = key[j];
+      const int i = (int)(0xFFFFFFFFu - (uint32_t)(kk & 0xFFFFFFFFu));
+      sc = __uint_as_float((uint32_t)(kk >> 32));
+      int l = 0;
+      while (l + 1 < p.n_levels && i >= p.off[l + 1]) ++l;
+      const float stride = (float)(1 << l);
+      const float ctr = (float)(i - p.off[l]) * stride;         // PtGenerator point (model.py:703-723)
+      left = ctr - offs[2 * i] * stride;
+      right = ctr + offs[2 * i + 1] * stride;
+      keep = (right - left) > p.seg_len_thresh;
+    }
+    int tot;
+    const int pos = block_exscan(keep, s_wave, tot);
+    if (keep) {
+      out_segs[2 * (run + pos)] = left;
+      out_segs[2 * (run + pos) + 1] = right;
+      out_scores[run + pos] = sc;
+    }
+    run += tot;
+  }
+  if (tid == 0) p.counts[q] = run;
+}
+
+int launch_collect(const CollectArgs& a, int nq, hipStream_t st) {
+  if (nq <= 0) return 0;
+  DCF_CHECK(a.pre_nms_topk >= 1 && a.pre_nms_topk <= CAND_CAP, "collect: pre_nms_topk=%d exceeds %d", a.pre_nms_topk, CAND_CAP);
+  DCF_CHECK(a.n_levels >= 1 && a.n_levels <= 16, "collect: bad n_levels");
+  hipLaunchKernelGGL(k_collect, dim3(nq), dim3(NT), 0, st, a);
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// hard NMS
+// ------------------------------------------------------------------------------------------
+constexpr int NMS_CAP = 4096;
+
+__global__ __launch_bounds__(NT) void k_nms(NmsArgs p) {
+  __shared__ unsigned long long key[NMS_CAP];
+  __shared__ float x1[NMS_CAP], x2[NMS_CAP], ar[NMS_CAP];
+  __shared__ unsigned char alive[NMS_CAP];
+  __shared__ int s_wave[NW + 1];
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const int n = p.counts ? min(p.counts[q], p.n_max) : p.n_max;
+  const float* segs = p.segs + (size_t)q * p.stride * 2;
+  const float* scores = p.scores + (size_t)q * p.stride;
+  long long* out = p.keep + (size_t)q * p.stride;
+  if (n <= 0) { if (tid == 0) p.keep_counts[q] = 0; return; }
+  const int n_pad = next_pow2(n);
+  for (int i = tid; i < n_pad; i += NT)
+    key[i] = i < n ? (((unsigned long long)fkey(scores[i]) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i)) : 0ull;
+  bitonic_desc(key, n_pad);
+  for (int a = tid; a < n; a += NT) {
+    const int i = (int)(0xFFFFFFFFu - (uint32_t)(key[a] & 0xFFFFFFFFu));
+    const float l = segs[2 * i], r = segs[2 * i + 1];
+    x1[a] = l; x2[a] = r;
+    ar[a] = (r - l) + 1e-6f;                         // areas = x2 - x1 + 1e-6  (nms_cpu.cpp:31)
+    alive[a] = 1;
+  }
+  __syncthreads();
+  for (int a = 0; a < n; ++a) {
+    if (!alive[a]) continue;                         // uniform: written before the last barrier
+    const float ix1 = x1[a], ix2 = x2[a], ia = ar[a];
+    for (int b = a + 1 + tid; b < n; b += NT) {
+      if (!alive[b]) continue;
+      const float xx1 = fmaxf(ix1, x1[b]);
+      const float xx2 = fminf(ix2, x2[b]);
+      const float inter = fmaxf(0.f, xx2 - xx1);
+      const float ovr = inter / (ia + ar[b] - inter);
+      if (ovr >= p.iou_thresh) alive[b] = 0;
+    }
+    __syncthreads();
+  }
+  int run = 0;
+  for (int c0 = 0; c0 < n; c0 += NT) {
+    const int a = c0 + tid;
+    const int k = a < n ? alive[a] : 0;
+    int tot;
+    const int pos = block_exscan(k, s_wave, tot);
+    if (k) out[run + pos] = (long long)(0xFFFFFFFFu - (uint32_t)(key[a] & 0xFFFFFFFFu));
+    run += tot;
+  }
+  if (tid == 0) p.keep_counts[q] = run;
+}
+
+int launch_nms(const NmsArgs& a, int nq, hipStream_t st) {
+  if (nq <= 0) return 0;
+  DCF_CHECK(a.n_max >= 0 && a.n_max <= NMS_CAP, "nms: n=%d exceeds the on-chip capacity %d", a.n_max, NMS_CAP);
+  DCF_CHECK(a.stride >= a.n_max, "nms: stride < n_max");
+  hipLaunchKernelGGL(k_nms, dim3(nq), dim3(NT), 0, st, a);
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// soft NMS
+// ------------------------------------------------------------------------------------------
+struct MaxPos { float v; int pos; };
+__device__ __forceinline__ MaxPos better(MaxPos a, MaxPos b) {
+  // first maximum wins: larger value, or equal value at the lower position (nms_cpu.cpp:107-113)
+  if (b.pos >= 0 && (a.pos < 0 || b.v > a.v || (b.v == a.v && b.pos < a.pos))) return b;
+  return a;
+}
+
+__global__ __launch_bounds__(NT) void k_softnms(SoftNmsArgs p) {
+  __shared__ float x1[NMS_CAP], x2[NMS_CAP], sc[NMS_CAP], ar[NMS_CAP];
+  __shared__ int ind[NMS_CAP];
+  __shared__ int slot[NMS_CAP];
+  __shared__ int s_wave[NW + 1];
+  __shared__ float s_v[NW];
+  __shared__ int s_p[NW];
+  __shared__ int s_maxpos;
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n = p.counts ? min(p.counts[q], p.n_max) : p.n_max;
+  const float* segs = p.segs + (size_t)q * p.stride * 2;
+  const float* scores = p.scores + (size_t)q * p.stride;
+  float* dets = p.dets + (size_t)q * p.stride * 3;
+  long long* out = p.inds + (size_t)q * p.stride;
+  if (n <= 0) { if (tid == 0) p.out_counts[q] = 0; return; }
+  for (int i = tid; i < n; i += NT) {
+    const float l = segs[2 * i], r = segs[2 * i + 1];
+    x1[i] = l; x2[i] = r; sc[i] = scores[i]; ar[i] = (r - l) + 1e-6f; ind[i] = i;
+  }
+  __syncthreads();
+  int nsegs = n;
+  const int iters = p.max_iters > 0 ? p.max_iters : n;
+  int i = 0;
+  for (; i < nsegs && i < iters; ++i) {
+    // ---- argmax over [i, nsegs)
+    MaxPos best{0.f, -1};
+    for (int pos = i + tid; pos < nsegs; pos += NT) best = better(best, MaxPos{sc[pos], pos});
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      MaxPos o{__shfl_xor(best.v, off, 64), __shfl_xor(best.pos, off, 64)};
+      best = better(best, o);
+    }
+    if (lane == 0) { s_v[w] = best.v; s_p[w] = best.pos; }
+    __syncthreads();
+    if (tid == 0) {
+      MaxPos b{s_v[0], s_p[0]};
+      for (int k = 1; k < NW; ++k) b = better(b, MaxPos{s_v[k], s_p[k]});
+      const int mp = b.pos;
+      // swap i <-> mp and emit the detection (nms_cpu.cpp:115-133)
+      const float ix1 = x1[mp], ix2 = x2[mp], isc = sc[mp], iar = ar[mp];
+      const int iind = ind[mp];
+      dets[i * 3 + 0] = ix1; dets[i * 3 + 1] = ix2; dets[i * 3 + 2] = isc;
+      x1[mp] = x1[i]; x2[mp] = x2[i]; sc[mp] = sc[i]; ar[mp] = ar[i]; ind[mp] = ind[i];
+      x1[i] = ix1; x2[i] = ix2; sc[i] = isc; ar[i] = iar; ind[i] = iind;
+      s_maxpos = mp;
+    }
+    __syncthreads();
+    const float ix1 = x1[i], ix2 = x2[i], ia = ar[i];
+    // ---- decay every later segment (nms_cpu.cpp:137-155)
+    int dead_cnt = 0;
+    for (int pos = i + 1 + tid; pos < nsegs; pos += NT) {
+      const float xx1 = fmaxf(ix1, x1[pos]);
+      const float xx2 = fminf(ix2, x2[pos]);
+      const float inter = fmaxf(0.f, xx2 - xx1);
+      const float ovr = inter / (ia + ar[pos] - inter);
+      float weight = 1.f;
+      if (p.method == 0) { if (ovr >= p.iou_thresh) weight = 0.f; }
+      else if (p.method == 1) { if (ovr >= p.iou_thresh) weight = 1.f - ovr; }
+      else if (p.method == 2) {
+        // glibc expf is correctly rounded in (almost) all cases; so is exp in double rounded to float
+        weight = (float)exp((double)(-(ovr * ovr) / p.sigma));
+      }
+      const float s = sc[pos] * weight;
+      sc[pos] = s;
+      dead_cnt += s < p.min_score;
+    }
+    int n_dead;
+    block_exscan(dead_cnt, s_wave, n_dead);
+    if (n_dead == 0) continue;                        // uniform
+    // ---- emulate the sequential "swap with the last segment" pruning (nms_cpu.cpp:157-165):
+    // survivors keep their slots; the k-th dead slot (left to right) inside the new range is
+    // filled by the k-th surviving segment counted from the right end of the old range.
+    const int first = i + 1;
+    const int n_alive = (nsegs - first) - n_dead;
+    const int new_n = first + n_alive;
+    // each thread owns a contiguous run of positions so that prefix counts are ordered
+    const int span = nsegs - first;
+    const int per = (span + NT - 1) / NT;
+    const int lo = first + tid * per, hi = min(lo + per, nsegs);
+    int c_dead_left = 0, c_alive_right = 0;
+    for (int pos = lo; pos < hi; ++pos) {
+      const bool dead = sc[pos] < p.min_score;
+      if (pos < new_n) c_dead_left += dead; else c_alive_right += !dead;
+    }
+    int tot_d, tot_a;
+    int pd = block_exscan(c_dead_left, s_wave, tot_d);
+    int pa = block_exscan(c_alive_right, s_wave, tot_a);
+    for (int pos = lo; pos < hi; ++pos) {
+      if (pos < new_n && sc[pos] < p.min_score) slot[pd++] = pos;
+    }
+    __syncthreads();
+    for (int pos = lo; pos < hi; ++pos) {
+      if (pos >= new_n && !(sc[pos] < p.min_score)) {
+        // rank from the right = tot_a - 1 - (rank from the left)
+        const int dst = slot[tot_a - 1 - pa];
+        ++pa;
+        x1[dst] = x1[pos]; x2[dst] = x2[pos]; sc[dst] = sc[pos]; ar[dst] = ar[pos]; ind[dst] = ind[pos];
+      }
+    }
+    __syncthreads();
+    nsegs = new_n;
+  }
+  const int n_out = (p.max_iters > 0) ? min(i, nsegs) : nsegs;
+  for (int k = tid; k < n_out; k += NT) out[k] = (long long)ind[k];
+  if (tid == 0) p.out_counts[q] = n_out;
+}
+
+int launch_softnms(const SoftNmsArgs& a, int nq, hipStream_t st) {
+  if (nq <= 0) return 0;
+  DCF_CHECK(a.n_max >= 0 && a.n_max <= NMS_CAP, "softnms: n=%d exceeds the on-chip capacity %d", a.n_max, NMS_CAP);
+  DCF_CHECK(a.method >= 0 && a.method <= 2, "softnms: method must be 0, 1 or 2");
+  DCF_CHECK(a.stride >= a.n_max, "softnms: stride < n_max");
+  hipLaunchKernelGGL(k_softnms, dim3(nq), dim3(NT), 0, st, a);
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// segment voting: one wavefront per NMS survivor
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_voting(VotingArgs p) {
+  const int q = blockIdx.y, i = blockIdx.x, lane = threadIdx.x;
+  const int n1 = p.n1_counts ? min(p.n1_counts[q], p.n1_max) : p.n1_max;
+  const int n2 = p.n2_counts ? min(p.n2_counts[q], p.n2_max) : p.n2_max;
+  if (i >= n1) return;
+  const float* ns = p.nms_segs + ((size_t)q * p.n1_stride + i) * p.nms_ld;
+  const float* as = p.all_segs + (size_t)q * p.n2_stride * 2;
+  const float* sc = p.all_scores + (size_t)q * p.n2_stride;
+  const float a0 = ns[0], a1 = ns[1];
+  float sw = 0.f, sl = 0.f, sr = 0.f;
+  for (int j = lane; j < n2; j += 64) {
+    const float b0 = as[2 * j], b1 = as[2 * j + 1];
+    const float left = fmaxf(a0, b0), right = fminf(a1, b1);
+    const float ov = fmaxf(right - left, 0.f);
+    const float uni = (a1 - a0) + (b1 - b0) - ov;
+    const float iou = ov / uni;
+    const float wgt = (iou >= p.iou_thresh) ? sc[j] : 0.f;
+    sw += wgt; sl += wgt * b0; sr += wgt * b1;
+  }
+  sw = wave_sum(sw); sl = wave_sum(sl); sr = wave_sum(sr);
+  if (lane == 0) {
+    float* o = p.out + ((size_t)q * p.n1_stride + i) * 2;
+    o[0] = sl / sw;
+    o[1] = sr / sw;
+  }
+}
+
+int launch_voting(const VotingArgs& a, int nq, hipStream_t st) {
+  if (nq <= 0 || a.n1_max <= 0) return 0;
+  hipLaunchKernelGGL(k_voting, dim3(a.n1_max, nq), dim3(64), 0, st, a);
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace dcf

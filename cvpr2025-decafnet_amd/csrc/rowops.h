@@ -1,0 +1,68 @@
+// Launchers of the position-wise kernels (rowops.hip).  Token-major activations, see common.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dcf {
+
+constexpr int DCF_MAX_BATCH = 64;   // queries processed together in one batched forward
+
+struct LnArgs {
+  const float* X; int64_t ldx;
+  float* Y; int64_t ldy;
+  const float* w; const float* b;   // affine (C) or nullptr
+  int rows, C;
+  int relu;                         // apply ReLU after LN
+  int skip_ln;                      // 1: no normalisation at all (used for a bare '+ pe * mask')
+  const float* pe;                  // optional (T, C) position encoding added where mask != 0
+  const uint8_t* mask;              // [rows] (needed with pe)
+  int T;                            // rows per batch element (pe index = row % T)
+};
+
+struct DecPreArgs {
+  const float* X; int64_t ldx;      // [B*T][ldx]
+  const uint8_t* mask;              // [B*T]
+  const float* ln_q_w; const float* ln_q_b;
+  const float* dw;                  // depthwise k3 weight repacked [3][C]
+  const float* qn_w; const float* qn_b;
+  float* Qc; float* Xa;             // [B*T][C]
+  int B, T, C;
+};
+
+struct EncPreArgs {
+  const float* X; int64_t ldx;      // [B*T_in][ldx]
+  const uint8_t* mask_in;           // [B*T_in]
+  const float* ln_w; const float* ln_b;
+  const float* dw_q; const float* dw_k; const float* dw_v;     // [3][C] each
+  const float* qn_w; const float* qn_b; const float* kn_w; const float* kn_b; const float* vn_w; const float* vn_b;
+  float* Qc; float* Kc; float* Vc;  // [B*T_out][C]
+  float* Skip;                      // [B*T_out][C] (stride 2 only)
+  int B, T_in, C;
+};
+
+struct TextMeta {                   // lives in device memory
+  const float* text[DCF_MAX_BATCH];        // (TE, len) channel-major per query
+  const uint8_t* text_mask[DCF_MAX_BATCH]; // (len) or nullptr
+  int len[DCF_MAX_BATCH];
+};
+
+struct TextLnArgs {
+  const TextMeta* meta;
+  float* out;                       // [B*Lkmax][TE]
+  uint8_t* kvmask;                  // [B*Lkmax] or nullptr
+  const float* w; const float* b;   // ln_xattn_kv affine (TE)
+  int Lkmax, TE;
+};
+
+int launch_rowflags(const uint8_t* mask, uint8_t* nbr, int T, int rows, hipStream_t st);
+int launch_mask_down(const uint8_t* in, uint8_t* out, int rows_out, hipStream_t st);
+int launch_vidmap_combine(const float* P1, const float* P2, const float* bias, const float* gate, const uint8_t* mask,
+                          float* X, int T, int rows, int E, hipStream_t st);
+int launch_ln(const LnArgs& a, hipStream_t st);
+int launch_dec_pre(const DecPreArgs& a, hipStream_t st);
+int launch_dec_mid(const float* Xa, const float* H, const float* ln_w, const float* ln_b, float* Q3, float* Xn, int rows,
+                   int C, hipStream_t st);
+int launch_enc_pre(const EncPreArgs& a, int stride, hipStream_t st);
+int launch_text_ln(const TextLnArgs& a, int B, hipStream_t st);
+
+}  // namespace dcf

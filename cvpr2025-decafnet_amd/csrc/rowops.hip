@@ -1,0 +1,355 @@
+// Position-wise ("row") kernels of the grounding path: everything between the dense GEMMs.
+//
+// One 64-lane wavefront owns one clip position (a row of E channels, 16 B per lane per
+// 256-channel chunk => every global access is a fully coalesced 1 KiB wave transaction)
+// and walks a strip of consecutive positions so that the k3 depthwise convolutions / k3 s2
+// max-pool can slide a 3-row window through registers: each input row is read and
+// layer-normalised exactly once.  All of these kernels are HBM/L2-bandwidth bound.
+#include "common.h"
+#include "rowops.h"
+
+namespace dcf {
+
+constexpr int STRIP = 16;  // output rows per wavefront
+
+// ------------------------------------------------------------------------------------------
+// masks
+// ------------------------------------------------------------------------------------------
+// nbr[r]: bit0 = row usable, bit1 = left neighbour (same batch) usable, bit2 = right.
+__global__ void k_rowflags(const uint8_t* __restrict__ mask, uint8_t* __restrict__ nbr, int T, int rows) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  int t = r % T;
+  unsigned f = mask[r] ? 1u : 0u;
+  if (t > 0 && mask[r - 1]) f |= 2u;
+  if (t < T - 1 && mask[r + 1]) f |= 4u;
+  nbr[r] = (uint8_t)f;
+}
+
+// stride-2 MaskedConv1D mask: nearest downsample == mask[2i] (libs/modeling/blocks.py:101-105)
+__global__ void k_mask_down(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int rows_out) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < rows_out) out[r] = in[2 * r];
+}
+
+// ------------------------------------------------------------------------------------------
+// vid_map epilogue: X0[b,t,:] = m * (g * P1[t,:] + P2[t,:]) + bias     (model.py:543-555)
+// P1 = W[:, :D] . vid, P2 = W[:, D:] . shallow are query independent and computed once.
+// ------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) void k_vidmap_combine(const float* __restrict__ P1, const float* __restrict__ P2,
+                                                         const float* __restrict__ bias, const float* __restrict__ gate,
+                                                         const uint8_t* __restrict__ mask, float* __restrict__ X,
+                                                         int T, int rows, int E) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int t = r % T;
+  const float m = mask[r] ? 1.f : 0.f;
+  const float g = gate[r];
+  Row<NCH> a, b;
+  a.load(P1 + (int64_t)t * E, E, lane);
+  if (P2) b.load(P2 + (int64_t)t * E, E, lane); else b.zero();
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    int c = 256 * j + 4 * lane;
+    if (c < E) {
+      f32x4 bb = *reinterpret_cast<const f32x4*>(bias + c);
+      a.v[j] = m * (g * a.v[j] + b.v[j]) + bb;
+    }
+  }
+  a.store(X + (int64_t)r * E, E, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// generic LayerNorm row kernel:  Y = [relu] LN(X) [+ pe[t] * mask]
+// ------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) void k_ln(LnArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= p.rows) return;
+  Row<NCH> x;
+  x.load(p.X + (int64_t)r * p.ldx, p.C, lane);
+  if (!p.skip_ln) row_layernorm(x, p.C, lane, p.w, p.b);
+  const bool relu = p.relu;
+  const float* pe = nullptr;
+  if (p.pe && p.mask[r]) pe = p.pe + (int64_t)(r % p.T) * p.C;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    int c = 256 * j + 4 * lane;
+    if (c < p.C) {
+      f32x4 v = x.v[j];
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (pe) v += *reinterpret_cast<const f32x4*>(pe + c);
+      x.v[j] = v;
+    }
+  }
+  x.store(p.Y + (int64_t)r * p.ldy, p.C, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// helpers for the sliding-window kernels
+// ------------------------------------------------------------------------------------------
+template <int NCH>
+__device__ __forceinline__ void axpy3(Row<NCH>& out, const Row<NCH>& a, const Row<NCH>& b, const Row<NCH>& c,
+                                      const float* __restrict__ w /* [3][C] */, int C, int lane) {
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    int ch = 256 * j + 4 * lane;
+    if (ch < C) {
+      f32x4 w0 = *reinterpret_cast<const f32x4*>(w + ch);
+      f32x4 w1 = *reinterpret_cast<const f32x4*>(w + C + ch);
+      f32x4 w2 = *reinterpret_cast<const f32x4*>(w + 2 * C + ch);
+      out.v[j] = w0 * a.v[j] + w1 * b.v[j] + w2 * c.v[j];
+    } else {
+      out.v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// TransformerDecoder front half (libs/modeling/blocks.py:632-645, :513-516):
+//   q  = x * m
+//   Qc = q_norm( dwconv3( ln_xattn_q(q) * m ) )          -> input of the query projection
+//   Xa = adaln(q * m)  (LayerNorm without affine)          -> modulated later by the xattn output
+// ------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) void k_dec_pre(DecPreArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int strips_per_b = (p.T + STRIP - 1) / STRIP;
+  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= strips_per_b * p.B) return;
+  const int b = s / strips_per_b;
+  const int t0 = (s % strips_per_b) * STRIP;
+  const int64_t base = (int64_t)b * p.T;
+  const int C = p.C;
+
+  // normalised-and-masked row (conv input), zero outside [0,T) or where the mask is 0
+  auto conv_in = [&](int t, Row<NCH>& raw, Row<NCH>& ln) __attribute__((always_inline)) {
+    if (t >= 0 && t < p.T && p.mask[base + t]) {
+      raw.load(p.X + (base + t) * p.ldx, C, lane);
+      ln = raw;
+      row_layernorm(ln, C, lane, p.ln_q_w, p.ln_q_b);
+    } else {
+      raw.zero();
+      ln.zero();
+    }
+  };
+
+  Row<NCH> raw_c, raw_n, prev, cur, nxt, tmp;
+  conv_in(t0 - 1, tmp, prev);
+  conv_in(t0, raw_c, cur);
+  const int t1 = min(t0 + STRIP, p.T);
+  for (int t = t0; t < t1; ++t) {
+    conv_in(t + 1, raw_n, nxt);
+    Row<NCH> q;
+    axpy3(q, prev, cur, nxt, p.dw, C, lane);
+    row_layernorm(q, C, lane, p.qn_w, p.qn_b);
+    q.store(p.Qc + (base + t) * (int64_t)C, C, lane);
+    Row<NCH> xa = raw_c;                       // already zero where masked
+    row_layernorm(xa, C, lane, nullptr, nullptr);
+    xa.store(p.Xa + (base + t) * (int64_t)C, C, lane);
+    prev = cur; cur = nxt; raw_c = raw_n;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// TransformerDecoder middle (blocks.py:643-648):  q3 = Xa * scale + shift,  Xn = ln_ffn(q3)
+// H = xattn output (rows, 2C): scale = H[:, :C], shift = H[:, C:]
+// ------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) void k_dec_mid(const float* __restrict__ Xa, const float* __restrict__ H,
+                                                  const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                  float* __restrict__ Q3, float* __restrict__ Xn, int rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  Row<NCH> x, sc, sh;
+  x.load(Xa + (int64_t)r * C, C, lane);
+  sc.load(H + (int64_t)r * 2 * C, C, lane);
+  sh.load(H + (int64_t)r * 2 * C + C, C, lane);
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) x.v[j] = x.v[j] * sc.v[j] + sh.v[j];
+  x.store(Q3 + (int64_t)r * C, C, lane);
+  row_layernorm(x, C, lane, ln_w, ln_b);
+  x.store(Xn + (int64_t)r * C, C, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// TransformerEncoder front half (blocks.py:578-585, :462-469) for conv stride S in {1, 2}:
+//   x    = x * m
+//   skip = S == 2 ? masked_max_pool1d(x, m)  (blocks.py:31-47)  : x
+//   xn   = ln_attn(x);  {q,k,v}c = {q,k,v}_norm( dwconv3_strideS( xn * m ) )
+// Output row i reads input rows S*i-1, S*i, S*i+1.
+// ------------------------------------------------------------------------------------------
+template <int NCH, int S>
+__global__ __launch_bounds__(256) void k_enc_pre(EncPreArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int To = p.T_in / S;
+  const int strips_per_b = (To + STRIP - 1) / STRIP;
+  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= strips_per_b * p.B) return;
+  const int b = s / strips_per_b;
+  const int i0 = (s % strips_per_b) * STRIP;
+  const int64_t ibase = (int64_t)b * p.T_in;
+  const int64_t obase = (int64_t)b * To;
+  const int C = p.C;
+
+  auto conv_in = [&](int t, Row<NCH>& raw, Row<NCH>& ln, bool& valid) __attribute__((always_inline)) {
+    valid = (t >= 0 && t < p.T_in && p.mask_in[ibase + t]);
+    if (valid) {
+      raw.load(p.X + (ibase + t) * p.ldx, C, lane);
+      ln = raw;
+      row_layernorm(ln, C, lane, p.ln_w, p.ln_b);
+    } else {
+      raw.zero();
+      ln.zero();
+    }
+  };
+
+  Row<NCH> rp, rc, rn, lp, lc, ln_;
+  bool vp, vc, vn;
+  conv_in(S * i0 - 1, rp, lp, vp);
+  const int i1 = min(i0 + STRIP, To);
+  for (int i = i0; i < i1; ++i) {
+    if (S == 2 || i == i0) conv_in(S * i, rc, lc, vc);
+    conv_in(S * i + 1, rn, ln_, vn);
+    Row<NCH> o;
+    axpy3(o, lp, lc, ln_, p.dw_q, C, lane);
+    row_layernorm(o, C, lane, p.qn_w, p.qn_b);
+    o.store(p.Qc + (obase + i) * (int64_t)C, C, lane);
+    axpy3(o, lp, lc, ln_, p.dw_k, C, lane);
+    row_layernorm(o, C, lane, p.kn_w, p.kn_b);
+    o.store(p.Kc + (obase + i) * (int64_t)C, C, lane);
+    axpy3(o, lp, lc, ln_, p.dw_v, C, lane);
+    row_layernorm(o, C, lane, p.vn_w, p.vn_b);
+    o.store(p.Vc + (obase + i) * (int64_t)C, C, lane);
+    if (S == 2) {
+      // max over the valid window entries; 0 when the output position itself is padded
+      // (its mask is mask_in[2i] == vc) -- the global-min filler never wins, see DESIGN.md
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {
+        f32x4 m = rc.v[j];
+        if (vp) { m.x = fmaxf(m.x, rp.v[j].x); m.y = fmaxf(m.y, rp.v[j].y); m.z = fmaxf(m.z, rp.v[j].z); m.w = fmaxf(m.w, rp.v[j].w); }
+        if (vn) { m.x = fmaxf(m.x, rn.v[j].x); m.y = fmaxf(m.y, rn.v[j].y); m.z = fmaxf(m.z, rn.v[j].z); m.w = fmaxf(m.w, rn.v[j].w); }
+        o.v[j] = vc ? m : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      o.store(p.Skip + (obase + i) * (int64_t)C, C, lane);
+      rp = rn; lp = ln_; vp = vn;
+    } else {
+      rp = rc; lp = lc; vp = vc;
+      rc = rn; lc = ln_; vc = vn;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// text side of the cross attention (blocks.py:639): kvn = ln_xattn_kv(text).  The encoded
+// text arrives in the reference layout (1, TE, Lk) channel-major, one tensor per query;
+// output is token-major (B * Lkmax, TE) zero-padded, plus the key mask.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_text_ln(TextLnArgs p) {
+  const int j = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const int len = p.meta->len[b];
+  float* out = p.out + ((int64_t)b * p.Lkmax + j) * p.TE;
+  if (j >= len) {
+    for (int c = lane; c < p.TE; c += 64) out[c] = 0.f;
+    if (lane == 0 && p.kvmask) p.kvmask[b * p.Lkmax + j] = 0;
+    return;
+  }
+  const float* src = p.meta->text[b];
+  float s = 0.f;
+  for (int c = lane; c < p.TE; c += 64) s += src[(int64_t)c * len + j];
+  const float mean = wave_sum(s) / (float)p.TE;
+  float sq = 0.f;
+  for (int c = lane; c < p.TE; c += 64) { float d = src[(int64_t)c * len + j] - mean; sq += d * d; }
+  const float rs = 1.0f / sqrtf(wave_sum(sq) / (float)p.TE + 1e-5f);
+  for (int c = lane; c < p.TE; c += 64) out[c] = (src[(int64_t)c * len + j] - mean) * rs * p.w[c] + p.b[c];
+  if (lane == 0 && p.kvmask) p.kvmask[b * p.Lkmax + j] = p.meta->text_mask[b] ? p.meta->text_mask[b][j] : 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+#define DISPATCH_NCH(C, CALL)                                                     \
+  do {                                                                            \
+    int _n = ((C) + 255) / 256;                                                   \
+    DCF_CHECK((C) % 4 == 0 && _n >= 1 && _n <= 4, "channels=%d unsupported (need C %% 4 == 0, C <= 1024)", (int)(C)); \
+    switch (_n) {                                                                 \
+      case 1: { constexpr int NCH = 1; CALL; } break;                             \
+      case 2: { constexpr int NCH = 2; CALL; } break;                             \
+      case 3: { constexpr int NCH = 3; CALL; } break;                             \
+      default: { constexpr int NCH = 4; CALL; } break;                            \
+    }                                                                             \
+    DCF_HIP(hipGetLastError());                                                   \
+  } while (0)
+
+int launch_rowflags(const uint8_t* mask, uint8_t* nbr, int T, int rows, hipStream_t st) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(k_rowflags, dim3((rows + 255) / 256), dim3(256), 0, st, mask, nbr, T, rows);
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_mask_down(const uint8_t* in, uint8_t* out, int rows_out, hipStream_t st) {
+  if (rows_out <= 0) return 0;
+  hipLaunchKernelGGL(k_mask_down, dim3((rows_out + 255) / 256), dim3(256), 0, st, in, out, rows_out);
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_vidmap_combine(const float* P1, const float* P2, const float* bias, const float* gate, const uint8_t* mask,
+                          float* X, int T, int rows, int E, hipStream_t st) {
+  if (rows <= 0) return 0;
+  DISPATCH_NCH(E, hipLaunchKernelGGL((k_vidmap_combine<NCH>), dim3((rows + 3) / 4), dim3(256), 0, st, P1, P2, bias, gate,
+                                     mask, X, T, rows, E));
+  return 0;
+}
+
+int launch_ln(const LnArgs& a, hipStream_t st) {
+  if (a.rows <= 0) return 0;
+  DCF_CHECK(a.ldx % 4 == 0 && a.ldy % 4 == 0, "launch_ln: row pitch must be a multiple of 4");
+  DCF_CHECK(!a.pe || (a.mask && a.T > 0), "launch_ln: pe needs mask and T");
+  DISPATCH_NCH(a.C, hipLaunchKernelGGL((k_ln<NCH>), dim3((a.rows + 3) / 4), dim3(256), 0, st, a));
+  return 0;
+}
+
+int launch_dec_pre(const DecPreArgs& a, hipStream_t st) {
+  if (a.B * a.T <= 0) return 0;
+  int strips = a.B * ((a.T + STRIP - 1) / STRIP);
+  DISPATCH_NCH(a.C, hipLaunchKernelGGL((k_dec_pre<NCH>), dim3((strips + 3) / 4), dim3(256), 0, st, a));
+  return 0;
+}
+
+int launch_dec_mid(const float* Xa, const float* H, const float* ln_w, const float* ln_b, float* Q3, float* Xn, int rows,
+                   int C, hipStream_t st) {
+  if (rows <= 0) return 0;
+  DISPATCH_NCH(C, hipLaunchKernelGGL((k_dec_mid<NCH>), dim3((rows + 3) / 4), dim3(256), 0, st, Xa, H, ln_w, ln_b, Q3, Xn,
+                                     rows, C));
+  return 0;
+}
+
+int launch_enc_pre(const EncPreArgs& a, int stride, hipStream_t st) {
+  DCF_CHECK(stride == 1 || stride == 2, "enc_pre: stride %d unsupported", stride);
+  DCF_CHECK(a.T_in % stride == 0, "enc_pre: T_in %% stride != 0");
+  if (a.B * a.T_in <= 0) return 0;
+  int To = a.T_in / stride;
+  int strips = a.B * ((To + STRIP - 1) / STRIP);
+  if (stride == 1) {
+    DISPATCH_NCH(a.C, hipLaunchKernelGGL((k_enc_pre<NCH, 1>), dim3((strips + 3) / 4), dim3(256), 0, st, a));
+  } else {
+    DCF_CHECK(a.Skip, "enc_pre: stride 2 needs a skip buffer");
+    DISPATCH_NCH(a.C, hipLaunchKernelGGL((k_enc_pre<NCH, 2>), dim3((strips + 3) / 4), dim3(256), 0, st, a));
+  }
+  return 0;
+}
+
+int launch_text_ln(const TextLnArgs& a, int B, hipStream_t st) {
+  if (B <= 0 || a.Lkmax <= 0) return 0;
+  hipLaunchKernelGGL(k_text_ln, dim3(a.Lkmax, B), dim3(64), 0, st, a);
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace dcf

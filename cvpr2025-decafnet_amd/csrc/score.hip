@@ -1,0 +1,167 @@
+// Sidekick/expert clip scoring and the block top-k gate.
+//
+// Scoring (libs/modeling/model.py:500-505) is one streaming pass over the (D, T) shallow feature
+// matrix (64 MiB at D=1024, T=16384): lanes run along T (16 B per lane, 1 KiB per wave
+// transaction), the D channels are cut into SCORE_SLICES slices so that >= 1024 wavefronts are in
+// flight, and the per-slice partial sums are combined in a fixed order (deterministic: the gate
+// below is a discrete decision, so no float atomics).
+//
+// Gate (model.py:531-541): ceil-mode block mean over `sn` clips -> ascending rank -> keep the top
+// int(sratio * n) blocks -> nearest-neighbour upsample back to clips.  One workgroup per query,
+// rank-by-counting in LDS (n <= 8192 blocks).  Ties are broken by block index (stable); the
+// reference's argsort leaves tie order unspecified.
+#include "common.h"
+#include "score.h"
+
+namespace dcf {
+
+__global__ __launch_bounds__(256) void k_text_cls_norm(const float* __restrict__ cls, float* __restrict__ tn, int D, int norm) {
+  __shared__ float red[4];
+  const int q = blockIdx.x, tid = threadIdx.x;
+  float s = 0.f;
+  for (int c = tid; c < D; c += 256) { float v = cls[(size_t)q * D + c]; s += v * v; }
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  const float nrm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+  const float inv = norm ? 1.0f / (nrm + 1e-4f) : 1.0f;
+  for (int c = tid; c < D; c += 256) tn[(size_t)q * D + c] = cls[(size_t)q * D + c] * inv;
+}
+
+// grid = (ceil(T/256), SCORE_SLICES); block = 64 (one wave, 4 clips per lane)
+template <int NQ>
+__global__ __launch_bounds__(64) void k_sidekick_partial(ScoreArgs p, int q0) {
+  const int lane = threadIdx.x;
+  const int t = (blockIdx.x * 64 + lane) * 4;
+  const int slice = blockIdx.y;
+  const int cps = (p.D + SCORE_SLICES - 1) / SCORE_SLICES;
+  const int c0 = slice * cps, c1 = min(c0 + cps, p.D);
+  const bool vec = (p.T & 3) == 0;
+  f32x4 ss = {0.f, 0.f, 0.f, 0.f};
+  f32x4 dot[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) dot[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (t < p.T) {
+    for (int c = c0; c < c1; ++c) {
+      const float* src = p.shallow + (size_t)c * p.T + t;
+      f32x4 x = {0.f, 0.f, 0.f, 0.f};
+      if (vec) x = *reinterpret_cast<const f32x4*>(src);
+      else { x.x = src[0]; if (t + 1 < p.T) x.y = src[1]; if (t + 2 < p.T) x.z = src[2]; if (t + 3 < p.T) x.w = src[3]; }
+      ss += x * x;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) dot[q] += x * p.tn[(size_t)(q0 + q) * p.D + c];   // wave-uniform scalar load
+    }
+    float* dst = p.partial + ((size_t)slice * (p.NQ + 1)) * p.T + t;
+    const int n = min(4, p.T - t);
+    for (int i = 0; i < n; ++i) {
+      if (q0 == 0) dst[i] = ss[i];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) dst[(size_t)(1 + q0 + q) * p.T + i] = dot[q][i];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_sidekick_final(ScoreArgs p) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= p.T) return;
+  float ss = 0.f;
+  for (int s = 0; s < SCORE_SLICES; ++s) ss += p.partial[((size_t)s * (p.NQ + 1)) * p.T + t];
+  const float inv = p.norm ? 1.0f / (sqrtf(ss) + 1e-4f) : 1.0f;
+  for (int q = 0; q < p.NQ; ++q) {
+    float d = 0.f;
+    for (int s = 0; s < SCORE_SLICES; ++s) d += p.partial[((size_t)s * (p.NQ + 1) + 1 + q) * p.T + t];
+    p.correl[(size_t)q * p.T + t] = d * inv;
+  }
+}
+
+int launch_sidekick(const ScoreArgs& a, hipStream_t st) {
+  if (a.NQ <= 0 || a.T <= 0) return 0;
+  hipLaunchKernelGGL(k_text_cls_norm, dim3(a.NQ), dim3(256), 0, st, a.text_cls, a.tn, a.D, a.norm);
+  dim3 grid((a.T + 255) / 256, SCORE_SLICES);
+  for (int q0 = 0; q0 < a.NQ; q0 += SCORE_MAXQ) {
+    int n = a.NQ - q0 < SCORE_MAXQ ? a.NQ - q0 : SCORE_MAXQ;
+    switch (n) {
+      case 1: hipLaunchKernelGGL(k_sidekick_partial<1>, grid, dim3(64), 0, st, a, q0); break;
+      case 2: hipLaunchKernelGGL(k_sidekick_partial<2>, grid, dim3(64), 0, st, a, q0); break;
+      case 3: hipLaunchKernelGGL(k_sidekick_partial<3>, grid, dim3(64), 0, st, a, q0); break;
+      case 4: hipLaunchKernelGGL(k_sidekick_partial<4>, grid, dim3(64), 0, st, a, q0); break;
+      case 5: hipLaunchKernelGGL(k_sidekick_partial<5>, grid, dim3(64), 0, st, a, q0); break;
+      case 6: hipLaunchKernelGGL(k_sidekick_partial<6>, grid, dim3(64), 0, st, a, q0); break;
+      case 7: hipLaunchKernelGGL(k_sidekick_partial<7>, grid, dim3(64), 0, st, a, q0); break;
+      default: hipLaunchKernelGGL(k_sidekick_partial<8>, grid, dim3(64), 0, st, a, q0); break;
+    }
+  }
+  hipLaunchKernelGGL(k_sidekick_final, dim3((a.T + 255) / 256), dim3(256), 0, st, a);
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+constexpr int GATE_MAX_BLOCKS = 8192;
+
+__global__ __launch_bounds__(1024) void k_gate(GateArgs p) {
+  __shared__ float pooled[GATE_MAX_BLOCKS];
+  __shared__ uint8_t sel[GATE_MAX_BLOCKS];
+  __shared__ int s_len;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* correl = p.correl + (size_t)(p.q0 + b) * p.T;
+  // vid_len = vid_masks.sum()  (model.py:531), computed on device: no host sync
+  if (tid == 0) s_len = 0;
+  __syncthreads();
+  int cnt = 0;
+  for (int t = tid; t < p.T; t += 1024) cnt += p.vid_mask[t] ? 1 : 0;
+  cnt = (int)wave_sum((float)cnt);
+  if ((tid & 63) == 0 && cnt) atomicAdd(&s_len, cnt);
+  __syncthreads();
+  const int len = s_len;
+  const int n = (len + p.sn - 1) / p.sn;             // avg_pool1d(ceil_mode=True)
+  // block means: sequential fp32 sum then one division by the true window size (ATen avg_pool2d)
+  for (int i = tid; i < n; i += 1024) {
+    const int s0 = i * p.sn, s1 = min(s0 + p.sn, len);
+    float acc = 0.f;
+    for (int t = s0; t < s1; ++t) acc += correl[t];
+    pooled[i] = acc / (float)(s1 - s0);
+  }
+  __syncthreads();
+  const int k = (int)(p.sratio * (double)n);          // int(ratio * n): truncation of the double product
+  for (int i = tid; i < n; i += 1024) {
+    unsigned char s = 1;
+    if (k > 0) {                                      // ranked[-0:] keeps everything (model.py:535)
+      const float v = pooled[i];
+      int rank = 0;
+      for (int j = 0; j < n; ++j) {
+        const float u = pooled[j];
+        rank += (u < v || (u == v && j < i)) ? 1 : 0;
+      }
+      s = rank >= n - k;
+    }
+    sel[i] = s;
+  }
+  __syncthreads();
+  // nearest upsample (ATen upsample_nearest1d): identity / >>1 / min(floor(t * float(n/len)), n-1)
+  const float scale = (len > 0) ? (float)n / (float)len : 0.f;
+  for (int t = tid; t < p.T; t += 1024) {
+    float g = 0.f;
+    if (t < len) {
+      int src;
+      if (len == n) src = t;
+      else if (len == 2 * n) src = t >> 1;
+      else src = min((int)floorf((float)t * scale), n - 1);
+      g = sel[src] ? 1.f : 0.f;
+    }
+    p.gate[(size_t)b * p.T + t] = g;
+    const bool m = p.vid_mask[t] != 0;
+    p.mask_out[(size_t)b * p.T + t] = p.msf ? m : (m && g != 0.f);
+  }
+}
+
+int launch_gate(const GateArgs& a, hipStream_t st) {
+  if (a.B <= 0) return 0;
+  DCF_CHECK(a.sn >= 1, "gate: sn must be >= 1");
+  DCF_CHECK((a.T + a.sn - 1) / a.sn <= GATE_MAX_BLOCKS, "gate: more than %d pooling blocks (T=%d, sn=%d)", GATE_MAX_BLOCKS, a.T, a.sn);
+  hipLaunchKernelGGL(k_gate, dim3(a.B), dim3(1024), 0, st, a);
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace dcf

@@ -1,0 +1,513 @@
+"""Host-side mirror of the reference ``libs/modeling`` interface for the grounding hot path.
+
+``PtTransformerEarlyFusionIterative`` keeps the reference's constructor, method names,
+argument meaning, return structure and -- above all -- its state_dict (the parameter ABI,
+SURVEY.md 8b), so ``Evaluator`` (libs/worker_v2.py:726-1187) can use it unchanged.  The
+modules below are parameter containers only: the eval forward is executed by the HIP
+engine behind the C ABI (include/decafnet_hip.h); there is no PyTorch implementation of
+the video path to fall back to.  The text encoder (<= 33 tokens per query, microseconds)
+stays host-side PyTorch, as SURVEY.md 2 (#7) prescribes.
+
+Reference citations are relative to the reference repository.
+"""
+from __future__ import annotations
+
+import copy
+import ctypes
+import math
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+__all__ = ['PtTransformerEarlyFusionIterative', 'PtGenerator', 'create_model', 'sinusoid_encoding']
+
+
+# ------------------------------------------------------------------------------------------
+# parameter containers (names and shapes == reference)
+# ------------------------------------------------------------------------------------------
+class MaskedConv1D(nn.Module):
+    """Holds ``conv`` like libs/modeling/blocks.py:63-85 (bias zero-initialised)."""
+
+    def __init__(self, cin, cout, k, stride=1, padding=0, groups=1, bias=True):
+        super().__init__()
+        self.stride = stride
+        self.conv = nn.Conv1d(cin, cout, k, stride=stride, padding=padding, groups=groups, bias=bias)
+        if bias:
+            nn.init.zeros_(self.conv.bias)
+
+
+class LayerNorm(nn.Module):
+    """Channel LayerNorm parameters, shaped (C, 1) as in blocks.py:119-121."""
+
+    def __init__(self, c, affine=True):
+        super().__init__()
+        if affine:
+            self.weight = nn.Parameter(torch.ones(c, 1))
+            self.bias = nn.Parameter(torch.zeros(c, 1))
+        else:
+            self.weight = self.bias = None
+
+
+class LayerScale(nn.Module):
+    """blocks.py:670-678: per-channel residual scale (1, C, 1), init 1e-4."""
+
+    def __init__(self, c, init_scale=1e-4):
+        super().__init__()
+        self.scale = nn.Parameter(init_scale * torch.ones((1, c, 1)))
+
+
+class Scale(nn.Module):
+    """blocks.py:653-664."""
+
+    def __init__(self, init=1.0):
+        super().__init__()
+        self.scale = nn.Parameter(torch.as_tensor(init, dtype=torch.float))
+
+
+class MaskedMHA(nn.Module):
+    """Projection weights of blocks.py:145-200."""
+
+    def __init__(self, embd_dim, q_dim=None, kv_dim=None, out_dim=None, n_heads=4, window_size=0):
+        super().__init__()
+        assert embd_dim % n_heads == 0
+        q_dim = q_dim or embd_dim
+        kv_dim = kv_dim or embd_dim
+        out_dim = out_dim or q_dim
+        self.n_heads, self.window_size = n_heads, window_size
+        self.query = nn.Conv1d(q_dim, embd_dim, 1)
+        self.key = nn.Conv1d(kv_dim, embd_dim, 1)
+        self.value = nn.Conv1d(kv_dim, embd_dim, 1)
+        self.proj = nn.Conv1d(embd_dim, out_dim, 1)
+
+
+class ConvAttNLayer(nn.Module):
+    """blocks.py:414-460."""
+
+    def __init__(self, embd_dim, stride=1, n_heads=4, window_size=0):
+        super().__init__()
+        if stride > 0:
+            for n in 'qkv':
+                setattr(self, f'{n}_conv', MaskedConv1D(embd_dim, embd_dim, 3, stride, 1, groups=embd_dim, bias=False))
+            for n in 'qkv':
+                setattr(self, f'{n}_norm', LayerNorm(embd_dim))
+        self.attn = MaskedMHA(embd_dim, n_heads=n_heads, window_size=window_size)
+
+
+class FFN(nn.Module):
+    """blocks.py:523-533."""
+
+    def __init__(self, c, expansion=4):
+        super().__init__()
+        self.fc = nn.Conv1d(c, c * expansion, 1)
+        self.proj = nn.Conv1d(c * expansion, c, 1)
+
+
+class TransformerEncoder(nn.Module):
+    """blocks.py:541-576."""
+
+    def __init__(self, embd_dim, stride=1, n_heads=4, window_size=0):
+        super().__init__()
+        self.stride, self.n_heads, self.window_size = stride, n_heads, window_size
+        self.attn = ConvAttNLayer(embd_dim, stride, n_heads, window_size)
+        self.ln_attn = LayerNorm(embd_dim)
+        self.drop_path_attn = LayerScale(embd_dim)
+        self.ffn = FFN(embd_dim)
+        self.ln_ffn = LayerNorm(embd_dim)
+        self.drop_path_ffn = LayerScale(embd_dim)
+
+
+class ConvXAttNLayer(nn.Module):
+    """blocks.py:476-511."""
+
+    def __init__(self, embd_dim, kv_dim, out_dim, n_heads=4):
+        super().__init__()
+        self.q_conv = MaskedConv1D(embd_dim, embd_dim, 3, 1, 1, groups=embd_dim, bias=False)
+        self.q_norm = LayerNorm(embd_dim)
+        self.xattn = MaskedMHA(embd_dim, kv_dim=kv_dim, out_dim=out_dim, n_heads=n_heads)
+
+
+class TransformerDecoder(nn.Module):
+    """blocks.py:594-630 (xattn_mode 'adaln')."""
+
+    def __init__(self, embd_dim, kv_dim, n_heads=4, xattn_mode='adaln'):
+        super().__init__()
+        if xattn_mode != 'adaln':
+            raise NotImplementedError("only fusion.xattn_mode == 'adaln' is on the hot path")
+        self.xattn = ConvXAttNLayer(embd_dim, kv_dim, embd_dim * 2, n_heads)
+        self.ln_xattn_q = LayerNorm(embd_dim)
+        self.ln_xattn_kv = LayerNorm(kv_dim)
+        self.ffn = FFN(embd_dim)
+        self.ln_ffn = LayerNorm(embd_dim)
+        self.drop_path_ffn = LayerScale(embd_dim)
+
+
+class XAttNFusion(nn.Module):
+    """fusion.py:16-54."""
+
+    def __init__(self, vid_dim, text_dim, n_layers=2, n_heads=4, xattn_mode='adaln', **_):
+        super().__init__()
+        self.n_heads = n_heads
+        self.layers = nn.ModuleList(TransformerDecoder(vid_dim, text_dim, n_heads, xattn_mode) for _ in range(n_layers))
+        self.ln_out = LayerNorm(vid_dim)
+
+
+class VideoTransformer(nn.Module):
+    """video_net.py:20-121 (stride 1)."""
+
+    def __init__(self, in_dim, embd_dim, max_seq_len, n_heads, mha_win_size, stride=1, arch=(2, 1, 6),
+                 use_abs_pe=False, pool_only=False, **_):
+        super().__init__()
+        if stride != 1 or pool_only:
+            raise NotImplementedError('vid_net.stride != 1 / pool_only are not on the hot path')
+        assert len(arch) == 3
+        self.max_seq_len, self.embd_dim, self.arch = max_seq_len, embd_dim, tuple(arch)
+        self.n_heads, self.mha_win_size, self.use_abs_pe = n_heads, mha_win_size, use_abs_pe
+        self.embd_fc = MaskedConv1D(in_dim, embd_dim, 1)
+        self.embd_convs = nn.ModuleList(MaskedConv1D(embd_dim, embd_dim, 3, 1, 1, bias=False) for _ in range(arch[0]))
+        self.embd_norms = nn.ModuleList(LayerNorm(embd_dim) for _ in range(arch[0]))
+        self.stem = nn.ModuleList(TransformerEncoder(embd_dim, 1, n_heads, mha_win_size) for _ in range(arch[1]))
+        self.branch = nn.ModuleList(TransformerEncoder(embd_dim, 2 if i > 0 else 1, n_heads, mha_win_size)
+                                    for i in range(arch[2]))
+        for mod in self.modules():
+            if isinstance(mod, nn.Conv1d) and mod.bias is not None:
+                nn.init.zeros_(mod.bias)
+
+
+class ConvHead(nn.Module):
+    """ClsHead / RegHead parameters, head.py:18-51 and :67-93."""
+
+    def __init__(self, embd_dim, out_name, out_dim, n_layers=2, num_fpn_levels=None, prior_prob=0.0):
+        super().__init__()
+        self.convs = nn.ModuleList(MaskedConv1D(embd_dim, embd_dim, 3, 1, 1, bias=False) for _ in range(n_layers))
+        self.norms = nn.ModuleList(LayerNorm(embd_dim) for _ in range(n_layers))
+        setattr(self, out_name, MaskedConv1D(embd_dim, out_dim, 3, 1, 1))
+        if out_name == 'cls_head' and prior_prob > 0:
+            nn.init.constant_(self.cls_head.conv.bias, -math.log((1 - prior_prob) / prior_prob))
+        if num_fpn_levels is not None:
+            self.scales = nn.ModuleList(Scale() for _ in range(num_fpn_levels))
+
+
+class DilatedResidualLayer(nn.Module):
+    """tcn.py:4-19."""
+
+    def __init__(self, dilation, c):
+        super().__init__()
+        self.conv_dilated = nn.Conv1d(c, c, 3, padding=dilation, dilation=dilation)
+        self.conv_1x1 = nn.Conv1d(c, c, 1)
+        self.norm = nn.LayerNorm(c, eps=1e-5)
+
+
+class TCN(nn.Module):
+    """tcn.py:40-58 with in_map=True."""
+
+    def __init__(self, in_dim, hid_dim, out_dim, num_layers):
+        super().__init__()
+        self.conv_1x1 = nn.Conv1d(in_dim, hid_dim, 1)
+        self.layers = nn.ModuleList(DilatedResidualLayer(2 ** i, hid_dim) for i in range(num_layers))
+        self.conv_out = nn.Conv1d(hid_dim, out_dim, 1)
+
+
+def sinusoid_encoding(seq_len, n_freqs):
+    """blocks.py:134-142."""
+    tics = torch.arange(seq_len, dtype=torch.float)
+    freqs = 10000 ** torch.linspace(0, 1, n_freqs + 1)[:n_freqs]
+    x = tics[None, :] / freqs[:, None]
+    return torch.cat((torch.sin(x), torch.cos(x)))
+
+
+# ------------------------------------------------------------------------------------------
+# text encoder (host-side PyTorch; runs on whatever device its parameters live on)
+# ------------------------------------------------------------------------------------------
+def _chan_ln(x, ln: LayerNorm, eps=1e-5):
+    x = x - x.mean(dim=1, keepdim=True)
+    x = x / torch.sqrt((x * x).mean(dim=1, keepdim=True) + eps)
+    return x * ln.weight + ln.bias
+
+
+class TextTransformer(nn.Module):
+    """text_net.py:92-188."""
+
+    def __init__(self, in_dim, embd_dim, n_heads, max_seq_len, n_layers=5, use_abs_pe=True, use_bkgd_token=True, **_):
+        super().__init__()
+        self.max_seq_len, self.n_heads = max_seq_len, n_heads
+        self.embd_fc = MaskedConv1D(in_dim, embd_dim, 1)
+        if use_abs_pe:
+            pe = sinusoid_encoding(max_seq_len, embd_dim // 2) / embd_dim ** 0.5
+            self.register_buffer('pe', pe, persistent=False)
+        else:
+            self.pe = None
+        if use_bkgd_token:
+            self.bkgd_token = nn.Parameter(torch.empty(embd_dim, 1))
+            nn.init.trunc_normal_(self.bkgd_token, mean=0.0, std=0.02, a=-2.0, b=2.0)
+        else:
+            self.bkgd_token = None
+        self.transformer = nn.ModuleList(TransformerEncoder(embd_dim, 0, n_heads, 0) for _ in range(n_layers))
+        for mod in self.modules():
+            if isinstance(mod, nn.Conv1d) and mod.bias is not None:
+                nn.init.zeros_(mod.bias)
+
+    def _encoder(self, blk: TransformerEncoder, x, mask):
+        mf = mask.to(x.dtype)
+        x = x * mf
+        h = _chan_ln(x, blk.ln_attn)
+        a = blk.attn.attn
+        q, k, v = a.query(h), a.key(h), a.value(h)
+        bs, c, t = q.shape
+        nh = self.n_heads
+        d = c // nh
+        scale = 1.0 / math.sqrt(math.sqrt(d))
+        q = q.view(bs, nh, d, t).transpose(2, 3) * scale
+        k = k.view(bs, nh, d, t) * scale
+        v = v.view(bs, nh, d, t).transpose(2, 3)
+        att = (q @ k).masked_fill(~mask[:, :, None, :], float('-inf'))
+        att = F.softmax(att, dim=-1)
+        h = a.proj((att @ v).transpose(2, 3).reshape(bs, c, t))
+        x = x * mf + blk.drop_path_attn.scale * h
+        h = blk.ffn.proj(F.gelu(blk.ffn.fc(_chan_ln(x, blk.ln_ffn)))) * mf
+        return x + blk.drop_path_ffn.scale * h
+
+    def forward(self, x, mask):
+        bs, _, t = x.size()
+        if mask.ndim == 2:
+            mask = mask.unsqueeze(1)
+        x = self.embd_fc.conv(x * mask.to(x.dtype))
+        if self.pe is not None:
+            pe = self.pe.to(x.dtype)
+            if t > self.max_seq_len:
+                pe = F.interpolate(pe[None], size=t, mode='linear', align_corners=True)[0]
+            x = x + pe[..., :t] * mask.to(x.dtype)
+        if self.bkgd_token is not None:
+            x = torch.cat((self.bkgd_token.repeat(bs, 1, 1), x), dim=-1)
+            mask = torch.cat((mask[..., :1], mask), dim=-1)
+        for blk in self.transformer:
+            x = self._encoder(blk, x, mask)
+        return x, mask
+
+
+# ------------------------------------------------------------------------------------------
+# the model
+# ------------------------------------------------------------------------------------------
+class _Engine:
+    """Owns one dcf_model handle and keeps it bound to the module's current parameter storage."""
+
+    def __init__(self, cfg: _lib.DcfConfig):
+        self.lib = _lib.lib()
+        self.handle = ctypes.c_void_p()
+        _lib.check(self.lib.dcf_model_create(ctypes.byref(cfg), ctypes.byref(self.handle)), 'dcf_model_create')
+        self.signature = None
+        self.keepalive = []
+        self.pe_cache = {}
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                self.lib.dcf_model_destroy(self.handle)
+        except Exception:
+            pass
+
+    def bind(self, named_tensors):
+        sig = tuple((n, t.data_ptr(), t._version) for n, t in named_tensors)
+        if sig == self.signature:
+            return
+        keep = []
+        for name, t in named_tensors:
+            if not (t.is_cuda and t.dtype == torch.float32):
+                raise RuntimeError(f'parameter {name} must be a float32 tensor on the GPU (got {t.dtype} on {t.device}); '
+                                   f'call model.cuda() first -- there is no CPU path')
+            tc = t.detach().contiguous()
+            keep.append(tc)
+            shape = (ctypes.c_int64 * max(tc.dim(), 1))(*(tc.shape if tc.dim() else (1,)))
+            _lib.check(self.lib.dcf_model_bind(self.handle, name.encode(), _lib.ptr(tc), shape, max(tc.dim(), 1)),
+                       f'dcf_model_bind({name})')
+        _lib.check(self.lib.dcf_model_finalize(self.handle, _lib.current_stream()), 'dcf_model_finalize')
+        self.keepalive = keep
+        self.signature = sig
+
+
+class PtTransformerEarlyFusionIterative(nn.Module):
+    """Drop-in for libs/modeling/model.py:397-565 (created by libs/worker_v2.py:182-211).
+
+    ``opt`` needs ``opt.model.{vid_net,text_net,fusion,cls_head,reg_head,sn,sratio,msf,scat,sfonly,norm}``
+    (attribute or item access).  Unlike the reference the constructor does not mutate ``opt``.
+    """
+
+    def __init__(self, opt, second_fusion=True):
+        super().__init__()
+        mo = opt['model'] if isinstance(opt, dict) else opt.model
+        mo = copy.deepcopy(mo)
+        self.opt = opt
+        if second_fusion:
+            raise NotImplementedError('second_fusion=True (per-level fusion) is not on the hot path; '
+                                      'create_model() uses second_fusion=False (libs/worker_v2.py:191-193)')
+        if mo.get('scat', False) or mo.get('sfonly', False):
+            raise NotImplementedError('opt.model.scat / sfonly are not supported by the HIP path')
+        vn, tn, fu = dict(mo['vid_net']), dict(mo['text_net']), dict(mo['fusion'])
+        if vn.get('name', 'transformer') != 'transformer' or tn.get('name', 'transformer') != 'transformer':
+            raise NotImplementedError('only the transformer video / text backbones are supported')
+        self.sn, self.sratio = int(mo['sn']), float(mo['sratio'])
+        self.msf, self.norm = bool(mo['msf']), bool(mo['norm'])
+        D, E = int(vn['in_dim']), int(vn['embd_dim'])
+        self.D, self.E = D, E
+
+        tn.pop('name', None)
+        self.text_net = TextTransformer(**tn)
+        self.vid_map = MaskedConv1D(2 * D if self.msf else D, E, 1)
+        vn.pop('name', None)
+        vn['in_dim'] = E
+        self.vid_net = VideoTransformer(**vn)
+        fu.pop('name', None)
+        self.fusion = XAttNFusion(**fu)
+        ch, rh = dict(mo['cls_head']), dict(mo['reg_head'])
+        n_levels = self.vid_net.arch[2]
+        self.cls_head = ConvHead(ch['embd_dim'], 'cls_head', 1, ch.get('n_layers', 2), None, ch.get('prior_prob', 0.0))
+        self.refine = TCN(n_levels, 32, 32, num_layers=n_levels)
+        self.cls_head2 = ConvHead(ch['embd_dim'] + 32, 'cls_head', 1, ch.get('n_layers', 2), None, ch.get('prior_prob', 0.0))
+        self.reg_head = ConvHead(rh['embd_dim'] + 32, 'reg_head', 2, rh.get('n_layers', 2),
+                                 rh.get('num_fpn_levels', n_levels))
+        self.second_fusion = second_fusion
+        self.head_layers = ch.get('n_layers', 2)
+        self.max_batch = int(mo.get('max_batch', 0) or 0)
+        self._engine = None
+
+    # -- reference API ---------------------------------------------------------------------
+    def encode_text(self, tokens, token_masks):
+        """model.py:434-436: tokens (1, C_t, Lq) f32, token_masks (1, 1, Lq) bool -> ((1, TE, Lq+1), (1, 1, Lq+1))."""
+        return self.text_net(tokens, token_masks)
+
+    def forward(self, vid, shallow_vid, vid_masks, text, text_cls, text_masks, text_size=None, mv_data=None, eval=False):
+        if not eval:
+            raise NotImplementedError('only the eval forward (eval=True) is implemented; training is out of scope')
+        return self._drop_forward_eval(vid, shallow_vid, vid_masks, text, text_cls, text_masks, text_size, mv_data, eval)
+
+    # -- HIP path ----------------------------------------------------------------------------
+    def _config(self) -> _lib.DcfConfig:
+        c = _lib.DcfConfig()
+        vn = self.vid_net
+        c.D, c.E, c.TE = self.D, self.E, self.fusion.layers[0].ln_xattn_kv.weight.shape[0] if len(self.fusion.layers) else self.E
+        c.vid_heads, c.fusion_heads, c.fusion_layers = vn.n_heads, self.fusion.n_heads, len(self.fusion.layers)
+        c.n_embd_convs, c.n_stem, c.n_levels = vn.arch
+        c.win, c.head_layers = vn.mha_win_size, self.head_layers
+        c.sn, c.sratio, c.msf, c.norm = self.sn, self.sratio, int(self.msf), int(self.norm)
+        c.use_abs_pe, c.max_batch = int(vn.use_abs_pe), self.max_batch
+        return c
+
+    def _named_engine_tensors(self):
+        return [(n, p) for n, p in self.state_dict(keep_vars=True).items() if not n.startswith('text_net.')]
+
+    def _position_encoding(self, T, device):
+        """vid_net.pe for length T, token-major (T, E) (video_net.py:75-78,141-151)."""
+        eng = self._engine
+        if T not in eng.pe_cache:
+            vn = self.vid_net
+            pe = sinusoid_encoding(vn.max_seq_len, vn.embd_dim // 2) / vn.embd_dim ** 0.5
+            if T > vn.max_seq_len:
+                pe = F.interpolate(pe[None], size=T, mode='linear', align_corners=True)[0]
+            eng.pe_cache = {T: pe[:, :T].t().contiguous().to(device)}
+        return eng.pe_cache[T]
+
+    def _drop_forward_eval(self, vid, shallow_vid, vid_masks, text, text_cls, text_masks, text_size=None, mv_data=None,
+                           eval=False):
+        assert mv_data is None and eval
+        assert vid.size(0) == 1, vid.size()                                  # model.py:496
+        if not vid.is_cuda:
+            raise RuntimeError('the grounding forward runs on the MI355X only: move the inputs to the GPU')
+        dev = vid.device
+        if self._engine is None:
+            self._engine = _Engine(self._config())
+        eng = self._engine
+        eng.bind(self._named_engine_tensors())
+        lib = eng.lib
+        T = vid.size(-1)
+        vid_c = vid[0].contiguous().float()
+        sh_c = shallow_vid[0].contiguous().float()
+        mask_c = vid_masks.reshape(-1).to(torch.bool).contiguous()
+        assert mask_c.numel() == T and sh_c.shape == vid_c.shape == (self.D, T)
+        if not isinstance(text, (tuple, list)):
+            text, text_masks = (text,), (text_masks,)
+        nq = len(text)
+        cls_c = text_cls.contiguous().float()
+        assert cls_c.shape == (nq, self.D), (cls_c.shape, nq, self.D)
+        keep = []
+        tptr = (ctypes.c_void_p * nq)()
+        mptr = (ctypes.c_void_p * nq)()
+        tlen = (ctypes.c_int32 * nq)()
+        for q in range(nq):
+            t = text[q][0].contiguous().float()                              # (TE, Lk)
+            m = text_masks[q].reshape(-1).to(torch.bool).contiguous()
+            assert t.dim() == 2 and m.numel() == t.size(1)
+            keep += [t, m]
+            tptr[q], mptr[q], tlen[q] = t.data_ptr(), m.data_ptr(), t.size(1)
+        if self.vid_net.use_abs_pe:
+            pe = self._position_encoding(T, dev)
+            _lib.check(lib.dcf_model_set_pe(eng.handle, _lib.ptr(pe), T), 'dcf_model_set_pe')
+        S = lib.dcf_points_per_query(eng.handle, T)
+        logits = torch.empty(nq, S, device=dev, dtype=torch.float32)
+        offsets = torch.empty(nq, S, 2, device=dev, dtype=torch.float32)
+        masks = torch.empty(nq, S, device=dev, dtype=torch.bool)
+        _lib.check(lib.dcf_forward_eval(eng.handle, _lib.ptr(vid_c), _lib.ptr(sh_c), _lib.ptr(mask_c), T, nq, tptr, mptr, tlen,
+                                        _lib.ptr(cls_c), _lib.ptr(logits), _lib.ptr(offsets), _lib.ptr(masks),
+                                        _lib.current_stream()), 'dcf_forward_eval')
+        # keep the borrowed inputs alive until the stream has consumed them
+        self._last_inputs = (vid_c, sh_c, mask_c, cls_c, keep)
+        self._last_flat = (logits, offsets, masks)
+        L = self.vid_net.arch[2]
+        sizes = [T >> l for l in range(L)]
+        lg = [tuple(x.unsqueeze(0) for x in logits[q].split(sizes)) for q in range(nq)]
+        of = [tuple(x.unsqueeze(0) for x in offsets[q].split(sizes)) for q in range(nq)]
+        mk = [tuple(x.unsqueeze(0) for x in masks[q].split(sizes)) for q in range(nq)]
+        return lg, of, mk
+
+
+def create_model(opt):
+    """libs/worker_v2.py:182-211: only ``opt.model.name == 'iter'`` exists in the reference."""
+    name = opt['model']['name'] if isinstance(opt, dict) else opt.model.name
+    if name != 'iter':
+        raise NotImplementedError(f"unknown model name {name!r}: the reference only builds 'iter'")
+    return PtTransformerEarlyFusionIterative(opt, second_fusion=False)
+
+
+class PtGenerator(nn.Module):
+    """Candidate point generator, model.py:668-743 (same ctor, buffers and forward)."""
+
+    def __init__(self, max_seq_len, num_fpn_levels, regression_range=4, sigma=1, use_offset=False):
+        super().__init__()
+        self.num_fpn_levels = num_fpn_levels
+        assert max_seq_len % 2 ** (num_fpn_levels - 1) == 0
+        self.max_seq_len = max_seq_len
+        assert 0 < sigma <= 1
+        rng = [(0, regression_range)]
+        rr = regression_range
+        for l in range(1, num_fpn_levels):
+            assert rr <= max_seq_len
+            lo, hi = rr * sigma, rr * 2
+            if l == num_fpn_levels - 1:
+                hi = max(hi, max_seq_len + 1)
+            rng.append((lo, hi))
+            rr = hi
+        self.regression_range = tuple(rng)
+        self.use_offset = use_offset
+        tics = torch.arange(0, max_seq_len, 1.0)
+        for l in range(num_fpn_levels):
+            stride = 2 ** l
+            pts = tics[::stride][:, None].clone()
+            if use_offset:
+                pts += 0.5 * stride
+            r = torch.as_tensor(rng[l], dtype=torch.float32)[None].repeat(len(pts), 1)
+            s = torch.full((len(pts), 1), float(stride))
+            self.register_buffer(f'points_{l}', torch.cat((pts, r, s), 1), persistent=False)
+
+    @property
+    def buffer_points(self):
+        return [getattr(self, f'points_{l}') for l in range(self.num_fpn_levels)]
+
+    def forward(self, fpn_n_points):
+        assert len(fpn_n_points) == self.num_fpn_levels
+        out = tuple()
+        for n, pts in zip(fpn_n_points, self.buffer_points):
+            assert n <= len(pts), f'number of requested points {n} cannot exceed max number of buffered points {len(pts)}'
+            out += (pts[:n],)
+        return out

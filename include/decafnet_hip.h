@@ -1,0 +1,152 @@
+/*
+ * libdecafnet_hip.so -- C ABI of the MI355X (gfx950) DeCafNet grounding hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch types.  Every entry point
+ * names the reference interface it replaces (paths relative to the reference repository).
+ * All `const float*` / `uint8_t*` DATA pointers are DEVICE pointers (hipMalloc'ed or
+ * torch-ROCm storage) unless a parameter says "host".  `stream` is a hipStream_t passed as
+ * void* (NULL = the default stream).  Functions return 0 on success and -1 on failure;
+ * dcf_last_error() then holds a message (thread local).
+ *
+ * There is NO CPU fallback: if the library, the device or a kernel is missing the call fails.
+ */
+#ifndef DECAFNET_HIP_H
+#define DECAFNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* dcf_last_error(void);
+int dcf_abi_version(void);
+
+/* --------------------------------------------------------------------------------------------
+ * Model: replaces PtTransformerEarlyFusionIterative (libs/modeling/model.py:397-565) as built by
+ * create_model (libs/worker_v2.py:182-211).  Hyper-parameters mirror opt.model.* (libs/core/opt.py:75-130).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct dcf_model dcf_model;
+
+typedef struct dcf_config {
+  int32_t D;              /* opt.model.vid_net.in_dim: expert / sidekick feature dim               */
+  int32_t E;              /* opt.model.vid_net.embd_dim                                            */
+  int32_t TE;             /* opt.model.text_net.embd_dim = fusion.text_dim                         */
+  int32_t vid_heads;      /* opt.model.vid_net.n_heads                                             */
+  int32_t fusion_heads;   /* opt.model.fusion.n_heads                                              */
+  int32_t fusion_layers;  /* opt.model.fusion.n_layers                                             */
+  int32_t n_embd_convs;   /* opt.model.vid_net.arch[0]                                             */
+  int32_t n_stem;         /* opt.model.vid_net.arch[1]                                             */
+  int32_t n_levels;       /* opt.model.vid_net.arch[2]  (= number of FPN levels = TCN depth)       */
+  int32_t win;            /* opt.model.vid_net.mha_win_size (odd, > 0)                             */
+  int32_t head_layers;    /* opt.model.cls_head.n_layers (= reg_head.n_layers)                     */
+  int32_t sn;             /* opt.model.sn     (clips per scoring block)                            */
+  float sratio;           /* opt.model.sratio (fraction of blocks that keep expert features)       */
+  int32_t msf;            /* opt.model.msf                                                         */
+  int32_t norm;           /* opt.model.norm                                                        */
+  int32_t use_abs_pe;     /* opt.model.vid_net.use_abs_pe                                          */
+  int32_t max_batch;      /* queries processed together (>= 1); 0 = library default                */
+} dcf_config;
+
+int dcf_model_create(const dcf_config* cfg, dcf_model** out);
+void dcf_model_destroy(dcf_model* m);
+
+/* Bind one tensor of the reference state_dict by its NAME (the parameter ABI):
+ * "vid_map.conv.weight", "fusion.layers.0.xattn.xattn.query.weight", ...  The memory is borrowed
+ * (fp32, contiguous, device) and must stay alive until the model is destroyed or re-bound.
+ * text_net.* tensors are accepted and ignored (the text encoder is host-side PyTorch).
+ * Replaces nn.Module.load_state_dict(ckpt['model_ema']) (libs/worker_v2.py:806-812). */
+int dcf_model_bind(dcf_model* m, const char* name, const float* data, const int64_t* shape, int32_t ndim);
+
+/* Absolute position encoding buffer `vid_net.pe` (non-persistent in the reference,
+ * libs/modeling/video_net.py:75-78): token-major (T, E) fp32 already resampled for length T
+ * (video_net.py:141-151).  Borrowed.  Needed only when use_abs_pe != 0. */
+int dcf_model_set_pe(dcf_model* m, const float* pe_tokens, int64_t T);
+
+/* Validate that every parameter is bound and repack convolution weights for the kernels. */
+int dcf_model_finalize(dcf_model* m, void* stream);
+
+/* Number of points per query, sum_l T / 2^l. */
+int64_t dcf_points_per_query(const dcf_model* m, int64_t T);
+
+/* Eval forward: replaces model(vid, shallow_vid, vid_masks, text, text_cls, text_masks, eval=True)
+ * (libs/modeling/model.py:473-565; caller libs/worker_v2.py:1007).
+ *   vid, shallow_vid : (D, T) fp32 channel-major = tensor[0] of the reference's (1, D, T) inputs
+ *   vid_mask         : (T) bytes (torch.bool storage), 1 = valid clip
+ *   text[q]          : HOST array of nq device pointers, each (TE, text_len[q]) fp32 = encode_text()[0][0]
+ *   text_mask[q]     : HOST array of nq device pointers, each (text_len[q]) bytes; entries may be NULL (= all valid)
+ *   text_len         : HOST array of nq ints
+ *   text_cls         : (nq, D) fp32
+ * Outputs (device, caller allocated), S = dcf_points_per_query(T), levels concatenated l = 0..L-1:
+ *   logits_out (nq, S) raw fp32 logits;  offsets_out (nq, S, 2) fp32 >= 0;  masks_out (nq, S) bytes. */
+int dcf_forward_eval(dcf_model* m, const float* vid, const float* shallow_vid, const uint8_t* vid_mask, int64_t T,
+                     int32_t nq, const float* const* text, const uint8_t* const* text_mask, const int32_t* text_len,
+                     const float* text_cls, float* logits_out, float* offsets_out, uint8_t* masks_out, void* stream);
+
+/* Debug taps for parity tests: copy an intermediate of the LAST forward chunk into `dst` (device).
+ * what: 0 = sidekick scores (nq, T); 1 = gate (B, T); 2 = vid_map output (B*T, E) token-major;
+ *       3 = fusion output (B*T, E); 4 = pyramid features (B*S rows [level][b][t], E+32). */
+int dcf_debug_copy(dcf_model* m, int32_t what, float* dst, int64_t max_floats, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Proposal decoding: replaces Evaluator._collect_segments (libs/worker_v2.py:1131-1187).
+ *   logits (nq, S), offsets (nq, S, 2), masks (nq, S) as produced by dcf_forward_eval.
+ *   segs_out (nq, pre_nms_topk, 2), scores_out (nq, pre_nms_topk), counts_out (nq) int32 (device).
+ * ------------------------------------------------------------------------------------------ */
+int dcf_collect_segments(const float* logits, const float* offsets, const uint8_t* masks, int32_t nq, int64_t T,
+                         int32_t n_levels, float pre_nms_thresh, int32_t pre_nms_topk, float seg_len_thresh,
+                         float* segs_out, float* scores_out, int32_t* counts_out, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * NMS: replaces the extension module nms_1d_cpu_vg (libs/nms/src/nms_cpu.cpp:184-194).
+ * Batched over nq independent problems laid out with a fixed `stride` (entries) per problem;
+ * counts (device int32, may be NULL => every problem has n_max entries).  n_max <= 4096.
+ *   dcf_nms_1d      <- nms_1d(segs, scores, iou_thresh)                       (nms_cpu.cpp:20-70)
+ *   dcf_softnms_1d  <- softnms_1d(segs, scores, dets, iou_thresh, sigma, min_score, method) (:72-181)
+ *   max_iters = 0 reproduces the reference (all picks); k > 0 stops after k picks (the only
+ *   ones SoftNMSop keeps when max_num_segs = k, libs/nms/nms.py:54-59).
+ * ------------------------------------------------------------------------------------------ */
+int dcf_nms_1d(const float* segs, const float* scores, const int32_t* counts, int32_t nq, int32_t n_max,
+               int32_t stride, float iou_thresh, int64_t* keep_out, int32_t* keep_counts_out, void* stream);
+int dcf_softnms_1d(const float* segs, const float* scores, const int32_t* counts, int32_t nq, int32_t n_max,
+                   int32_t stride, float iou_thresh, float sigma, float min_score, int32_t method,
+                   int32_t max_iters, float* dets_out, int64_t* inds_out, int32_t* out_counts, void* stream);
+/* segment_voting (libs/nms/nms.py:64-103). nms_segs rows have `nms_ld` floats (2, or 3 for dets). */
+int dcf_segment_voting(const float* nms_segs, int32_t nms_ld, const int32_t* n1_counts, int32_t n1_max,
+                       int32_t n1_stride, const float* all_segs, const float* all_scores,
+                       const int32_t* n2_counts, int32_t n2_max, int32_t n2_stride, float iou_thresh,
+                       int32_t nq, float* out, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Single-operator entry points (used by the parity tests and micro-benchmarks).
+ * ------------------------------------------------------------------------------------------ */
+/* C[M][N] = act(A[M][K] * W[N][K]^T + bias): nn.Conv1d(k=1) on token-major activations.
+ * act: 0 none, 1 exact GELU, 2 ReLU. */
+int dcf_op_linear(const float* A, const float* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K,
+                  int32_t act, void* stream);
+/* same with A given channel-major (K, M) -- the reference's (C, T) layout */
+int dcf_op_linear_cm(const float* A_cm, const float* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K,
+                     void* stream);
+/* MaskedConv1D(k=3, pad=1, no bias) on token-major (B*T, Cin) rows; W is the PyTorch (N, Cin, 3) weight. */
+int dcf_op_conv3(const float* X, const uint8_t* mask, const float* W_ock, float* Y, int32_t B, int32_t T, int32_t Cin,
+                 int32_t N, void* stream);
+/* channel LayerNorm (libs/modeling/blocks.py:125-131) per row; w/b may be NULL. */
+int dcf_op_layernorm(const float* X, const float* w, const float* b, float* Y, int32_t rows, int32_t C, int32_t relu,
+                     void* stream);
+/* cross-attention core (libs/modeling/blocks.py:374-389): Q (B*T, C), K/V (B*Lk, C), kvmask (B*Lk) -> O (B*T, C) */
+int dcf_op_xattn(const float* Q, const float* K, const float* V, const uint8_t* kvmask, float* O, int32_t B, int32_t T,
+                 int32_t Lk, int32_t C, int32_t heads, void* stream);
+/* sliding-window attention core (blocks.py:204-325,357-373): Q/K/V (B*T, C), mask (B*T) -> O */
+int dcf_op_local_attn(const float* Q, const float* K, const float* V, const uint8_t* mask, float* O, int32_t B, int32_t T,
+                      int32_t C, int32_t heads, int32_t window, void* stream);
+/* sidekick scoring (model.py:500-505): shallow (D, T) channel-major, text_cls (nq, D) -> correl (nq, T) */
+int dcf_op_sidekick(const float* shallow, const float* text_cls, float* correl, int32_t D, int32_t T, int32_t nq,
+                    int32_t norm, void* stream);
+/* block top-k gate (model.py:531-541) for nq queries: correl (nq, T), vid_mask (T) -> gate (nq, T) fp32 0/1 */
+int dcf_op_gate(const float* correl, const uint8_t* vid_mask, float* gate, uint8_t* mask_out, int32_t T, int32_t nq,
+                int32_t sn, double sratio, int32_t msf, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DECAFNET_HIP_H */
