@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Throughput of the DeCafNet grounding forward on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--nq NQ] [--T 16384]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one eval forward of PtTransformerEarlyFusionIterative over one synthetic video of
+T=16384 clips (D=1024) for NQ text queries, inputs already resident in HBM, timed from
+model.forward entry to logits/offsets/masks on the device.  Workload =
+BASELINE.json configs[2] with the survey's probe hyper-parameters.
+With N > 1 every rank runs its own (video, queries) replica -- the path shards over independent
+(video, query) units with no data-path collective (weak scaling); value = all clips of all ranks
+divided by the slowest rank's time.
+
+Rank 0 prints ONE JSON line: the driver contract fields plus
+  roofline     : dominant kernel (fp32 MFMA GEMM), live HIP-event timing of every launch
+  cpu_baseline : the CPU oracle (a port of the reference algorithm) timed on this host's cores
+  stages       : per-kernel-family time of one step (same event timing)
+  post         : proposal decode + NMS latency and the NMS index match against the oracle
+"""
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0            # HBM3E spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--nq', type=int, default=1, help='text queries per video')
+    ap.add_argument('--T', type=int, default=16384)
+    ap.add_argument('--vid-len', type=int, default=0, help='valid clips (default: T)')
+    ap.add_argument('--max-batch', type=int, default=8)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-post', action='store_true')
+    ap.add_argument('--cpu-T', type=int, default=0, help='T of the CPU-baseline sample (default: same T)')
+    return ap.parse_args()
+
+
+def probe_kwargs(T):
+    # BASELINE.md section 2 probe hyper-parameters; max_seq_len*10 >= T so PtGenerator covers the video
+    return dict(D=1024, E=256, TE=256, text_in=512, n_levels=8, win=9, n_heads=4, sn=60, sratio=0.3, msf=True,
+                norm=True, max_seq_len=2304, text_layers=5, text_max_len=48, fusion_layers=2)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    pkg = importlib.import_module('cvpr2025-decafnet_amd')
+    lib = pkg._lib.lib()
+
+    T = args.T
+    vid_len = args.vid_len or T
+    kw = probe_kwargs(T)
+    opt = pkg.config.make_opt(**kw)
+    opt.model['max_batch'] = args.max_batch
+    model = pkg.modeling.create_model(opt)
+    shapes = {k: list(v.shape) for k, v in model.state_dict().items()}
+    sd = pkg.synth.make_state_dict(shapes, 2025)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval().requires_grad_(False)
+    inp = pkg.synth.make_inputs(kw['D'], T, vid_len, args.nq, kw['text_in'], 32, 2025 + 3 + rank)
+    vid, shallow, vmask = inp['vid'].to(dev), inp['shallow_vid'].to(dev), inp['vid_masks'].to(dev)
+    text_cls = inp['text_cls'].to(dev)
+    texts, tmasks = [], []
+    for tok in inp['tokens']:
+        t, m = model.encode_text(tok[None].to(dev), torch.ones(1, 1, tok.size(-1), dtype=torch.bool, device=dev))
+        texts.append(t)
+        tmasks.append(m)
+    texts, tmasks = tuple(texts), tuple(tmasks)
+
+    def step():
+        return model(vid, shallow, vmask, texts, text_cls, tmasks, eval=True)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    clips_per_step = vid_len * args.nq
+    value = world * clips_per_step * args.steps / elapsed
+
+    result = {
+        'metric': 'clips/sec (grounding fwd, T=16384 D=1024)', 'value': value, 'unit': 'clips/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'BASELINE configs[2]: T={T} D=1024 full multi-scale pyramid + sidekick top-k 30% + expert path, '
+                               f'NQ={args.nq} queries/video, one video replica per GPU',
+                   'T': T, 'vid_len': vid_len, 'D': 1024, 'E': 256, 'TE': 256, 'levels': 8, 'win': 9, 'heads': 4,
+                   'fusion_layers': 2, 'sn': 60, 'sratio': 0.3, 'msf': True, 'norm': True, 'Lq': 32, 'nq': args.nq,
+                   'max_batch': args.max_batch, 'parallelism': f'replicas x{world}'},
+    }
+
+    if rank == 0:
+        # ---- live per-kernel timing: the same steps again with every launch bracketed by HIP events
+        lib.dcf_profile_enable(1)
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        need = lib.dcf_profile_report(None, 0)
+        buf = ctypes.create_string_buffer(int(need) + 16)
+        lib.dcf_profile_report(buf, len(buf))
+        lib.dcf_profile_enable(0)
+        prof = json.loads(buf.value.decode())
+        tot_ms = sum(v['ms'] for v in prof.values())
+        stages = {k: {'ms_per_step': v['ms'] / args.steps, 'launches_per_step': v['count'] / args.steps,
+                      'share': v['ms'] / tot_ms,
+                      'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['ms'] > 0 else 0.0,
+                      'alg_GBps': (v['bytes'] / (v['ms'] * 1e-3) / 1e9) if v['ms'] > 0 else 0.0}
+                  for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}
+        dom = max((k for k in prof if k.startswith('gemm_f32')), key=lambda k: prof[k]['ms'])
+        d = prof[dom]
+        result['roofline'] = {
+            'kernel': dom, 'bound': 'mfma', 'achieved': d['flops'] / (d['ms'] * 1e-3) / 1e12, 'peak': PEAK_F32_MFMA_TFLOPS,
+            'unit': 'TFLOP/s', 'frac': d['flops'] / (d['ms'] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+            'launches': d['count'], 'avg_launch_us': 1e3 * d['ms'] / d['count'],
+            'alg_flops_per_launch': d['flops'] / d['count'],
+            'note': 'HIP events around every launch of this kernel, same K steps re-run right after the timed region',
+        }
+        xa = prof.get('xattn_core')
+        if xa:
+            result['xattn'] = {'bound': 'hbm', 'achieved': xa['bytes'] / (xa['ms'] * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS,
+                               'unit': 'GB/s', 'frac': xa['bytes'] / (xa['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                               'avg_launch_us': 1e3 * xa['ms'] / xa['count']}
+        result['stages'] = stages
+        result['event_ms_per_step'] = tot_ms / args.steps
+
+        # ---- proposal decode + NMS (reported separately) and the NMS index match
+        if not args.no_post:
+            from oracle import nms_oracle
+            fl, fo, fm = model._last_flat
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                segs, scores, counts = pkg.nms.collect_segments(fl, fo, fm, T, 8)
+            torch.cuda.synchronize()
+            t_collect = (time.perf_counter() - t1) / reps
+            n = int(counts[0])
+            s_d, c_d = segs[:1, :n].contiguous(), scores[:1, :n].contiguous()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                keep, kc = pkg.nms.nms_device(s_d, c_d, None, n, n, 0.5)
+            torch.cuda.synchronize()
+            t_nms = (time.perf_counter() - t1) / reps
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                dets, inds, oc = pkg.nms.softnms_device(s_d, c_d, None, n, n, 0.1, 0.9, 0.001, 2)
+            torch.cuda.synchronize()
+            t_soft = (time.perf_counter() - t1) / reps
+            s_cpu, c_cpu = s_d[0].cpu(), c_d[0].cpu()
+            ref_keep = nms_oracle.nms(s_cpu, c_cpu, 0.5)
+            d2 = torch.zeros(n, 3)
+            ref_soft = nms_oracle.softnms(s_cpu, c_cpu, d2, 0.1, 0.9, 0.001, 2)
+            t1 = time.perf_counter()
+            nms_oracle.nms(s_cpu, c_cpu, 0.5)
+            t_cpu_nms = time.perf_counter() - t1
+            result['post'] = {
+                'candidates': n, 'collect_ms_per_video': 1e3 * t_collect, 'nms_ms': 1e3 * t_nms, 'softnms_full_ms': 1e3 * t_soft,
+                'cpu_oracle_nms_ms': 1e3 * t_cpu_nms,
+                'nms_index_match': bool(torch.equal(keep[0, :int(kc)].cpu(), ref_keep)),
+                'softnms_index_match': bool(torch.equal(inds[0, :int(oc)].cpu(), ref_soft)),
+            }
+
+        # ---- CPU baseline: the oracle (port of the reference algorithm) on this host, bounded sample
+        if not args.no_cpu_baseline:
+            from oracle import decafnet_ref as R
+            cpu_T = args.cpu_T or T
+            cinp = pkg.synth.make_inputs(kw['D'], cpu_T, min(vid_len, cpu_T), 1, kw['text_in'], 32, 2025 + 3)
+            t_cpu, m_cpu = R.encode_text(sd, opt.model, cinp['tokens'][0][None], torch.ones(1, 1, 32, dtype=torch.bool))
+            with torch.no_grad():
+                t1 = time.perf_counter()
+                R.forward_eval(sd, opt.model, cinp['vid'], cinp['shallow_vid'], cinp['vid_masks'], [t_cpu], cinp['text_cls'], [m_cpu])
+                cpu_s = time.perf_counter() - t1
+            result['cpu_baseline'] = {
+                'value': min(vid_len, cpu_T) / cpu_s, 'unit': 'clips/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                'sample': f'1 video x 1 query, T={cpu_T}, oracle/decafnet_ref.py forward_eval (torch {torch.__version__} CPU fp32), {cpu_s:.2f} s',
+            }
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -177,6 +177,8 @@ int launch_xattn(const XAttnArgs& a, hipStream_t st) {
   int groups = (a.T + 3) / 4;
   int gx = groups < 512 ? groups : 512;     // each workgroup re-stages K/V once, then strides over rows
   dim3 grid(gx, a.B);
+  const double rows = (double)a.B * a.T;
+  ProfScope prof("xattn_core", st, 4.0 * rows * a.C * a.Lk, 4.0 * (2.0 * rows * a.C + 2.0 * a.B * a.Lk * a.C));
   DISPATCH_ATTN(XATTN_LAUNCH, a.C, a.heads, grid, lds, st, a);
   return 0;
 }
@@ -186,6 +188,7 @@ int launch_local_attn(const LocalAttnArgs& a, hipStream_t st) {
   if (rows <= 0) return 0;
   DCF_CHECK(a.window >= 1 && (a.window & 1), "local_attn: window must be odd");
   dim3 grid((unsigned)((rows + 3) / 4));
+  ProfScope prof("local_attn", st, 4.0 * rows * a.C * a.window, 4.0 * 4.0 * rows * a.C);
   DISPATCH_ATTN(LOCAL_LAUNCH, a.C, a.heads, grid, st, a);
   return 0;
 }

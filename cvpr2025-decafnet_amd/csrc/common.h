@@ -18,21 +18,51 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---- wave-level reductions (64 lanes) -------------------------------------------------
+// Cross-lane adds go through DPP (data-parallel primitives: quad_perm / row mirrors / row broadcasts),
+// which cost a few cycles each; __shfl_xor lowers to ds_bpermute (an LDS crossbar round trip of
+// ~100 cycles per step) and made every LayerNorm latency bound.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_zero(float v) {   // lanes not written by the DPP move read 0
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_self(float v) {   // lanes not written keep their own value
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+constexpr int DPP_XOR1 = 0xB1;          // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;          // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141;  // lane i <- lane 7-i of its 8-lane half row
+constexpr int DPP_MIRROR = 0x140;       // lane i <- lane 15-i of its 16-lane row
+constexpr int DPP_BCAST15 = 0x142;      // lane 15 of row r -> every lane of row r+1
+constexpr int DPP_BCAST31 = 0x143;      // lane 31 -> every lane of rows 2,3
+
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += dpp_zero<DPP_XOR1>(v);
+  v += dpp_zero<DPP_XOR2>(v);
+  v += dpp_zero<DPP_HALF_MIRROR>(v);
+  v += dpp_zero<DPP_MIRROR>(v);           // every lane: sum of its 16-lane row
+  v += dpp_zero<DPP_BCAST15, 0xA>(v);     // rows 1,3 += rows 0,2
+  v += dpp_zero<DPP_BCAST31, 0xC>(v);     // rows 2,3 += row 1 total; lane 63 holds the wave sum
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-  return v;
+  v = fmaxf(v, dpp_self<DPP_XOR1>(v));
+  v = fmaxf(v, dpp_self<DPP_XOR2>(v));
+  v = fmaxf(v, dpp_self<DPP_HALF_MIRROR>(v));
+  v = fmaxf(v, dpp_self<DPP_MIRROR>(v));
+  v = fmaxf(v, dpp_self<DPP_BCAST15, 0xA>(v));
+  v = fmaxf(v, dpp_self<DPP_BCAST31, 0xC>(v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
-// reduce within aligned groups of G lanes (G power of two <= 64)
+// sum within aligned groups of G lanes (G power of two <= 64); every lane of the group gets the sum
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-  for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  if constexpr (G == 64) return wave_sum(v);
+  if constexpr (G >= 2) v += dpp_zero<DPP_XOR1>(v);
+  if constexpr (G >= 4) v += dpp_zero<DPP_XOR2>(v);
+  if constexpr (G >= 8) v += dpp_zero<DPP_HALF_MIRROR>(v);
+  if constexpr (G >= 16) v += dpp_zero<DPP_MIRROR>(v);
+  if constexpr (G >= 32) v += __shfl_xor(v, 16, 64);
   return v;
 }
 
@@ -110,6 +140,17 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
+}  // namespace dcf
+
+// ---- optional per-launch timing (HIP events on the launch stream; off by default) --------------
+namespace dcf {
+struct ProfScope {
+  int idx;
+  hipStream_t st;
+  // flops / bytes are the ALGORITHMIC work of this launch, not measured traffic
+  ProfScope(const char* name, hipStream_t st, double flops, double bytes);
+  ~ProfScope();
+};
 }  // namespace dcf
 
 // ---- host-side error plumbing -----------------------------------------------------------

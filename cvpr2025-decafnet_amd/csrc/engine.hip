@@ -40,6 +40,23 @@ void set_error(const char* fmt, ...) {
   g_err = buf;
 }
 
+// ---- per-launch profiler (dcf_profile_*) --------------------------------------------------
+struct ProfRec { std::string name; hipEvent_t a, b; double flops, bytes; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_recs;
+
+ProfScope::ProfScope(const char* name, hipStream_t s, double flops, double bytes) : idx(-1), st(s) {
+  if (!g_prof_on) return;
+  ProfRec r{name, nullptr, nullptr, flops, bytes};
+  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+  (void)hipEventRecord(r.a, st);
+  g_recs.push_back(r);
+  idx = (int)g_recs.size() - 1;
+}
+ProfScope::~ProfScope() {
+  if (idx >= 0) (void)hipEventRecord(g_recs[idx].b, st);
+}
+
 // ---- tiny utility kernels ------------------------------------------------------------------
 // dst[perm(i0,i1,i2)] = src[i0][i1][i2];  p0..p2 give the destination axis order
 __global__ void k_permute3(const float* __restrict__ src, float* __restrict__ dst, int d0, int d1, int d2, int p0, int p1,
@@ -130,8 +147,10 @@ struct dcf_model {
   char* arena = nullptr;
   size_t arena_bytes = 0;
   std::vector<Plan> plans;
-  TextMeta* h_meta = nullptr;                // pinned host
-  TextMeta* d_meta = nullptr;
+  static constexpr int META_SLOTS = 64;      // ring of pinned/device TextMeta slots (one per forward chunk)
+  TextMeta* h_meta = nullptr;                // pinned host [META_SLOTS]
+  TextMeta* d_meta = nullptr;                // device      [META_SLOTS]
+  int meta_next = 0;
   // last-forward bookkeeping for dcf_debug_copy
   struct {
     float *correl = nullptr, *gate = nullptr, *vidmap = nullptr, *fused = nullptr, *F = nullptr;
@@ -485,8 +504,8 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
     carve(real, c, T0, Bmax, nq, S, Lk, b);
   }
   if (!m->h_meta) {
-    DCF_HIP(hipHostMalloc(&m->h_meta, sizeof(TextMeta)));
-    DCF_HIP(hipMalloc(&m->d_meta, sizeof(TextMeta)));
+    DCF_HIP(hipHostMalloc(&m->h_meta, sizeof(TextMeta) * dcf_model::META_SLOTS));
+    DCF_HIP(hipMalloc(&m->d_meta, sizeof(TextMeta) * dcf_model::META_SLOTS));
   }
 
   // ---- per video: sidekick scores and the query-independent halves of vid_map
@@ -523,13 +542,19 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
     if (m->keep_debug && m->dbg_vidmap) DCF_HIP(hipMemcpyAsync(m->dbg_vidmap, b.X, (size_t)rows0 * E * 4, hipMemcpyDeviceToDevice, st));
 
     // ---- text side: pointers of this chunk
-    DCF_HIP(hipStreamSynchronize(st));        // h_meta is reused between chunks
-    for (int i = 0; i < B; ++i) {
-      m->h_meta->text[i] = text[q0 + i];
-      m->h_meta->text_mask[i] = text_mask ? text_mask[q0 + i] : nullptr;
-      m->h_meta->len[i] = text_len[q0 + i];
+    if (m->meta_next == dcf_model::META_SLOTS) {   // ring wrapped: make sure the old slots were consumed
+      DCF_HIP(hipStreamSynchronize(st));
+      m->meta_next = 0;
     }
-    DCF_HIP(hipMemcpyAsync(m->d_meta, m->h_meta, sizeof(TextMeta), hipMemcpyHostToDevice, st));
+    TextMeta* hm = m->h_meta + m->meta_next;
+    TextMeta* dm = m->d_meta + m->meta_next;
+    m->meta_next++;
+    for (int i = 0; i < B; ++i) {
+      hm->text[i] = text[q0 + i];
+      hm->text_mask[i] = text_mask ? text_mask[q0 + i] : nullptr;
+      hm->len[i] = text_len[q0 + i];
+    }
+    DCF_HIP(hipMemcpyAsync(dm, hm, sizeof(TextMeta), hipMemcpyHostToDevice, st));
 
     // ---- fusion: XAttNFusion (fusion.py:56-66)
     for (size_t li = 0; li < m->dec.size(); ++li) {
@@ -538,7 +563,7 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
       TRY(launch_dec_pre(dp, st));
       GemmArgs gq = gemm(b.R[0], E, w.wq, w.bq, b.R[2], E, rows0, E, E);
       TRY(launch_gemm(&gq, 1, A_ROWS, st));
-      TextLnArgs tl{m->d_meta, b.kvn, b.kvmask, w.ln_kv_w, w.ln_kv_b, Lk, c.TE};
+      TextLnArgs tl{dm, b.kvn, b.kvmask, w.ln_kv_w, w.ln_kv_b, Lk, c.TE};
       TRY(launch_text_ln(tl, B, st));
       GemmArgs gkv[2] = {gemm(b.kvn, c.TE, w.wk, w.bk, b.Kt, E, B * Lk, E, c.TE), gemm(b.kvn, c.TE, w.wv, w.bv, b.Vt, E, B * Lk, E, c.TE)};
       TRY(launch_gemm(gkv, 2, A_ROWS, st));
@@ -716,6 +741,42 @@ int dcf_debug_copy(dcf_model* m, int32_t what, float* dst, int64_t max_floats, v
   DCF_CHECK(n <= max_floats, "dcf_debug_copy: destination too small (%lld > %lld)", (long long)n, (long long)max_floats);
   DCF_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
   return 0;
+}
+
+// ---- profiling ---------------------------------------------------------------------------------
+int dcf_profile_enable(int32_t on) {
+  for (auto& r : dcf::g_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  dcf::g_recs.clear();
+  dcf::g_prof_on = on != 0;
+  return 0;
+}
+
+int64_t dcf_profile_report(char* buf, int64_t cap) {
+  struct Agg { long count = 0; double ms = 0, flops = 0, bytes = 0; };
+  std::vector<std::pair<std::string, Agg>> aggs;
+  for (auto& r : dcf::g_recs) {
+    if (hipEventSynchronize(r.b) != hipSuccess) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+    Agg* a = nullptr;
+    for (auto& kv : aggs) if (kv.first == r.name) a = &kv.second;
+    if (!a) { aggs.emplace_back(r.name, Agg()); a = &aggs.back().second; }
+    a->count++; a->ms += ms; a->flops += r.flops; a->bytes += r.bytes;
+  }
+  std::string out = "{";
+  for (size_t i = 0; i < aggs.size(); ++i) {
+    char line[512];
+    snprintf(line, sizeof(line), "%s\"%s\": {\"count\": %ld, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}", i ? ", " : "",
+             aggs[i].first.c_str(), aggs[i].second.count, aggs[i].second.ms, aggs[i].second.flops, aggs[i].second.bytes);
+    out += line;
+  }
+  out += "}";
+  if (buf && cap > 0) {
+    size_t n = std::min((size_t)cap - 1, out.size());
+    memcpy(buf, out.data(), n);
+    buf[n] = 0;
+  }
+  return (int64_t)out.size() + 1;
 }
 
 // ---- post-processing -------------------------------------------------------------------------

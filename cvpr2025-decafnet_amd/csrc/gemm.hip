@@ -12,6 +12,8 @@
 //   successive MFMAs; the k index inside an 8-chunk is therefore permuted identically for A
 //   and W, which leaves the dot product unchanged.
 //   The next K tile is prefetched global->registers while the current one is multiplied.
+#include <cstdio>
+
 #include "common.h"
 #include "gemm.h"
 
@@ -55,53 +57,69 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
   f32x4 areg[A_F4];
   f32x4 breg[B_F4];
 
+  // Row predicates / base pointers of this thread's A-tile slots are K-invariant: resolve them once so
+  // that the K loop issues nothing but 16-byte loads (a mask byte load inside the loop would force an
+  // s_waitcnt vmcnt(0) in front of the MFMAs and expose the whole W-tile fetch every step).
+  const float* a_ptr[A_F4];
+  unsigned a_flag[A_F4];
+#pragma unroll
+  for (int i = 0; i < A_F4; ++i) {
+    int idx = i * 256 + tid;
+    if constexpr (AMODE == A_CHANMAJOR) {
+      constexpr int TPR = BM / 4;
+      int kr = idx / TPR, m4 = idx % TPR;
+      a_ptr[i] = p.A + (int64_t)kr * p.lda + m0 + m4 * 4;
+      a_flag[i] = (unsigned)(m0 + m4 * 4);
+    } else {
+      int row = idx >> 3, c4 = idx & 7;
+      int m = m0 + row;
+      unsigned f = 0;
+      if (m < M) {
+        if constexpr (AMODE == A_ROWS) f = (p.flags & G_AMASK) ? (p.rowmask[m] ? 1u : 0u) : 1u;
+        else f = p.nbr[m];
+      }
+      a_flag[i] = f;
+      a_ptr[i] = p.A + (int64_t)(m < M ? m : 0) * p.lda + c4 * 4;
+    }
+  }
+  const f32x4* w_ptr[B_F4];
+#pragma unroll
+  for (int i = 0; i < B_F4; ++i) {
+    int idx = i * 256 + tid;
+    int row = idx >> 3, c4 = idx & 7;
+    w_ptr[i] = reinterpret_cast<const f32x4*>(p.W + (int64_t)(n0 + row) * p.ldw + c4 * 4);
+  }
+
   auto load_tiles = [&](int kt) __attribute__((always_inline)) {
     const int k0 = kt * BK;
     // ---- W tile: rows n0..n0+BN, cols k0..k0+32 (always in range: N % BN == 0, K % 32 == 0)
 #pragma unroll
-    for (int i = 0; i < B_F4; ++i) {
-      int idx = i * 256 + tid;
-      int row = idx >> 3, c4 = idx & 7;
-      breg[i] = *reinterpret_cast<const f32x4*>(p.W + (int64_t)(n0 + row) * p.ldw + k0 + c4 * 4);
-    }
+    for (int i = 0; i < B_F4; ++i) breg[i] = w_ptr[i][k0 / 4];
     // ---- A tile
     if constexpr (AMODE == A_ROWS) {
 #pragma unroll
       for (int i = 0; i < A_F4; ++i) {
-        int idx = i * 256 + tid;
-        int row = idx >> 3, c4 = idx & 7;
-        int m = m0 + row;
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        bool ok = m < M;
-        if (ok && (p.flags & G_AMASK)) ok = p.rowmask[m] != 0;
-        if (ok) v = *reinterpret_cast<const f32x4*>(p.A + (int64_t)m * p.lda + k0 + c4 * 4);
+        if (a_flag[i]) v = *reinterpret_cast<const f32x4*>(a_ptr[i] + k0);
         areg[i] = v;
       }
     } else if constexpr (AMODE == A_ROWS_TAP3) {
       const int tap = k0 / p.cin;           // cin % 32 == 0 so a K tile never straddles taps
       const int c0 = k0 - tap * p.cin;
+      const unsigned bit = tap == 0 ? 2u : (tap == 1 ? 1u : 4u);
+      const int64_t shift = (int64_t)(tap - 1) * p.lda + c0;
 #pragma unroll
       for (int i = 0; i < A_F4; ++i) {
-        int idx = i * 256 + tid;
-        int row = idx >> 3, c4 = idx & 7;
-        int m = m0 + row;
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (m < M) {
-          unsigned f = p.nbr[m];
-          bool ok = (tap == 0) ? (f & 2u) : (tap == 1) ? (f & 1u) : (f & 4u);
-          if (ok) v = *reinterpret_cast<const f32x4*>(p.A + (int64_t)(m + tap - 1) * p.lda + c0 + c4 * 4);
-        }
+        if (a_flag[i] & bit) v = *reinterpret_cast<const f32x4*>(a_ptr[i] + shift);
         areg[i] = v;
       }
     } else {  // A_CHANMAJOR: 32 k-rows x BM m, f32x4 along m
-      constexpr int TPR = BM / 4;            // threads per k-row
       const bool vec = (p.lda & 3) == 0;
 #pragma unroll
       for (int i = 0; i < A_F4; ++i) {
-        int idx = i * 256 + tid;
-        int kr = idx / TPR, m4 = idx % TPR;
-        int m = m0 + m4 * 4;
-        const float* src = p.A + (int64_t)(k0 + kr) * p.lda + m;
+        const int m = (int)a_flag[i];
+        const float* src = a_ptr[i] + (int64_t)k0 * p.lda;
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
         if (vec && m + 3 < M) {
           v = *reinterpret_cast<const f32x4*>(src);
@@ -221,6 +239,11 @@ static int launch_cfg(const GemmBatch& b, int count, GemmAMode mode, hipStream_t
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const GemmArgs& p = b.g[0];
   dim3 grid((p.M + BM - 1) / BM, p.N / BN, count);
+  char name[96];
+  snprintf(name, sizeof(name), "gemm_f32<%dx%d,%s>", BM, BN, mode == A_ROWS ? "rows" : mode == A_ROWS_TAP3 ? "tap3" : "chanmajor");
+  const double mnk = (double)count * p.M * (double)p.N * p.K;
+  ProfScope prof(name, stream, 2.0 * mnk,
+                 4.0 * count * ((double)p.M * p.K / (mode == A_ROWS_TAP3 ? 3 : 1) + (double)p.N * p.K + (double)p.M * p.N * ((p.flags & G_RES) ? 2 : 1)));
   size_t lds_rows = (size_t)(BM + BN) * PITCH * sizeof(float);
   size_t lds_km = (size_t)(BK * (BM + 4) + BN * PITCH) * sizeof(float);
   switch (mode) {
@@ -258,11 +281,16 @@ int launch_gemm(const GemmArgs* g, int count, GemmAMode mode, hipStream_t stream
   if (p.M <= 0) return 0;
   DCF_CHECK(p.K > 0 && p.K % BK == 0, "launch_gemm: K=%d must be a positive multiple of 32", p.K);
   DCF_CHECK(p.N > 0 && p.N % 32 == 0, "launch_gemm: N=%d must be a positive multiple of 32", p.N);
+  // Tile choice: the largest tile that still gives every CU >= 2 workgroups (one wave per SIMD cannot
+  // overlap its own global->LDS staging with its MFMAs); small problems take the smallest tile so that
+  // the launch is spread over as many CUs as possible.
   const int N = p.N;
-  if (N % 256 == 0) return launch_cfg<2, 2, 1, 4>(b, count, mode, stream);
-  if (N % 160 == 0) return launch_cfg<4, 1, 1, 5>(b, count, mode, stream);
-  if (N % 128 == 0) return launch_cfg<2, 2, 1, 2>(b, count, mode, stream);
-  if (N % 96 == 0) return launch_cfg<4, 1, 1, 3>(b, count, mode, stream);
+  auto wgs = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * (N / bn) * count; };
+  constexpr long WANT = 512;
+  if (N % 256 == 0 && wgs(64, 256) >= WANT) return launch_cfg<2, 2, 1, 4>(b, count, mode, stream);
+  if (N % 160 == 0 && N % 64 != 0) return launch_cfg<4, 1, 1, 5>(b, count, mode, stream);
+  if (N % 128 == 0 && wgs(64, 128) >= WANT) return launch_cfg<2, 2, 1, 2>(b, count, mode, stream);
+  if (N % 96 == 0 && N % 64 != 0) return launch_cfg<4, 1, 1, 3>(b, count, mode, stream);
   if (N % 64 == 0) return launch_cfg<2, 2, 1, 1>(b, count, mode, stream);
   return launch_cfg<4, 1, 1, 1>(b, count, mode, stream);
 }

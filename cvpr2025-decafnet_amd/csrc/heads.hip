@@ -72,6 +72,7 @@ int launch_conv_out(const ConvOutArgs& a, hipStream_t st) {
   DCF_CHECK(a.C % 4 == 0 && a.C <= 1024, "conv_out: C=%d unsupported", a.C);
   const int n = (a.C + 255) / 256;
   dim3 grid((a.rows + 3) / 4), blk(256);
+  ProfScope prof("conv_out", st, 6.0 * a.rows * a.C * a.NO, 4.0 * a.rows * a.C);
 #define CO(NCH_)                                                                          \
   if (a.NO == 1) hipLaunchKernelGGL((k_conv_out<NCH_, 1>), grid, blk, 0, st, a);          \
   else hipLaunchKernelGGL((k_conv_out<NCH_, 2>), grid, blk, 0, st, a)
@@ -120,47 +121,76 @@ __device__ __forceinline__ void load_row32(const float* __restrict__ src, float 
 }
 
 // DilatedResidualLayer.forward (tcn.py:21-38): relu(dilated k3) -> 1x1 -> (x + out) * mask -> LayerNorm(32)
+// One lane = one row, 32 accumulators in registers.  The layer's 4 K weights are staged in LDS once
+// per workgroup and read back as wave-uniform (broadcast) ds_read_b128; the lane's 96 inputs are
+// parked in an LDS column so the reduction loop can stay ROLLED (a fully unrolled version makes the
+// compiler hoist 1024 weight reads and spill 6.5 KB per lane; scalar s_loads were latency bound).
 __global__ __launch_bounds__(64) void k_tcn_layer(const float* __restrict__ X, float* __restrict__ Y,
                                                    const float* __restrict__ wd, const float* __restrict__ bd,
                                                    const float* __restrict__ wp, const float* __restrict__ bp,
                                                    const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                    const uint8_t* __restrict__ mask, int B, int T0, int dil) {
-  const int r = blockIdx.x * 64 + threadIdx.x;
-  if (r >= B * T0) return;
-  const int t = r % T0;
-  float x0[TCN_HID], h[TCN_HID];
-#pragma unroll
-  for (int c = 0; c < TCN_HID; ++c) h[c] = bd[c];
+  __shared__ f32x4 s_wd[3 * TCN_HID * TCN_HID / 4];
+  __shared__ f32x4 s_wp[TCN_HID * TCN_HID / 4];
+  __shared__ float s_x[3 * TCN_HID][64];
+  __shared__ float s_h[TCN_HID][64];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 3 * TCN_HID * TCN_HID / 4; i += 64) s_wd[i] = reinterpret_cast<const f32x4*>(wd)[i];
+  for (int i = lane; i < TCN_HID * TCN_HID / 4; i += 64) s_wp[i] = reinterpret_cast<const f32x4*>(wp)[i];
+  const int r = blockIdx.x * 64 + lane;
+  const bool live = r < B * T0;
+  const int t = live ? r % T0 : 0;
+  float x0[TCN_HID];
 #pragma unroll
   for (int tap = 0; tap < 3; ++tap) {
     const int tt = t + (tap - 1) * dil;
     float xin[TCN_HID];
-    if (tt >= 0 && tt < T0) {
+    if (live && tt >= 0 && tt < T0) {
       load_row32(X + (int64_t)(r + (tap - 1) * dil) * TCN_HID, xin);
     } else {
 #pragma unroll
       for (int c = 0; c < TCN_HID; ++c) xin[c] = 0.f;
     }
-    if (tap == 1) {
 #pragma unroll
-      for (int c = 0; c < TCN_HID; ++c) x0[c] = xin[c];
+    for (int c = 0; c < TCN_HID; ++c) {
+      s_x[tap * TCN_HID + c][lane] = xin[c];
+      if (tap == 1) x0[c] = xin[c];
     }
+  }
+  __syncthreads();
+  float h[TCN_HID];
 #pragma unroll
-    for (int ci = 0; ci < TCN_HID; ++ci) {
-      const float* w = wd + ((size_t)tap * TCN_HID + ci) * TCN_HID;
+  for (int c = 0; c < TCN_HID; ++c) h[c] = bd[c];
+#pragma unroll 2
+  for (int k = 0; k < 3 * TCN_HID; ++k) {
+    const float xv = s_x[k][lane];
+    const f32x4* w = s_wd + k * (TCN_HID / 4);
 #pragma unroll
-      for (int co = 0; co < TCN_HID; ++co) h[co] += w[co] * xin[ci];
+    for (int c4 = 0; c4 < TCN_HID / 4; ++c4) {
+      const f32x4 ww = w[c4];
+      h[4 * c4 + 0] += ww.x * xv;
+      h[4 * c4 + 1] += ww.y * xv;
+      h[4 * c4 + 2] += ww.z * xv;
+      h[4 * c4 + 3] += ww.w * xv;
     }
   }
   float o[TCN_HID];
 #pragma unroll
-  for (int c = 0; c < TCN_HID; ++c) { o[c] = bp[c]; h[c] = fmaxf(h[c], 0.f); }
-#pragma unroll
+  for (int c = 0; c < TCN_HID; ++c) { s_h[c][lane] = fmaxf(h[c], 0.f); o[c] = bp[c]; }
+#pragma unroll 2
   for (int ci = 0; ci < TCN_HID; ++ci) {
-    const float* w = wp + (size_t)ci * TCN_HID;
+    const float hv = s_h[ci][lane];
+    const f32x4* w = s_wp + ci * (TCN_HID / 4);
 #pragma unroll
-    for (int co = 0; co < TCN_HID; ++co) o[co] += w[co] * h[ci];
+    for (int c4 = 0; c4 < TCN_HID / 4; ++c4) {
+      const f32x4 ww = w[c4];
+      o[4 * c4 + 0] += ww.x * hv;
+      o[4 * c4 + 1] += ww.y * hv;
+      o[4 * c4 + 2] += ww.z * hv;
+      o[4 * c4 + 3] += ww.w * hv;
+    }
   }
+  if (!live) return;
   const float m = mask[r] ? 1.f : 0.f;
   float mean = 0.f;
 #pragma unroll
@@ -234,6 +264,7 @@ int launch_refine(const RefineArgs& a, const LevelTable& lt, hipStream_t st) {
   if (rows0 <= 0) return 0;
   DCF_CHECK(a.ldf % 4 == 0 && a.E % 4 == 0, "refine: ldf/E must be multiples of 4");
   dim3 g64((rows0 + 63) / 64), b64(64);
+  ProfScope prof("refine_tcn", st, 2.0 * rows0 * (a.n_layers * 4096.0 + 32.0 * a.n_levels + 1024.0), 4.0 * rows0 * 64.0 * (a.n_layers + 2));
   hipLaunchKernelGGL(k_refine_in, g64, b64, 0, st, a);
   float* cur = a.bufA;
   float* nxt = a.bufB;

@@ -189,6 +189,7 @@ int launch_collect(const CollectArgs& a, int nq, hipStream_t st) {
   if (nq <= 0) return 0;
   DCF_CHECK(a.pre_nms_topk >= 1 && a.pre_nms_topk <= CAND_CAP, "collect: pre_nms_topk=%d exceeds %d", a.pre_nms_topk, CAND_CAP);
   DCF_CHECK(a.n_levels >= 1 && a.n_levels <= 16, "collect: bad n_levels");
+  ProfScope prof("collect_segments", st, 0.0, 4.0 * 4.0 * nq * a.S);
   hipLaunchKernelGGL(k_collect, dim3(nq), dim3(NT), 0, st, a);
   DCF_HIP(hipGetLastError());
   return 0;
@@ -251,6 +252,7 @@ int launch_nms(const NmsArgs& a, int nq, hipStream_t st) {
   if (nq <= 0) return 0;
   DCF_CHECK(a.n_max >= 0 && a.n_max <= NMS_CAP, "nms: n=%d exceeds the on-chip capacity %d", a.n_max, NMS_CAP);
   DCF_CHECK(a.stride >= a.n_max, "nms: stride < n_max");
+  ProfScope prof("nms_1d", st, 0.0, 0.0);
   hipLaunchKernelGGL(k_nms, dim3(nq), dim3(NT), 0, st, a);
   DCF_HIP(hipGetLastError());
   return 0;
@@ -378,6 +380,7 @@ int launch_softnms(const SoftNmsArgs& a, int nq, hipStream_t st) {
   DCF_CHECK(a.n_max >= 0 && a.n_max <= NMS_CAP, "softnms: n=%d exceeds the on-chip capacity %d", a.n_max, NMS_CAP);
   DCF_CHECK(a.method >= 0 && a.method <= 2, "softnms: method must be 0, 1 or 2");
   DCF_CHECK(a.stride >= a.n_max, "softnms: stride < n_max");
+  ProfScope prof("softnms_1d", st, 0.0, 0.0);
   hipLaunchKernelGGL(k_softnms, dim3(nq), dim3(NT), 0, st, a);
   DCF_HIP(hipGetLastError());
   return 0;

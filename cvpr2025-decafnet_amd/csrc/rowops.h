@@ -27,6 +27,7 @@ struct DecPreArgs {
   const float* qn_w; const float* qn_b;
   float* Qc; float* Xa;             // [B*T][C]
   int B, T, C;
+  int strip;                        // rows per wavefront (filled in by the launcher)
 };
 
 struct EncPreArgs {
@@ -38,6 +39,7 @@ struct EncPreArgs {
   float* Qc; float* Kc; float* Vc;  // [B*T_out][C]
   float* Skip;                      // [B*T_out][C] (stride 2 only)
   int B, T_in, C;
+  int strip;                        // output rows per wavefront (filled in by the launcher)
 };
 
 struct TextMeta {                   // lives in device memory

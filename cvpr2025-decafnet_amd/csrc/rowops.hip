@@ -10,7 +10,13 @@
 
 namespace dcf {
 
-constexpr int STRIP = 16;  // output rows per wavefront
+// Output rows per wavefront: long strips amortise the window warm-up (2 extra rows), short strips expose
+// more wavefronts when a pyramid level is small.
+static inline int pick_strip(long rows) {
+  int s = 16;
+  while (s > 2 && rows / s < 2048) s >>= 1;
+  return s;
+}
 
 // ------------------------------------------------------------------------------------------
 // masks
@@ -117,6 +123,7 @@ __device__ __forceinline__ void axpy3(Row<NCH>& out, const Row<NCH>& a, const Ro
 template <int NCH>
 __global__ __launch_bounds__(256) void k_dec_pre(DecPreArgs p) {
   const int lane = threadIdx.x & 63;
+  const int STRIP = p.strip;
   const int strips_per_b = (p.T + STRIP - 1) / STRIP;
   const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (s >= strips_per_b * p.B) return;
@@ -187,6 +194,7 @@ template <int NCH, int S>
 __global__ __launch_bounds__(256) void k_enc_pre(EncPreArgs p) {
   const int lane = threadIdx.x & 63;
   const int To = p.T_in / S;
+  const int STRIP = p.strip;
   const int strips_per_b = (To + STRIP - 1) / STRIP;
   const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (s >= strips_per_b * p.B) return;
@@ -302,6 +310,7 @@ int launch_mask_down(const uint8_t* in, uint8_t* out, int rows_out, hipStream_t 
 int launch_vidmap_combine(const float* P1, const float* P2, const float* bias, const float* gate, const uint8_t* mask,
                           float* X, int T, int rows, int E, hipStream_t st) {
   if (rows <= 0) return 0;
+  ProfScope prof("vidmap_combine", st, 3.0 * rows * E, 4.0 * 3.0 * rows * E);
   DISPATCH_NCH(E, hipLaunchKernelGGL((k_vidmap_combine<NCH>), dim3((rows + 3) / 4), dim3(256), 0, st, P1, P2, bias, gate,
                                      mask, X, T, rows, E));
   return 0;
@@ -311,13 +320,18 @@ int launch_ln(const LnArgs& a, hipStream_t st) {
   if (a.rows <= 0) return 0;
   DCF_CHECK(a.ldx % 4 == 0 && a.ldy % 4 == 0, "launch_ln: row pitch must be a multiple of 4");
   DCF_CHECK(!a.pe || (a.mask && a.T > 0), "launch_ln: pe needs mask and T");
+  ProfScope prof("layernorm", st, 8.0 * a.rows * a.C, 4.0 * a.rows * a.C * (a.pe ? 3.0 : 2.0));
   DISPATCH_NCH(a.C, hipLaunchKernelGGL((k_ln<NCH>), dim3((a.rows + 3) / 4), dim3(256), 0, st, a));
   return 0;
 }
 
-int launch_dec_pre(const DecPreArgs& a, hipStream_t st) {
-  if (a.B * a.T <= 0) return 0;
+int launch_dec_pre(const DecPreArgs& a_, hipStream_t st) {
+  if (a_.B * a_.T <= 0) return 0;
+  DecPreArgs a = a_;
+  a.strip = pick_strip((long)a.B * a.T);
+  const int STRIP = a.strip;
   int strips = a.B * ((a.T + STRIP - 1) / STRIP);
+  ProfScope prof("dec_pre", st, 30.0 * a.B * a.T * a.C, 4.0 * 3.0 * a.B * a.T * a.C);
   DISPATCH_NCH(a.C, hipLaunchKernelGGL((k_dec_pre<NCH>), dim3((strips + 3) / 4), dim3(256), 0, st, a));
   return 0;
 }
@@ -325,17 +339,23 @@ int launch_dec_pre(const DecPreArgs& a, hipStream_t st) {
 int launch_dec_mid(const float* Xa, const float* H, const float* ln_w, const float* ln_b, float* Q3, float* Xn, int rows,
                    int C, hipStream_t st) {
   if (rows <= 0) return 0;
+  ProfScope prof("dec_mid", st, 10.0 * rows * C, 4.0 * 5.0 * rows * C);
   DISPATCH_NCH(C, hipLaunchKernelGGL((k_dec_mid<NCH>), dim3((rows + 3) / 4), dim3(256), 0, st, Xa, H, ln_w, ln_b, Q3, Xn,
                                      rows, C));
   return 0;
 }
 
-int launch_enc_pre(const EncPreArgs& a, int stride, hipStream_t st) {
+int launch_enc_pre(const EncPreArgs& a_, int stride, hipStream_t st) {
   DCF_CHECK(stride == 1 || stride == 2, "enc_pre: stride %d unsupported", stride);
-  DCF_CHECK(a.T_in % stride == 0, "enc_pre: T_in %% stride != 0");
-  if (a.B * a.T_in <= 0) return 0;
+  DCF_CHECK(a_.T_in % stride == 0, "enc_pre: T_in %% stride != 0");
+  if (a_.B * a_.T_in <= 0) return 0;
+  EncPreArgs a = a_;
   int To = a.T_in / stride;
+  a.strip = pick_strip((long)a.B * To);
+  const int STRIP = a.strip;
   int strips = a.B * ((To + STRIP - 1) / STRIP);
+  ProfScope prof(stride == 1 ? "enc_pre_s1" : "enc_pre_s2", st, 50.0 * a.B * To * a.C,
+                 4.0 * a.C * a.B * ((double)a.T_in + (stride == 1 ? 3.0 : 4.0) * To));
   if (stride == 1) {
     DISPATCH_NCH(a.C, hipLaunchKernelGGL((k_enc_pre<NCH, 1>), dim3((strips + 3) / 4), dim3(256), 0, st, a));
   } else {

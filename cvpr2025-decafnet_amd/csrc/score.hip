@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256) void k_sidekick_final(ScoreArgs p) {
 
 int launch_sidekick(const ScoreArgs& a, hipStream_t st) {
   if (a.NQ <= 0 || a.T <= 0) return 0;
+  ProfScope prof("sidekick_score", st, 2.0 * (a.NQ + 1.0) * a.D * a.T, 4.0 * (double)a.D * a.T * ((a.NQ + SCORE_MAXQ - 1) / SCORE_MAXQ));
   hipLaunchKernelGGL(k_text_cls_norm, dim3(a.NQ), dim3(256), 0, st, a.text_cls, a.tn, a.D, a.norm);
   dim3 grid((a.T + 255) / 256, SCORE_SLICES);
   for (int q0 = 0; q0 < a.NQ; q0 += SCORE_MAXQ) {
@@ -159,6 +160,7 @@ int launch_gate(const GateArgs& a, hipStream_t st) {
   if (a.B <= 0) return 0;
   DCF_CHECK(a.sn >= 1, "gate: sn must be >= 1");
   DCF_CHECK((a.T + a.sn - 1) / a.sn <= GATE_MAX_BLOCKS, "gate: more than %d pooling blocks (T=%d, sn=%d)", GATE_MAX_BLOCKS, a.T, a.sn);
+  ProfScope prof("gate_topk", st, 0.0, 4.0 * 2.0 * a.B * a.T);
   hipLaunchKernelGGL(k_gate, dim3(a.B), dim3(1024), 0, st, a);
   DCF_HIP(hipGetLastError());
   return 0;

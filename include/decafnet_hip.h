@@ -118,6 +118,14 @@ int dcf_segment_voting(const float* nms_segs, int32_t nms_ld, const int32_t* n1_
                        int32_t nq, float* out, void* stream);
 
 /* --------------------------------------------------------------------------------------------
+ * Measurement aid: when enabled, every kernel launch of the library is bracketed by HIP events on
+ * its own stream.  dcf_profile_report writes a JSON object {kernel: {count, ms, flops, bytes}} (flops
+ * and bytes are the ALGORITHMIC work of the launches) into buf and returns the required size.
+ * ------------------------------------------------------------------------------------------ */
+int dcf_profile_enable(int32_t on);
+int64_t dcf_profile_report(char* buf, int64_t cap);
+
+/* --------------------------------------------------------------------------------------------
  * Single-operator entry points (used by the parity tests and micro-benchmarks).
  * ------------------------------------------------------------------------------------------ */
 /* C[M][N] = act(A[M][K] * W[N][K]^T + bias): nn.Conv1d(k=1) on token-major activations.

@@ -25,7 +25,16 @@ def L():
     return pkg, lib
 
 
+_KEEP = []
+
+
 def P(t):
+    """device address; the tensor is kept alive (temporaries like ``x.cuda()`` would otherwise be freed and
+    their memory reused before the kernel has run)"""
+    _KEEP.append(t)
+    if len(_KEEP) > 256:
+        torch.cuda.synchronize()
+        del _KEEP[:128]
     return ctypes.c_void_p(t.data_ptr())
 
 
