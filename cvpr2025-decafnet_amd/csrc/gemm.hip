@@ -13,21 +13,22 @@
 //   and W, which leaves the dot product unchanged.
 //   The next K tile is prefetched global->registers while the current one is multiplied.
 #include <cstdio>
+#include <cstdlib>
 
 #include "common.h"
 #include "gemm.h"
 
 namespace dcf {
 
-constexpr int BK = 32;
-constexpr int PITCH = 36;
 
 struct GemmBatch {
   GemmArgs g[3];
 };
 
-template <int WM, int WN, int TM, int TN, int AMODE>
+template <int WM, int WN, int TM, int TN, int AMODE, int BK>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
+  constexpr int PITCH = BK + 4;             // 36 = 4*9 / 68 = 4*17: odd multiples of 4 keep b128 reads conflict free
+  constexpr int C4 = BK / 4;                // f32x4 per tile row
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
   constexpr int A_F4 = BM * BK / 4 / 256;  // f32x4 per thread for the A tile
@@ -54,8 +55,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
   const int M = p.M, K = p.K;
   const int KT = K / BK;
 
-  f32x4 areg[A_F4];
-  f32x4 breg[B_F4];
 
   // Row predicates / base pointers of this thread's A-tile slots are K-invariant: resolve them once so
   // that the K loop issues nothing but 16-byte loads (a mask byte load inside the loop would force an
@@ -71,7 +70,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
       a_ptr[i] = p.A + (int64_t)kr * p.lda + m0 + m4 * 4;
       a_flag[i] = (unsigned)(m0 + m4 * 4);
     } else {
-      int row = idx >> 3, c4 = idx & 7;
+      int row = idx / C4, c4 = idx % C4;
       int m = m0 + row;
       unsigned f = 0;
       if (m < M) {
@@ -86,11 +85,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
 #pragma unroll
   for (int i = 0; i < B_F4; ++i) {
     int idx = i * 256 + tid;
-    int row = idx >> 3, c4 = idx & 7;
+    int row = idx / C4, c4 = idx % C4;
     w_ptr[i] = reinterpret_cast<const f32x4*>(p.W + (int64_t)(n0 + row) * p.ldw + c4 * 4);
   }
 
-  auto load_tiles = [&](int kt) __attribute__((always_inline)) {
+  auto load_tiles = [&](int kt, f32x4 (&areg)[A_F4], f32x4 (&breg)[B_F4]) __attribute__((always_inline)) {
     const int k0 = kt * BK;
     // ---- W tile: rows n0..n0+BN, cols k0..k0+32 (always in range: N % BN == 0, K % 32 == 0)
 #pragma unroll
@@ -134,11 +133,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
     }
   };
 
-  auto store_tiles = [&]() __attribute__((always_inline)) {
+  auto store_tiles = [&](const f32x4 (&areg)[A_F4], const f32x4 (&breg)[B_F4]) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < B_F4; ++i) {
       int idx = i * 256 + tid;
-      int row = idx >> 3, c4 = idx & 7;
+      int row = idx / C4, c4 = idx % C4;
       *reinterpret_cast<f32x4*>(Bs + row * PITCH + c4 * 4) = breg[i];
     }
     if constexpr (AMODE == A_CHANMAJOR) {
@@ -153,7 +152,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
 #pragma unroll
       for (int i = 0; i < A_F4; ++i) {
         int idx = i * 256 + tid;
-        int row = idx >> 3, c4 = idx & 7;
+        int row = idx / C4, c4 = idx % C4;
         *reinterpret_cast<f32x4*>(As + row * PITCH + c4 * 4) = areg[i];
       }
     }
@@ -167,12 +166,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  load_tiles(0);
-  for (int kt = 0; kt < KT; ++kt) {
-    __syncthreads();
-    store_tiles();
-    __syncthreads();
-    load_tiles(kt + 1 < KT ? kt + 1 : kt);   // unconditional (last iteration re-reads its own tile)
+  auto compute = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
       f32x4 a[TM], b[TN];
@@ -201,6 +195,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
         }
     }
+  };
+
+  // one K tile in flight: fetched global->registers while the previous tile is multiplied.  (Keeping
+  // two tiles in flight was measured and buys nothing: a lone workgroup is bound by its two barriers
+  // and the LDS round trip per K tile, not by the global fetch.)
+  f32x4 areg[A_F4], breg[B_F4];
+  load_tiles(0, areg, breg);
+  for (int kt = 0; kt < KT; ++kt) {
+    __syncthreads();
+    store_tiles(areg, breg);
+    __syncthreads();
+    load_tiles(kt + 1 < KT ? kt + 1 : kt, areg, breg);   // unconditional (last iteration re-reads its own tile)
+    compute();
   }
 
   // ---- epilogue.  D layout of a 32x32 tile: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * h
@@ -234,27 +241,29 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
   }
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int BK = 32>
 static int launch_cfg(const GemmBatch& b, int count, GemmAMode mode, hipStream_t stream) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const GemmArgs& p = b.g[0];
   dim3 grid((p.M + BM - 1) / BM, p.N / BN, count);
   char name[96];
-  snprintf(name, sizeof(name), "gemm_f32<%dx%d,%s>", BM, BN, mode == A_ROWS ? "rows" : mode == A_ROWS_TAP3 ? "tap3" : "chanmajor");
+  snprintf(name, sizeof(name), "gemm_f32<%dx%dx%d,%s>", BM, BN, BK, mode == A_ROWS ? "rows" : mode == A_ROWS_TAP3 ? "tap3" : "chanmajor");
   const double mnk = (double)count * p.M * (double)p.N * p.K;
   ProfScope prof(name, stream, 2.0 * mnk,
                  4.0 * count * ((double)p.M * p.K / (mode == A_ROWS_TAP3 ? 3 : 1) + (double)p.N * p.K + (double)p.M * p.N * ((p.flags & G_RES) ? 2 : 1)));
+  constexpr int PITCH = BK + 4;
   size_t lds_rows = (size_t)(BM + BN) * PITCH * sizeof(float);
   size_t lds_km = (size_t)(BK * (BM + 4) + BN * PITCH) * sizeof(float);
+  DCF_CHECK(p.K % BK == 0 && (mode != A_ROWS_TAP3 || p.cin % BK == 0), "launch_gemm: K/cin not a multiple of BK=%d", BK);
   switch (mode) {
     case A_ROWS:
-      hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, A_ROWS>), grid, dim3(256), lds_rows, stream, b);
+      hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, A_ROWS, BK>), grid, dim3(256), lds_rows, stream, b);
       break;
     case A_ROWS_TAP3:
-      hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, A_ROWS_TAP3>), grid, dim3(256), lds_rows, stream, b);
+      hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, A_ROWS_TAP3, BK>), grid, dim3(256), lds_rows, stream, b);
       break;
     case A_CHANMAJOR:
-      hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, A_CHANMAJOR>), grid, dim3(256), lds_km, stream, b);
+      hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, A_CHANMAJOR, BK>), grid, dim3(256), lds_km, stream, b);
       break;
   }
   DCF_HIP(hipGetLastError());
@@ -279,7 +288,7 @@ int launch_gemm(const GemmArgs* g, int count, GemmAMode mode, hipStream_t stream
     if (g[i].flags & G_RES) DCF_CHECK(g[i].R, "launch_gemm: residual missing");
   }
   if (p.M <= 0) return 0;
-  DCF_CHECK(p.K > 0 && p.K % BK == 0, "launch_gemm: K=%d must be a positive multiple of 32", p.K);
+  DCF_CHECK(p.K > 0 && p.K % 32 == 0, "launch_gemm: K=%d must be a positive multiple of 32", p.K);
   DCF_CHECK(p.N > 0 && p.N % 32 == 0, "launch_gemm: N=%d must be a positive multiple of 32", p.N);
   // Tile choice: the largest tile that still gives every CU >= 2 workgroups (one wave per SIMD cannot
   // overlap its own global->LDS staging with its MFMAs); small problems take the smallest tile so that
@@ -287,6 +296,30 @@ int launch_gemm(const GemmArgs* g, int count, GemmAMode mode, hipStream_t stream
   const int N = p.N;
   auto wgs = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * (N / bn) * count; };
   constexpr long WANT = 512;
+  // DCF_GEMM_CFG="BMxBN" forces a tile for experiments (tools/gemm_sweep.py); ignored if it does not divide N
+  static const char* forced = getenv("DCF_GEMM_CFG");
+  if (forced) {
+    int bm = 0, bn = 0, bk = 32;
+    const int nf = sscanf(forced, "%dx%dx%d", &bm, &bn, &bk);
+    const bool k64ok = p.K % 64 == 0 && (mode != A_ROWS_TAP3 || p.cin % 64 == 0);
+    if (nf >= 2 && bn > 0 && N % bn == 0 && bk == 64 && k64ok) {
+      if (bm == 64 && bn == 128) return launch_cfg<2, 2, 1, 2, 64>(b, count, mode, stream);
+      if (bm == 64 && bn == 64) return launch_cfg<2, 2, 1, 1, 64>(b, count, mode, stream);
+      if (bm == 128 && bn == 64) return launch_cfg<4, 1, 1, 2, 64>(b, count, mode, stream);
+      if (bm == 128 && bn == 128) return launch_cfg<4, 1, 1, 4, 64>(b, count, mode, stream);
+    }
+    if (nf >= 2 && bn > 0 && N % bn == 0 && bk == 32) {
+      if (bm == 64 && bn == 256) return launch_cfg<2, 2, 1, 4>(b, count, mode, stream);
+      if (bm == 64 && bn == 128) return launch_cfg<2, 2, 1, 2>(b, count, mode, stream);
+      if (bm == 64 && bn == 64) return launch_cfg<2, 2, 1, 1>(b, count, mode, stream);
+      if (bm == 128 && bn == 32) return launch_cfg<4, 1, 1, 1>(b, count, mode, stream);
+      if (bm == 128 && bn == 64) return launch_cfg<4, 1, 1, 2>(b, count, mode, stream);
+      if (bm == 128 && bn == 96) return launch_cfg<4, 1, 1, 3>(b, count, mode, stream);
+      if (bm == 128 && bn == 128) return launch_cfg<4, 1, 1, 4>(b, count, mode, stream);
+      if (bm == 128 && bn == 160) return launch_cfg<4, 1, 1, 5>(b, count, mode, stream);
+      if (bm == 129 && bn == 128) return launch_cfg<2, 2, 2, 2>(b, count, mode, stream);   // 128x128, 64x64 per wave
+    }
+  }
   if (N % 256 == 0 && wgs(64, 256) >= WANT) return launch_cfg<2, 2, 1, 4>(b, count, mode, stream);
   if (N % 160 == 0 && N % 64 != 0) return launch_cfg<4, 1, 1, 5>(b, count, mode, stream);
   if (N % 128 == 0 && wgs(64, 128) >= WANT) return launch_cfg<2, 2, 1, 2>(b, count, mode, stream);

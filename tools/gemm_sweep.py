@@ -1,0 +1,52 @@
+"""Sweep GEMM tile configurations on the shapes of the grounding forward (GPU only, dev tool).
+usage: python tools/gemm_sweep.py  -> prints TFLOP/s per (shape, tile).  Each tile runs in its own process
+because the override is read once (DCF_GEMM_CFG)."""
+import ctypes, importlib, json, os, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+SHAPES = [(16384, 256, 256), (16384, 1024, 256), (16384, 256, 1024), (16384, 512, 256), (8192, 256, 256), (8192, 1024, 256),
+          (8192, 256, 1024), (2048, 256, 256), (2048, 256, 1024), (512, 256, 256), (512, 256, 1024), (128, 1024, 256), (131072, 256, 256),
+          (131072, 256, 1024)]
+TILES = ['auto', '64x128', '64x128x64', '64x64', '64x64x64', '128x64', '128x64x64', '128x128', '128x128x64']
+
+def child():
+    import torch
+    pkg = importlib.import_module('cvpr2025-decafnet_amd')
+    lib = pkg._lib.lib()
+    out = {}
+    for (M, N, K) in SHAPES:
+        A = torch.randn(M, K, device='cuda'); W = torch.randn(N, K, device='cuda'); b = torch.randn(N, device='cuda')
+        C = torch.empty(M, N, device='cuda')
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        P = lambda t: ctypes.c_void_p(t.data_ptr())
+        for _ in range(3):
+            lib.dcf_op_linear(P(A), P(W), P(b), P(C), M, N, K, 0, st)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        e0.record()
+        for _ in range(reps):
+            lib.dcf_op_linear(P(A), P(W), P(b), P(C), M, N, K, 0, st)
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        out[f'{M}x{N}x{K}'] = (us, 2.0 * M * N * K / us / 1e6)
+    print(json.dumps(out))
+
+if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'child':
+        child()
+    else:
+        res = {}
+        for t in TILES:
+            env = dict(os.environ)
+            if t != 'auto':
+                env['DCF_GEMM_CFG'] = t
+            r = subprocess.run([sys.executable, __file__, 'child'], env=env, capture_output=True, text=True)
+            try:
+                res[t] = json.loads(r.stdout.strip().splitlines()[-1])
+            except Exception:
+                print(t, 'failed', r.stderr[-500:])
+        print('%-18s' % 'shape MxNxK' + ''.join('%16s' % t for t in res))
+        for (M, N, K) in SHAPES:
+            k = f'{M}x{N}x{K}'
+            print('%-18s' % k + ''.join('%9.1fus %4.0fTF' % tuple(res[t][k]) for t in res))
