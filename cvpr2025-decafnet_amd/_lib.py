@@ -36,6 +36,8 @@ SIGNATURES = {
     'dcf_points_per_query': (i64, [vp, i64]),
     'dcf_forward_eval': (i32, [vp, c_f32p, c_f32p, c_u8p, i64, i32, ctypes.POINTER(vp), ctypes.POINTER(vp),
                                ctypes.POINTER(i32), c_f32p, c_f32p, c_f32p, c_u8p, vp]),
+    'dcf_forward_eval_gated': (i32, [vp, c_f32p, c_f32p, c_u8p, i64, i32, ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                     ctypes.POINTER(i32), c_f32p, c_f32p, c_f32p, c_u8p, vp]),
     'dcf_debug_copy': (i32, [vp, i32, c_f32p, i64, vp]),
     'dcf_profile_enable': (i32, [i32]),
     'dcf_profile_report': (i64, [ctypes.c_char_p, i64]),

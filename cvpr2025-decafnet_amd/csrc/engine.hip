@@ -86,6 +86,18 @@ __global__ void k_masks_out(const uint8_t* __restrict__ mask_all, uint8_t* __res
   out[(int64_t)b * lt->S + lt->off[l] + t] = mask_all[r];
 }
 
+// gate[b][t] = override[q0 + b][t]; mask = vid_mask (msf) or vid_mask & gate (model.py:544-545)
+__global__ void k_apply_gate(const float* __restrict__ gate_in, const uint8_t* __restrict__ vid_mask, float* __restrict__ gate,
+                             uint8_t* __restrict__ mask_out, int T, int rows, int msf) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const int t = r % T;
+  const float g = gate_in[r];
+  const bool m = vid_mask[t] != 0;
+  gate[r] = g;
+  mask_out[r] = msf ? m : (m && g != 0.f);
+}
+
 struct Bound {
   const float* p = nullptr;
   std::vector<int64_t> shape;
@@ -469,7 +481,8 @@ static int run_head(dcf_model* m, const HeadW& h, Buffers& b, const Plan& pl, in
 
 static int forward(dcf_model* m, const float* vid, const float* shallow, const uint8_t* vid_mask, int T0, int nq,
                    const float* const* text, const uint8_t* const* text_mask, const int32_t* text_len,
-                   const float* text_cls, float* logits_out, float* offsets_out, uint8_t* masks_out, hipStream_t st) {
+                   const float* text_cls, const float* gate_override, float* logits_out, float* offsets_out,
+                   uint8_t* masks_out, hipStream_t st) {
   const dcf_config& c = m->cfg;
   const int E = c.E, D = c.D, L = c.n_levels;
   DCF_CHECK(m->finalized, "dcf_forward_eval: model not finalized");
@@ -509,8 +522,10 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
   }
 
   // ---- per video: sidekick scores and the query-independent halves of vid_map
-  ScoreArgs sa{shallow, text_cls, b.tn, b.partial, b.correl, D, T0, nq, c.norm};
-  TRY(launch_sidekick(sa, st));
+  if (!gate_override) {
+    ScoreArgs sa{shallow, text_cls, b.tn, b.partial, b.correl, D, T0, nq, c.norm};
+    TRY(launch_sidekick(sa, st));
+  }
   const int Din = c.msf ? 2 * D : D;
   {
     GemmArgs g = gemm(vid, T0, m->vid_map_w, nullptr, b.P1, E, T0, E, D);
@@ -531,8 +546,15 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
     const int rows0 = B * T0, rowsAll = B * S;
 
     // ---- gate + masks for every level
-    GateArgs ga{b.correl, vid_mask, b.gate, b.mask_all, T0, B, q0, c.sn, c.msf, (double)c.sratio};
-    TRY(launch_gate(ga, st));
+    if (gate_override) {
+      // T-sharded videos: the gate was selected globally (all-gathered scores) by the caller
+      hipLaunchKernelGGL(k_apply_gate, dim3((rows0 + 255) / 256), dim3(256), 0, st, gate_override + (int64_t)q0 * T0, vid_mask,
+                         b.gate, b.mask_all, T0, rows0, c.msf);
+      DCF_HIP(hipGetLastError());
+    } else {
+      GateArgs ga{b.correl, vid_mask, b.gate, b.mask_all, T0, B, q0, c.sn, c.msf, (double)c.sratio};
+      TRY(launch_gate(ga, st));
+    }
     for (int l = 1; l < L; ++l) TRY(launch_mask_down(b.mask_all + lt.start[l - 1], b.mask_all + lt.start[l], B * lt.T[l], st));
     for (int l = 0; l < L; ++l) TRY(launch_rowflags(b.mask_all + lt.start[l], b.nbr_all + lt.start[l], lt.T[l], B * lt.T[l], st));
     const uint8_t* mask0 = b.mask_all;
@@ -715,7 +737,17 @@ int dcf_forward_eval(dcf_model* m, const float* vid, const float* shallow_vid, c
   DCF_CHECK(m && vid && shallow_vid && vid_mask && text && text_len && text_cls && logits_out && offsets_out && masks_out,
             "dcf_forward_eval: null argument");
   DCF_CHECK(T < (1ll << 24), "T too large");
-  return dcf::forward(m, vid, shallow_vid, vid_mask, (int)T, nq, text, text_mask, text_len, text_cls, logits_out,
+  return dcf::forward(m, vid, shallow_vid, vid_mask, (int)T, nq, text, text_mask, text_len, text_cls, nullptr, logits_out,
+                      offsets_out, masks_out, (hipStream_t)stream);
+}
+
+int dcf_forward_eval_gated(dcf_model* m, const float* vid, const float* shallow_vid, const uint8_t* vid_mask, int64_t T,
+                           int32_t nq, const float* const* text, const uint8_t* const* text_mask, const int32_t* text_len,
+                           const float* gate, float* logits_out, float* offsets_out, uint8_t* masks_out, void* stream) {
+  DCF_CHECK(m && vid && shallow_vid && vid_mask && text && text_len && gate && logits_out && offsets_out && masks_out,
+            "dcf_forward_eval_gated: null argument");
+  DCF_CHECK(T < (1ll << 24), "T too large");
+  return dcf::forward(m, vid, shallow_vid, vid_mask, (int)T, nq, text, text_mask, text_len, nullptr, gate, logits_out,
                       offsets_out, masks_out, (hipStream_t)stream);
 }
 

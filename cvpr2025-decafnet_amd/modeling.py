@@ -409,8 +409,21 @@ class PtTransformerEarlyFusionIterative(nn.Module):
             eng.pe_cache = {T: pe[:, :T].t().contiguous().to(device)}
         return eng.pe_cache[T]
 
+    def forward_window(self, vid, shallow_vid, vid_masks, text, text_masks, gate, pe_tokens=None):
+        """Extension used by T-sharding (dist.py): the eval forward on a window of a longer video with an
+        externally selected 0/1 clip ``gate`` (NQ, T) and the window's slice ``pe_tokens`` (T, E) of the whole
+        video's position encoding.  Same return structure as ``forward(..., eval=True)``."""
+        return self._drop_forward_eval(vid, shallow_vid, vid_masks, text, None, text_masks, eval=True, gate=gate,
+                                       pe_tokens=pe_tokens)
+
+    def full_position_encoding(self, T, device):
+        """vid_net.pe for a video of T clips, token-major (T, E)"""
+        if self._engine is None:
+            self._engine = _Engine(self._config())
+        return self._position_encoding(T, device)
+
     def _drop_forward_eval(self, vid, shallow_vid, vid_masks, text, text_cls, text_masks, text_size=None, mv_data=None,
-                           eval=False):
+                           eval=False, gate=None, pe_tokens=None):
         assert mv_data is None and eval
         assert vid.size(0) == 1, vid.size()                                  # model.py:496
         if not vid.is_cuda:
@@ -429,8 +442,12 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         if not isinstance(text, (tuple, list)):
             text, text_masks = (text,), (text_masks,)
         nq = len(text)
-        cls_c = text_cls.contiguous().float()
-        assert cls_c.shape == (nq, self.D), (cls_c.shape, nq, self.D)
+        if gate is None:
+            cls_c = text_cls.contiguous().float()
+            assert cls_c.shape == (nq, self.D), (cls_c.shape, nq, self.D)
+        else:
+            cls_c = gate.contiguous().float()
+            assert cls_c.shape == (nq, T), (cls_c.shape, nq, T)
         keep = []
         tptr = (ctypes.c_void_p * nq)()
         mptr = (ctypes.c_void_p * nq)()
@@ -442,17 +459,21 @@ class PtTransformerEarlyFusionIterative(nn.Module):
             keep += [t, m]
             tptr[q], mptr[q], tlen[q] = t.data_ptr(), m.data_ptr(), t.size(1)
         if self.vid_net.use_abs_pe:
-            pe = self._position_encoding(T, dev)
+            pe = self._position_encoding(T, dev) if pe_tokens is None else pe_tokens.contiguous().float()
+            assert pe.shape == (T, self.E)
             _lib.check(lib.dcf_model_set_pe(eng.handle, _lib.ptr(pe), T), 'dcf_model_set_pe')
+        else:
+            pe = None
         S = lib.dcf_points_per_query(eng.handle, T)
         logits = torch.empty(nq, S, device=dev, dtype=torch.float32)
         offsets = torch.empty(nq, S, 2, device=dev, dtype=torch.float32)
         masks = torch.empty(nq, S, device=dev, dtype=torch.bool)
-        _lib.check(lib.dcf_forward_eval(eng.handle, _lib.ptr(vid_c), _lib.ptr(sh_c), _lib.ptr(mask_c), T, nq, tptr, mptr, tlen,
-                                        _lib.ptr(cls_c), _lib.ptr(logits), _lib.ptr(offsets), _lib.ptr(masks),
-                                        _lib.current_stream()), 'dcf_forward_eval')
+        fn = lib.dcf_forward_eval if gate is None else lib.dcf_forward_eval_gated
+        _lib.check(fn(eng.handle, _lib.ptr(vid_c), _lib.ptr(sh_c), _lib.ptr(mask_c), T, nq, tptr, mptr, tlen,
+                      _lib.ptr(cls_c), _lib.ptr(logits), _lib.ptr(offsets), _lib.ptr(masks), _lib.current_stream()),
+                   'dcf_forward_eval')
         # keep the borrowed inputs alive until the stream has consumed them
-        self._last_inputs = (vid_c, sh_c, mask_c, cls_c, keep)
+        self._last_inputs = (vid_c, sh_c, mask_c, cls_c, keep, pe)
         self._last_flat = (logits, offsets, masks)
         L = self.vid_net.arch[2]
         sizes = [T >> l for l in range(L)]

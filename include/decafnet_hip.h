@@ -83,6 +83,14 @@ int dcf_forward_eval(dcf_model* m, const float* vid, const float* shallow_vid, c
                      int32_t nq, const float* const* text, const uint8_t* const* text_mask, const int32_t* text_len,
                      const float* text_cls, float* logits_out, float* offsets_out, uint8_t* masks_out, void* stream);
 
+/* Same forward on a WINDOW of a longer video (T-sharding across GPUs): the 0/1 clip gate
+ * (nq, T) fp32 is supplied by the caller, who selected the top-k blocks on the all-gathered sidekick scores
+ * of the whole video; the position encoding set by dcf_model_set_pe must be the window's slice of the
+ * whole video's encoding.  No scoring, no text_cls. */
+int dcf_forward_eval_gated(dcf_model* m, const float* vid, const float* shallow_vid, const uint8_t* vid_mask, int64_t T,
+                           int32_t nq, const float* const* text, const uint8_t* const* text_mask, const int32_t* text_len,
+                           const float* gate, float* logits_out, float* offsets_out, uint8_t* masks_out, void* stream);
+
 /* Debug taps for parity tests: copy an intermediate of the LAST forward chunk into `dst` (device).
  * what: 0 = sidekick scores (nq, T); 1 = gate (B, T); 2 = vid_map output (B*T, E) token-major;
  *       3 = fusion output (B*T, E); 4 = pyramid features (B*S rows [level][b][t], E+32). */

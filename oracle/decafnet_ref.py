@@ -256,8 +256,9 @@ def xattn_fusion(sd: SD, cfg, vid: Tensor, vid_mask: Tensor, text: Tensor, text_
     return _ln(sd, p + '.ln_out', vid), vid_mask
 
 
-def video_transformer(sd: SD, cfg, x: Tensor, mask: Tensor, p: str = 'vid_net'):
-    """VideoTransformer.forward video_net.py:123-164 (eval, stride-1 embedding convs)."""
+def video_transformer(sd: SD, cfg, x: Tensor, mask: Tensor, p: str = 'vid_net', pe_override=None):
+    """VideoTransformer.forward video_net.py:123-164 (eval, stride-1 embedding convs).
+    ``pe_override`` (E, T): a window's slice of a longer video's position encoding (T-sharding tests)."""
     if mask.ndim == 2:
         mask = mask.unsqueeze(1)
     assert cfg.get('stride', 1) == 1, 'only vid_net.stride == 1 is on the hot path'
@@ -268,8 +269,11 @@ def video_transformer(sd: SD, cfg, x: Tensor, mask: Tensor, p: str = 'vid_net'):
         x = F.relu(_ln(sd, f'{p}.embd_norms.{i}', x))
     t = x.size(-1)
     if cfg['use_abs_pe']:
-        pe = position_encoding(cfg['max_seq_len'], cfg['embd_dim'])
-        x = x + resample_pe(pe, t, cfg['max_seq_len']) * mask.to(x.dtype)
+        if pe_override is None:
+            pe = position_encoding(cfg['max_seq_len'], cfg['embd_dim'])
+            x = x + resample_pe(pe, t, cfg['max_seq_len']) * mask.to(x.dtype)
+        else:
+            x = x + pe_override * mask.to(x.dtype)
     for i in range(n_stem):
         x, mask = transformer_encoder(sd, f'{p}.stem.{i}', x, mask, 1, cfg['n_heads'], cfg['mha_win_size'])
     fpn, fpn_masks = tuple(), tuple()
@@ -450,6 +454,30 @@ def forward_eval(sd: SD, cfg, vid: Tensor, shallow_vid: Tensor, vid_masks: Tenso
             inter.append(dict(vid_map=x, fused=fused, fpn=fpn, logits1=l1))
     if return_intermediates:
         return logits_list, offsets_list, masks_list, dict(correl=correl, per_query=inter)
+    return logits_list, offsets_list, masks_list
+
+
+def forward_eval_window(sd: SD, cfg, vid_w: Tensor, shallow_w: Tensor, mask_w: Tensor, text, text_masks, gate_w: Tensor,
+                        pe_w=None):
+    """The eval forward on a window of a longer video with an externally selected gate (NQ, Tw) and the
+    window's position-encoding slice (E, Tw).  Mirrors model.py:543-563 with the gate given."""
+    logits_list, offsets_list, masks_list = [], [], []
+    for b, (txt, txt_mask) in enumerate(zip(text, text_masks)):
+        g = gate_w[b][None, None, :]
+        x = vid_w * g
+        masks = mask_w.clone()
+        if not cfg['msf']:
+            masks = torch.logical_and(gate_w[b][None].bool(), masks)
+        else:
+            x = torch.cat([x, shallow_w], dim=1)
+        m = masks.unsqueeze(1)
+        x, m = masked_conv1d(x, m, sd['vid_map.conv.weight'], sd['vid_map.conv.bias'])
+        fused, fm = xattn_fusion(sd, cfg['fusion'], x, m, txt, txt_mask)
+        fpn, fpn_masks = video_transformer(sd, cfg['vid_net'], fused, fm, pe_override=pe_w)
+        _, l2, off, om = fuse_and_predict(sd, cfg, fpn, fpn_masks)
+        logits_list.append(l2)
+        offsets_list.append(off)
+        masks_list.append(om)
     return logits_list, offsets_list, masks_list
 
 

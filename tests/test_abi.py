@@ -1,0 +1,121 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads and exports every symbol the header declares,
+the ctypes table matches the header, the host module reproduces the reference's parameter ABI, and the
+host-side text encoder / point generator match the reference fixtures.  No GPU, no compute calls."""
+import ctypes
+import os
+import re
+import sys
+
+import pytest
+import torch
+
+from conftest import Golden, ROOT, load_pkg
+
+HEADER = os.path.join(ROOT, 'include', 'decafnet_hip.h')
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(dcf_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_header_symbols_are_exported():
+    pkg = load_pkg()
+    so = pkg.build.build()
+    h = ctypes.CDLL(so)
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(h, s), f'{s} declared in include/decafnet_hip.h but not exported by {so}'
+
+
+def test_ctypes_table_matches_header():
+    pkg = load_pkg()
+    assert sorted(pkg._lib.SIGNATURES) == declared_symbols()
+    src = re.sub(r'/\*.*?\*/', '', open(HEADER).read(), flags=re.S)
+    for name, (_, args) in pkg._lib.SIGNATURES.items():
+        m = re.search(name + r'\s*\((.*?)\)\s*;', src, flags=re.S)
+        assert m, name
+        params = [p for p in m.group(1).split(',') if p.strip() and p.strip() != 'void']
+        assert len(params) == len(args), (name, len(params), len(args))
+
+
+def test_config_struct_layout():
+    pkg = load_pkg()
+    src = open(HEADER).read()
+    body = src[src.index('typedef struct dcf_config {'):src.index('} dcf_config;')]
+    fields = re.findall(r'\b(?:int32_t|float)\s+(\w+)\s*;', body)
+    assert fields == [f[0] for f in pkg._lib.DcfConfig._fields_]
+
+
+@pytest.mark.parametrize('name', ['c1', 'pe', 'nomsf'])
+def test_parameter_abi_matches_reference(name):
+    """state_dict keys and shapes == the reference model's (captured in the fixture)"""
+    pkg = load_pkg()
+    g = Golden(f'e2e_{name}.npz')
+    model = pkg.modeling.create_model(pkg.config.make_opt(**g.js('opt_kwargs')))
+    mine = {k: list(v.shape) for k, v in model.state_dict().items()}
+    assert mine == g.js('shapes')
+    opt = pkg.config.make_opt(**g.js('opt_kwargs'))
+    before = repr(opt)
+    pkg.modeling.create_model(opt)
+    pkg.modeling.create_model(opt)
+    assert repr(opt) == before, 'the constructor must not mutate opt (the reference does, model.py:426-428)'
+
+
+def test_text_encoder_and_points_match_reference():
+    pkg = load_pkg()
+    g = Golden('e2e_c1.npz')
+    meta, kw = g.js('meta'), g.js('opt_kwargs')
+    model = pkg.modeling.create_model(pkg.config.make_opt(**kw)).eval()
+    model.load_state_dict(pkg.synth.make_state_dict(g.js('shapes'), meta['wseed']))
+    inp = pkg.synth.make_inputs(kw['D'], meta['T'], meta['vid_len'], meta['nq'], kw['text_in'], meta['lq'], meta['iseed'])
+    with torch.no_grad():
+        for q, tok in enumerate(inp['tokens']):
+            t, m = model.encode_text(tok[None], torch.ones(1, 1, tok.size(-1), dtype=torch.bool))
+            torch.testing.assert_close(t, g.t(f'q{q}/text'), rtol=1e-5, atol=1e-5)
+            assert torch.equal(m, g.t(f'q{q}/text_mask'))
+    pg = pkg.modeling.PtGenerator(kw['max_seq_len'] * 10, kw['n_levels'], 4, 0.5)
+    pts = pg([meta['T'] >> l for l in range(kw['n_levels'])])
+    for l, p in enumerate(pts):
+        assert torch.equal(p, g.t(f'points/l{l}'))
+
+
+def test_unsupported_switches_fail_loudly():
+    pkg = load_pkg()
+    kw = Golden('e2e_nomsf.npz').js('opt_kwargs')
+    opt = pkg.config.make_opt(**kw)
+    opt.model['scat'] = True
+    with pytest.raises(NotImplementedError):
+        pkg.modeling.create_model(opt)
+    opt = pkg.config.make_opt(**kw)
+    opt.model['name'] = 'default'
+    with pytest.raises(NotImplementedError):
+        pkg.modeling.create_model(opt)
+    model = pkg.modeling.create_model(pkg.config.make_opt(**kw))
+    with pytest.raises(NotImplementedError):
+        model(torch.zeros(1, 64, 128), torch.zeros(1, 64, 128), torch.ones(1, 128, dtype=torch.bool), (), torch.zeros(0, 64), ())
+    with pytest.raises(RuntimeError, match='GPU'):   # CPU tensors: no fallback
+        model(torch.zeros(1, 64, 128), torch.zeros(1, 64, 128), torch.ones(1, 128, dtype=torch.bool), (), torch.zeros(0, 64), (), eval=True)
+
+
+def test_product_never_imports_the_oracle():
+    pk = os.path.join(ROOT, 'cvpr2025-decafnet_amd')
+    for dirpath, _, files in os.walk(pk):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in txt.replace('nms_oracle', 'oracle') or f == 'README', (f, 'mentions oracle')
+    for f in ('nms_1d_cpu_vg/__init__.py',):
+        assert 'oracle' not in open(os.path.join(ROOT, f)).read()
+
+
+def test_padded_length_rule():
+    pkg = load_pkg()
+    ev = pkg.evaluator
+    assert ev.min_chunk_size(8, 9) == 1024 and ev.min_chunk_size(6, 5) == 128
+    assert ev.padded_length(1000, 2304, 8, 9) == 2304
+    assert ev.padded_length(16000, 2304, 8, 9) == 16384
+    assert ev.padded_length(16384, 2304, 8, 9) == 16384
+    assert ev.padded_length(65530, 2304, 8, 9) == 65536
