@@ -23,6 +23,10 @@ __device__ __forceinline__ float head_sum(float v) {
   else return group_sum<LPH>(v);
 }
 
+// exp(x) for x <= 0 (softmax after max subtraction) as one v_exp_f32: exp2(x * log2(e)).  Relative error
+// ~ (1 + |x|) * 2^-23; arguments below -126/log2(e) flush to 0 exactly like the tail of expf would round.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+
 __device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) {
   return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
 }
@@ -98,15 +102,20 @@ __global__ __launch_bounds__(256) void k_xattn_valu(XAttnArgs p) {
 //   as 64-byte pieces), O goes registers -> global as float4 (4 consecutive channels per lane).
 // The k index of each 16-wide chunk is permuted (lane group g owns d = 16c + 4g + j for step j) for
 // both operands alike, so one ds_read_b128 / global_load_dwordx4 feeds 4 MFMAs.
-template <int D16, int NKT>
+template <int D16, int NKT, int REM, int QT>
 __global__ __launch_bounds__(256) void k_xattn_mfma(XAttnArgs p) {
+  // NKT full 16-key MFMA tiles + REM (0..2) trailing keys on the vector ALU: Lk = 33 (32 words + the
+  // background token) would otherwise pay for 48 keys.  Each wavefront owns QT = 2 tiles of 16 clip rows so
+  // that every K / V fragment read from LDS feeds two MFMAs (QT = 1 for head dims >= 128: registers).
   constexpr int D = 16 * D16;          // head dim
   constexpr int PITCH = D + 4;         // LDS row pitch in floats
-  constexpr int LKP = 16 * NKT;        // padded key count
+  constexpr int LKP = 16 * NKT + REM;  // staged key rows
   extern __shared__ float smem[];
   float* Ks = smem;                    // [LKP][PITCH], pre-scaled by d^-1/4
-  float* Vs = smem + LKP * PITCH;      // [LKP][PITCH]
-  float* Ms = Vs + LKP * PITCH;        // [LKP] additive key mask (0 / -inf)
+  constexpr int VP = 16 * NKT + 4;     // pitch of the transposed V image (4*odd: conflict-free b128 reads)
+  float* Vt = smem + LKP * PITCH;      // [D][VP]   V^T of the NKT full tiles: Vt[chan][key]
+  float* Vr = Vt + D * VP;             // [REM][D]  trailing keys, row-major
+  float* Ms = Vr + (REM > 0 ? REM : 1) * D;  // [LKP] additive key mask (0 / -inf)
   const int C = p.C, Lk = p.Lk;
   const int head = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -122,69 +131,138 @@ __global__ __launch_bounds__(256) void k_xattn_mfma(XAttnArgs p) {
       vv = *reinterpret_cast<const f32x4*>(p.V + off);
     }
     *reinterpret_cast<f32x4*>(Ks + key * PITCH + c4 * 4) = kv;
-    *reinterpret_cast<f32x4*>(Vs + key * PITCH + c4 * 4) = vv;
+    if (key < 16 * NKT) {
+      Vt[(c4 * 4 + 0) * VP + key] = vv.x; Vt[(c4 * 4 + 1) * VP + key] = vv.y;
+      Vt[(c4 * 4 + 2) * VP + key] = vv.z; Vt[(c4 * 4 + 3) * VP + key] = vv.w;
+    } else {
+      *reinterpret_cast<f32x4*>(Vr + (key - 16 * NKT) * D + c4 * 4) = vv;
+    }
   }
   for (int i = tid; i < LKP; i += 256) Ms[i] = (i < Lk && p.kvmask[(size_t)b * Lk + i]) ? 0.f : -INFINITY;
   __syncthreads();
 
-  const int n_groups = (p.T + 63) / 64;
-  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-    const int t = grp * 64 + wave * 16 + r;
-    const bool live = t < p.T;
-    const int64_t row = (int64_t)b * p.T + (live ? t : p.T - 1);
-    // ---- Q fragment: q[c] = Q[row][head*D + 16c + 4g .. +3], scaled
-    f32x4 q[D16];
-    const float* qp = p.Q + row * C + (size_t)head * D + 4 * g;
+  constexpr int ROWS = 64 * QT;        // clip rows per workgroup iteration
+  const int n_groups = (p.T + ROWS - 1) / ROWS;
+  // Q fragments are fetched one row group ahead: the next group's 1 KiB wave loads stay in flight while
+  // the current group is multiplied (a wave has nothing else to overlap its own HBM latency with).
+  f32x4 qn[QT][D16];
+  auto fetch_q = [&](int grp) __attribute__((always_inline)) {
 #pragma unroll
-    for (int c = 0; c < D16; ++c) q[c] = *reinterpret_cast<const f32x4*>(qp + 16 * c) * scale;
+    for (int t = 0; t < QT; ++t) {
+      int tt = grp * ROWS + (wave * QT + t) * 16 + r;
+      tt = tt < p.T ? tt : p.T - 1;
+      const float* qp = p.Q + ((int64_t)b * p.T + tt) * C + (size_t)head * D + 4 * g;
+#pragma unroll
+      for (int c = 0; c < D16; ++c) qn[t][c] = *reinterpret_cast<const f32x4*>(qp + 16 * c);
+    }
+  };
+  if ((int)blockIdx.x < n_groups) fetch_q(blockIdx.x);
+  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    // ---- Q fragments: q[t][c] = Q[row_t][head*D + 16c + 4g .. +3], scaled
+    f32x4 q[QT][D16];
+    bool live[QT];
+    int64_t row[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      const int tt = grp * ROWS + (wave * QT + t) * 16 + r;
+      live[t] = tt < p.T;
+      row[t] = (int64_t)b * p.T + (live[t] ? tt : p.T - 1);
+#pragma unroll
+      for (int c = 0; c < D16; ++c) q[t][c] = qn[t][c] * scale;
+    }
+    if (grp + (int)gridDim.x < n_groups) fetch_q(grp + gridDim.x);
     // ---- S^T tiles
-    f32x4 s[NKT];
+    f32x4 s[QT][NKT > 0 ? NKT : 1];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < QT; ++t) s[t][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < D16; ++c) {
         const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + (16 * kt + r) * PITCH + 16 * c + 4 * g);
-        s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, q[c].x, s[kt], 0, 0, 0);
-        s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, q[c].y, s[kt], 0, 0, 0);
-        s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, q[c].z, s[kt], 0, 0, 0);
-        s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, q[c].w, s[kt], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          s[t][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, q[t][c].x, s[t][kt], 0, 0, 0);
+          s[t][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, q[t][c].y, s[t][kt], 0, 0, 0);
+          s[t][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, q[t][c].z, s[t][kt], 0, 0, 0);
+          s[t][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, q[t][c].w, s[t][kt], 0, 0, 0);
+        }
       }
     }
-    // ---- softmax over keys (lane holds keys 16kt + 4g + j of its row)
-    float mx = -INFINITY;
+    // ---- trailing keys: full dot product per row, replicated over the 4 lane groups
+    float sr[QT][REM > 0 ? REM : 1];
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + 16 * kt + 4 * g);
-      s[kt] += mk;
-      mx = fmaxf(fmaxf(mx, fmaxf(s[kt].x, s[kt].y)), fmaxf(s[kt].z, s[kt].w));
+    for (int j = 0; j < REM; ++j) {
+      float part[QT];
+#pragma unroll
+      for (int t = 0; t < QT; ++t) part[t] = 0.f;
+#pragma unroll
+      for (int c = 0; c < D16; ++c) {
+        const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + (16 * NKT + j) * PITCH + 16 * c + 4 * g);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) part[t] += dot4(q[t][c], kf);
+      }
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+        sr[t][j] = xor32_sum(xor16_sum(part[t])) + Ms[16 * NKT + j];
+      }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      s[kt].x = expf(s[kt].x - mx); s[kt].y = expf(s[kt].y - mx);
-      s[kt].z = expf(s[kt].z - mx); s[kt].w = expf(s[kt].w - mx);
-      sum += (s[kt].x + s[kt].y) + (s[kt].z + s[kt].w);
-    }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;          // all keys masked: exp(nan) -> NaN row, as the reference
-    // ---- O^T tiles and store
-    float* op = p.O + row * C + (size_t)head * D + 4 * g;
-#pragma unroll
-    for (int ct = 0; ct < D16; ++ct) {
-      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < QT; ++t) {
+      // ---- softmax over keys (lane holds keys 16kt + 4g + j of its row, plus the replicated trailing keys)
+      float mx = -INFINITY;
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt) {
-        const float* vp = Vs + (16 * kt + 4 * g) * PITCH + 16 * ct + r;
-        o = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[0], s[kt].x, o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[PITCH], s[kt].y, o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[2 * PITCH], s[kt].z, o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[3 * PITCH], s[kt].w, o, 0, 0, 0);
+        const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + 16 * kt + 4 * g);
+        s[t][kt] += mk;
+        mx = fmaxf(fmaxf(mx, fmaxf(s[t][kt].x, s[t][kt].y)), fmaxf(s[t][kt].z, s[t][kt].w));
       }
-      if (live) *reinterpret_cast<f32x4*>(op + 16 * ct) = o * inv;
+      if (NKT > 0) mx = xor32_max(xor16_max(mx));
+#pragma unroll
+      for (int j = 0; j < REM; ++j) mx = fmaxf(mx, sr[t][j]);
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        s[t][kt].x = fast_exp(s[t][kt].x - mx); s[t][kt].y = fast_exp(s[t][kt].y - mx);
+        s[t][kt].z = fast_exp(s[t][kt].z - mx); s[t][kt].w = fast_exp(s[t][kt].w - mx);
+        sum += (s[t][kt].x + s[t][kt].y) + (s[t][kt].z + s[t][kt].w);
+      }
+      if (NKT > 0) sum = xor32_sum(xor16_sum(sum));
+#pragma unroll
+      for (int j = 0; j < REM; ++j) { sr[t][j] = fast_exp(sr[t][j] - mx); sum += sr[t][j]; }
+      const float inv = 1.0f / sum;        // all keys masked: NaN row, as the reference
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) s[t][kt] *= inv;
+#pragma unroll
+      for (int j = 0; j < REM; ++j) sr[t][j] *= inv;
+    }
+    // ---- O^T tiles and store
+#pragma unroll
+    for (int ct = 0; ct < D16; ++ct) {
+      f32x4 o[QT];
+#pragma unroll
+      for (int t = 0; t < QT; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        const f32x4 vf = *reinterpret_cast<const f32x4*>(Vt + (16 * ct + r) * VP + 16 * kt + 4 * g);
+        const float v0 = vf.x, v1 = vf.y, v2 = vf.z, v3 = vf.w;
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v0, s[t][kt].x, o[t], 0, 0, 0);
+          o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v1, s[t][kt].y, o[t], 0, 0, 0);
+          o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v2, s[t][kt].z, o[t], 0, 0, 0);
+          o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v3, s[t][kt].w, o[t], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < REM; ++j) {
+        const f32x4 vr = *reinterpret_cast<const f32x4*>(Vr + j * D + 16 * ct + 4 * g);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) o[t] += sr[t][j] * vr;
+      }
+#pragma unroll
+      for (int t = 0; t < QT; ++t)
+        if (live[t]) *reinterpret_cast<f32x4*>(p.O + row[t] * C + (size_t)head * D + 4 * g + 16 * ct) = o[t];
     }
   }
 }
@@ -278,21 +356,36 @@ __global__ __launch_bounds__(256) void k_local_attn(LocalAttnArgs p) {
 
 template <int D16>
 static int launch_xattn_mfma(const XAttnArgs& a, hipStream_t st) {
-  const int nkt = (a.Lk + 15) / 16;
-  const int n_groups = (a.T + 63) / 64;
+  // keys = 16 * nkt + rem: up to 2 trailing keys go to the vector ALU instead of a mostly empty MFMA tile
+  int nkt = a.Lk / 16, rem = a.Lk % 16;
+  if (rem > 2) { nkt += 1; rem = 0; }
+  const int n_groups = (a.T + (D16 <= 4 ? 127 : 63)) / (D16 <= 4 ? 128 : 64);
   // enough workgroups to fill the chip, few enough that K/V staging (2*Lk*d floats) is amortised
   int gx = n_groups;
   const int per = a.heads * a.B;
-  const int cap = (2048 + per - 1) / per;
+  const int cap = (1536 + per - 1) / per;
   if (gx > cap) gx = cap;
   dim3 grid(gx, a.heads, a.B);
-  const size_t lds = (size_t)(2 * 16 * nkt * (16 * D16 + 4) + 16 * nkt) * sizeof(float);
-  switch (nkt) {
-    case 1: hipLaunchKernelGGL((k_xattn_mfma<D16, 1>), grid, dim3(256), lds, st, a); break;
-    case 2: hipLaunchKernelGGL((k_xattn_mfma<D16, 2>), grid, dim3(256), lds, st, a); break;
-    case 3: hipLaunchKernelGGL((k_xattn_mfma<D16, 3>), grid, dim3(256), lds, st, a); break;
-    default: hipLaunchKernelGGL((k_xattn_mfma<D16, 4>), grid, dim3(256), lds, st, a); break;
+  constexpr int D = 16 * D16;
+  constexpr int QT = D16 <= 4 ? 2 : 1;
+  const size_t lds = (size_t)((16 * nkt + rem) * (D + 4) + D * (16 * nkt + 4) + (rem > 0 ? rem : 1) * D + 16 * nkt + rem) * sizeof(float);
+#define XL(NKT_, REM_) hipLaunchKernelGGL((k_xattn_mfma<D16, NKT_, REM_, QT>), grid, dim3(256), lds, st, a)
+  switch (nkt * 4 + rem) {
+    case 0 * 4 + 1: XL(0, 1); break;
+    case 0 * 4 + 2: XL(0, 2); break;
+    case 1 * 4 + 0: XL(1, 0); break;
+    case 1 * 4 + 1: XL(1, 1); break;
+    case 1 * 4 + 2: XL(1, 2); break;
+    case 2 * 4 + 0: XL(2, 0); break;
+    case 2 * 4 + 1: XL(2, 1); break;
+    case 2 * 4 + 2: XL(2, 2); break;
+    case 3 * 4 + 0: XL(3, 0); break;
+    case 3 * 4 + 1: XL(3, 1); break;
+    case 3 * 4 + 2: XL(3, 2); break;
+    case 4 * 4 + 0: XL(4, 0); break;
+    default: DCF_CHECK(false, "xattn: Lk=%d not supported by the MFMA kernel", a.Lk);
   }
+#undef XL
   DCF_HIP(hipGetLastError());
   return 0;
 }
@@ -304,7 +397,7 @@ int launch_xattn(const XAttnArgs& a, hipStream_t st) {
   const double rows = (double)a.B * a.T;
   ProfScope prof("xattn_core", st, 4.0 * rows * a.C * a.Lk, 4.0 * (2.0 * rows * a.C + 2.0 * a.B * a.Lk * a.C));
   const int d = a.C / a.heads;
-  if (a.Lk <= 64 && d % 16 == 0 && d <= 256 && (d & (d - 1)) == 0) {
+  if (a.Lk <= 64 && d % 16 == 0 && d <= 256 && (d & (d - 1)) == 0) {   // Lk in 65..66 would need nkt=4,rem>0: VALU path
     switch (d / 16) {
       case 1: return launch_xattn_mfma<1>(a, st);
       case 2: return launch_xattn_mfma<2>(a, st);

@@ -54,6 +54,28 @@ __device__ __forceinline__ float wave_max(float v) {
   v = fmaxf(v, dpp_self<DPP_BCAST31, 0xC>(v));
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+// xor-16 / xor-32 butterflies across the four 16-lane rows of a wave with the gfx950 lane-swap
+// instructions (VALU speed; the ds_bpermute behind __shfl_xor costs an LDS round trip):
+//   v_permlane16_swap a, b : swaps the odd rows of a with the even rows of b
+//   v_permlane32_swap a, b : swaps the upper half of a with the lower half of b
+// With a == b == v the two results hold {r0,r0,r2,r2}/{r1,r1,r3,r3} resp. {lo,lo}/{hi,hi}.
+__device__ __forceinline__ float xor16_sum(float v) {
+  auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+  auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+}
+__device__ __forceinline__ float xor16_max(float v) {
+  auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(t[0]), __uint_as_float(t[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+  auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(t[0]), __uint_as_float(t[1]));
+}
+
 // sum within aligned groups of G lanes (G power of two <= 64); every lane of the group gets the sum
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
@@ -62,7 +84,7 @@ __device__ __forceinline__ float group_sum(float v) {
   if constexpr (G >= 4) v += dpp_zero<DPP_XOR2>(v);
   if constexpr (G >= 8) v += dpp_zero<DPP_HALF_MIRROR>(v);
   if constexpr (G >= 16) v += dpp_zero<DPP_MIRROR>(v);
-  if constexpr (G >= 32) v += __shfl_xor(v, 16, 64);
+  if constexpr (G >= 32) v = xor16_sum(v);
   return v;
 }
 
