@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: bf16 dense MFMA peak
 PEAK_HBM_GBS = 8000.0            # HBM3E spec
 
 
@@ -145,16 +146,29 @@ def main():
                       'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['ms'] > 0 else 0.0,
                       'alg_GBps': (v['bytes'] / (v['ms'] * 1e-3) / 1e9) if v['ms'] > 0 else 0.0}
                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}
-        gk = [k for k in prof if k.startswith('gemm_f32')]
+        # dominant kernel = the dense-conv GEMM.  Default arithmetic: fp32-accurate bf16x6 operand split on
+        # v_mfma_f32_32x32x16_bf16 (6 bf16 MFMA products per fp32 MAC) => fp32-equivalent peak = 2500 / 6 TFLOP/s;
+        # with DCF_GEMM_MODE=fp32 the native fp32 MFMA (157.3 TFLOP/s) is used instead.
+        fam = 'gemm_bf16x6' if any(k.startswith('gemm_bf16x6') for k in prof) else \
+              ('gemm_bf16x3' if any(k.startswith('gemm_bf16x3') for k in prof) else 'gemm_f32')
+        gk = [k for k in prof if k.startswith(fam)]
         d = {f: sum(prof[k][f] for k in gk) for f in ('ms', 'flops', 'bytes', 'count')}
-        dom = 'gemm_f32_kernel<*> (all %d tile/operand instantiations, %.0f%% of the step)' % (len(gk), 100 * d['ms'] / tot_ms)
+        terms = {'gemm_bf16x6': 6, 'gemm_bf16x3': 3, 'gemm_f32': 0}[fam]
+        peak = PEAK_BF16_MFMA_TFLOPS / terms if terms else PEAK_F32_MFMA_TFLOPS
+        ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
         result['roofline'] = {
-            'kernel': dom, 'bound': 'mfma', 'achieved': d['flops'] / (d['ms'] * 1e-3) / 1e12, 'peak': PEAK_F32_MFMA_TFLOPS,
-            'unit': 'TFLOP/s', 'frac': d['flops'] / (d['ms'] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+            'kernel': '%s_kernel<*> (all %d tile/operand instantiations, %.0f%% of the step)' % (
+                'gemm_bf16s' if terms else 'gemm_f32', len(gk), 100 * d['ms'] / tot_ms),
+            'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
             'launches': d['count'], 'avg_launch_us': 1e3 * d['ms'] / d['count'],
             'alg_flops_per_launch': d['flops'] / d['count'],
-            'note': 'HIP events around every launch of this kernel, same K steps re-run right after the timed region',
+            'peak_note': ('bf16 dense MFMA peak 2500 TFLOP/s / %d bf16 products per fp32 multiply-add (fp32-accurate operand split)' % terms)
+                         if terms else 'native fp32 MFMA dense peak',
+            'frac_of_native_f32_mfma_peak': ach / PEAK_F32_MFMA_TFLOPS,
+            'note': 'HIP events around every launch of this kernel, same K steps re-run right after the timed region; '
+                    'achieved = algorithmic 2*M*N*K flops / event time',
         }
+        result['config']['gemm_mode'] = {6: 'bf16x6 split MFMA (fp32 accurate)', 3: 'bf16x3 split MFMA', 0: 'native fp32 MFMA'}[terms]
         xa = prof.get('xattn_core')
         if xa:
             result['xattn_in_forward'] = {'bound': 'hbm', 'achieved': xa['bytes'] / (xa['ms'] * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS,

@@ -21,7 +21,7 @@ vp = ctypes.c_void_p
 class DcfConfig(ctypes.Structure):
     _fields_ = [(n, i32) for n in ('D', 'E', 'TE', 'vid_heads', 'fusion_heads', 'fusion_layers', 'n_embd_convs',
                                    'n_stem', 'n_levels', 'win', 'head_layers', 'sn')] + \
-               [('sratio', f32)] + [(n, i32) for n in ('msf', 'norm', 'use_abs_pe', 'max_batch')]
+               [('sratio', f32)] + [(n, i32) for n in ('msf', 'norm', 'use_abs_pe', 'max_batch', 'gemm_mode')]
 
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
@@ -46,6 +46,7 @@ SIGNATURES = {
     'dcf_softnms_1d': (i32, [c_f32p, c_f32p, c_i32p, i32, i32, i32, f32, f32, f32, i32, i32, c_f32p, c_i64p, c_i32p, vp]),
     'dcf_segment_voting': (i32, [c_f32p, i32, c_i32p, i32, i32, c_f32p, c_f32p, c_i32p, i32, i32, f32, i32, c_f32p, vp]),
     'dcf_op_linear': (i32, [c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, i32, vp]),
+    'dcf_op_linear_split': (i32, [c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, i32, i32, vp]),
     'dcf_op_linear_cm': (i32, [c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, vp]),
     'dcf_op_conv3': (i32, [c_f32p, c_u8p, c_f32p, c_f32p, i32, i32, i32, i32, vp]),
     'dcf_op_layernorm': (i32, [c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, vp]),

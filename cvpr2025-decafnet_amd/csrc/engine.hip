@@ -14,6 +14,7 @@
 // Nothing here synchronises the host: vid_len, the gate and every mask stay on the device.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -139,6 +140,8 @@ struct dcf_model {
   dcf_config cfg{};
   std::unordered_map<std::string, Bound> bound;
   std::vector<float*> owned;                 // packed weights
+  std::unordered_map<const float*, const unsigned short*> wsplit;   // fp32 weight -> [3][N][K] bf16 planes
+  int gemm_terms = 6;                        // 6 / 3: bf16-split MFMA GEMM; 0: fp32 MFMA
   bool finalized = false;
   const float* pe = nullptr;
   int64_t pe_T = 0;
@@ -178,6 +181,7 @@ namespace dcf {
 static int free_model(dcf_model* m) {
   for (float* p : m->owned) (void)hipFree(p);
   m->owned.clear();
+  m->wsplit.clear();
   for (auto& pl : m->plans) if (pl.d_lt) (void)hipFree(pl.d_lt);
   m->plans.clear();
   if (m->arena) (void)hipFree(m->arena);
@@ -211,6 +215,18 @@ static int pack3(dcf_model* m, const float* src, int d0, int d1, int d2, int p0,
   return 0;
 }
 
+// bf16 planes of a GEMM weight [N][K] (row pitch K); owned by the model
+static int split_weight(dcf_model* m, const float* W, int N, int K, hipStream_t st) {
+  if (m->gemm_terms == 0 || m->wsplit.count(W)) return 0;
+  unsigned short* planes = nullptr;
+  DCF_HIP(hipMalloc(&planes, (size_t)3 * N * K * sizeof(unsigned short)));
+  m->owned.push_back(reinterpret_cast<float*>(planes));
+  if (launch_split_planes(W, planes, N, K, K, st)) return -1;
+  m->wsplit[W] = planes;
+  return 0;
+}
+#define SPLIT(W, N, K) do { if (split_weight(m, (W), (N), (K), st)) return -1; } while (0)
+
 #define GET(name, shape, dst) do { if (get(m, (name), shape, &(dst))) return -1; } while (0)
 #define SH(...) std::initializer_list<int64_t>{__VA_ARGS__}
 
@@ -232,6 +248,8 @@ static int resolve_encoder(dcf_model* m, const std::string& p, int E, hipStream_
   GET(p + ".ffn.fc.weight", SH(4 * E, E), w.fc_w); GET(p + ".ffn.fc.bias", SH(4 * E), w.fc_b);
   GET(p + ".ffn.proj.weight", SH(E, 4 * E), w.pj_w); GET(p + ".ffn.proj.bias", SH(E), w.pj_b);
   GET(p + ".drop_path_ffn.scale", SH(E), w.ls_ffn);
+  SPLIT(w.wq, E, E); SPLIT(w.wk, E, E); SPLIT(w.wv, E, E); SPLIT(w.wp, E, E);
+  SPLIT(w.fc_w, 4 * E, E); SPLIT(w.pj_w, E, 4 * E);
   return 0;
 }
 
@@ -243,6 +261,7 @@ static int resolve_head(dcf_model* m, const std::string& p, const std::string& o
     GET(p + ".convs." + s + ".conv.weight", SH(C, C, 3), t);
     const float* pk;
     if (pack3(m, t, C, C, 3, 0, 2, 1, st, &pk)) return -1;      // (N, Cin, 3) -> [N][3][Cin]
+    SPLIT(pk, C, 3 * C);
     h.conv.push_back(pk);
     const float *lw, *lb;
     GET(p + ".norms." + s + ".weight", SH(C), lw); GET(p + ".norms." + s + ".bias", SH(C), lb);
@@ -260,6 +279,12 @@ static int finalize(dcf_model* m, hipStream_t st) {
   const int Din = c.msf ? 2 * D : D;
   for (float* p : m->owned) (void)hipFree(p);
   m->owned.clear();
+  m->wsplit.clear();
+  {
+    const int gm = c.gemm_mode;
+    m->gemm_terms = gm == 1 ? 0 : (gm == 3 ? 3 : 6);
+    if (const char* ev = getenv("DCF_GEMM_MODE")) m->gemm_terms = !strcmp(ev, "fp32") ? 0 : (!strcmp(ev, "x3") ? 3 : 6);
+  }
   m->dec.clear(); m->stem.clear(); m->branch.clear();
   m->embd_conv.clear(); m->embd_ln_w.clear(); m->embd_ln_b.clear();
   m->cls1 = HeadW(); m->cls2 = HeadW(); m->reg = HeadW();
@@ -282,15 +307,19 @@ static int finalize(dcf_model* m, hipStream_t st) {
     GET(p + ".ffn.fc.weight", SH(4 * E, E), w.fc_w); GET(p + ".ffn.fc.bias", SH(4 * E), w.fc_b);
     GET(p + ".ffn.proj.weight", SH(E, 4 * E), w.pj_w); GET(p + ".ffn.proj.bias", SH(E), w.pj_b);
     GET(p + ".drop_path_ffn.scale", SH(E), w.ls_ffn);
+    SPLIT(w.wq, E, E); SPLIT(w.wk, E, TE); SPLIT(w.wv, E, TE); SPLIT(w.wp, 2 * E, E);
+    SPLIT(w.fc_w, 4 * E, E); SPLIT(w.pj_w, E, 4 * E);
     m->dec.push_back(w);
   }
   GET("fusion.ln_out.weight", SH(E), m->fus_out_w); GET("fusion.ln_out.bias", SH(E), m->fus_out_b);
   GET("vid_net.embd_fc.conv.weight", SH(E, E), m->embd_fc_w); GET("vid_net.embd_fc.conv.bias", SH(E), m->embd_fc_b);
+  SPLIT(m->embd_fc_w, E, E);
   for (int i = 0; i < c.n_embd_convs; ++i) {
     const std::string s = std::to_string(i);
     GET("vid_net.embd_convs." + s + ".conv.weight", SH(E, E, 3), t);
     const float* pk;
     if (pack3(m, t, E, E, 3, 0, 2, 1, st, &pk)) return -1;
+    SPLIT(pk, E, 3 * E);
     m->embd_conv.push_back(pk);
     const float *lw, *lb;
     GET("vid_net.embd_norms." + s + ".weight", SH(E), lw); GET("vid_net.embd_norms." + s + ".bias", SH(E), lb);
@@ -422,6 +451,17 @@ static GemmArgs gemm(const float* A, int64_t lda, const float* W, const float* b
 
 #define TRY(x) do { if ((x) != 0) return -1; } while (0)
 
+// dense GEMM dispatch: bf16-split MFMA when the weight has split planes, fp32 MFMA otherwise
+static int run_gemm(dcf_model* m, GemmArgs* g, int count, GemmAMode mode, hipStream_t st) {
+  bool split = m->gemm_terms != 0 && mode != A_CHANMAJOR;
+  for (int i = 0; i < count && split; ++i) {
+    auto it = m->wsplit.find(g[i].W);
+    if (it == m->wsplit.end() || (g[i].ldw != 0 && g[i].ldw != g[i].K)) split = false;
+    else g[i].Ws = it->second;
+  }
+  return split ? launch_gemm_split(g, count, mode, m->gemm_terms, st) : launch_gemm(g, count, mode, st);
+}
+
 // TransformerEncoder (vid_net) at one level.  Xin: [B*T_in][ldx]; output rows [B*T_out] at Xout (ld ldo).
 static int run_encoder(dcf_model* m, const EncW& w, Buffers& b, const float* Xin, int64_t ldx, const uint8_t* mask_in,
                        const uint8_t* mask_out, int B, int T_in, int stride, float* Xout, int64_t ldo, hipStream_t st) {
@@ -436,23 +476,23 @@ static int run_encoder(dcf_model* m, const EncW& w, Buffers& b, const float* Xin
   TRY(launch_enc_pre(ep, stride, st));
   GemmArgs g3[3] = {gemm(b.R[0], E, w.wq, w.bq, b.R[4], E, rows, E, E), gemm(b.R[1], E, w.wk, w.bk, b.R[5], E, rows, E, E),
                     gemm(b.R[2], E, w.wv, w.bv, b.R[6], E, rows, E, E)};
-  TRY(launch_gemm(g3, 3, A_ROWS, st));
+  TRY(run_gemm(m, g3, 3, A_ROWS, st));
   LocalAttnArgs la{b.R[4], b.R[5], b.R[6], mask_out, b.R[0], B, To, E, c.vid_heads, c.win};
   TRY(launch_local_attn(la, st));
   // x' = skip * mask + ls_attn * (proj(ctx) + b)                       (blocks.py:586)
   GemmArgs gp = gemm(b.R[0], E, w.wp, w.bp, b.R[1], E, rows, E, E);
   gp.flags = G_RES | G_RES_MASK; gp.rowmask = mask_out; gp.ls = w.ls_attn;
   if (stride == 2) { gp.R = b.R[3]; gp.ldr = E; } else { gp.R = Xin; gp.ldr = ldx; }
-  TRY(launch_gemm(&gp, 1, A_ROWS, st));
+  TRY(run_gemm(m, &gp, 1, A_ROWS, st));
   LnArgs ln{}; ln.X = b.R[1]; ln.ldx = E; ln.Y = b.R[2]; ln.ldy = E; ln.w = w.ln_ffn_w; ln.b = w.ln_ffn_b; ln.rows = rows; ln.C = E;
   TRY(launch_ln(ln, st));
   GemmArgs gf = gemm(b.R[2], E, w.fc_w, w.fc_b, b.HID, 4 * E, rows, 4 * E, E);
   gf.flags = G_GELU;
-  TRY(launch_gemm(&gf, 1, A_ROWS, st));
+  TRY(run_gemm(m, &gf, 1, A_ROWS, st));
   // out = x' + ls_ffn * ((ffn) * mask)                                  (blocks.py:589-590)
   GemmArgs go = gemm(b.HID, 4 * E, w.pj_w, w.pj_b, Xout, ldo, rows, E, 4 * E);
   go.flags = G_RES | G_OUT_MASK; go.rowmask = mask_out; go.ls = w.ls_ffn; go.R = b.R[1]; go.ldr = E;
-  TRY(launch_gemm(&go, 1, A_ROWS, st));
+  TRY(run_gemm(m, &go, 1, A_ROWS, st));
   return 0;
 }
 
@@ -466,7 +506,7 @@ static int run_head(dcf_model* m, const HeadW& h, Buffers& b, const Plan& pl, in
   for (size_t i = 0; i < h.conv.size(); ++i) {
     GemmArgs g = gemm(in, ldin, h.conv[i], nullptr, b.HA, Cin, rowsAll, Cin, 3 * Cin);
     g.cin = Cin; g.nbr = b.nbr_all;
-    TRY(launch_gemm(&g, 1, A_ROWS_TAP3, st));
+    TRY(run_gemm(m, &g, 1, A_ROWS_TAP3, st));
     LnArgs ln{}; ln.X = b.HA; ln.ldx = Cin; ln.Y = b.HB; ln.ldy = Cin; ln.w = h.ln_w[i]; ln.b = h.ln_b[i];
     ln.rows = rowsAll; ln.C = Cin; ln.relu = 1;
     TRY(launch_ln(ln, st));
@@ -530,11 +570,11 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
   {
     GemmArgs g = gemm(vid, T0, m->vid_map_w, nullptr, b.P1, E, T0, E, D);
     g.ldw = Din;
-    TRY(launch_gemm(&g, 1, A_CHANMAJOR, st));
+    TRY(run_gemm(m, &g, 1, A_CHANMAJOR, st));
     if (c.msf) {
       GemmArgs g2 = gemm(shallow, T0, m->vid_map_w + D, nullptr, b.P2, E, T0, E, D);
       g2.ldw = Din;
-      TRY(launch_gemm(&g2, 1, A_CHANMAJOR, st));
+      TRY(run_gemm(m, &g2, 1, A_CHANMAJOR, st));
     }
   }
 
@@ -584,22 +624,22 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
       DecPreArgs dp{b.X, E, mask0, w.ln_q_w, w.ln_q_b, w.dw, w.qn_w, w.qn_b, b.R[0], b.R[1], B, T0, E};
       TRY(launch_dec_pre(dp, st));
       GemmArgs gq = gemm(b.R[0], E, w.wq, w.bq, b.R[2], E, rows0, E, E);
-      TRY(launch_gemm(&gq, 1, A_ROWS, st));
+      TRY(run_gemm(m, &gq, 1, A_ROWS, st));
       TextLnArgs tl{dm, b.kvn, b.kvmask, w.ln_kv_w, w.ln_kv_b, Lk, c.TE};
       TRY(launch_text_ln(tl, B, st));
       GemmArgs gkv[2] = {gemm(b.kvn, c.TE, w.wk, w.bk, b.Kt, E, B * Lk, E, c.TE), gemm(b.kvn, c.TE, w.wv, w.bv, b.Vt, E, B * Lk, E, c.TE)};
-      TRY(launch_gemm(gkv, 2, A_ROWS, st));
+      TRY(run_gemm(m, gkv, 2, A_ROWS, st));
       XAttnArgs xa{b.R[2], b.Kt, b.Vt, b.kvmask, b.R[0], B, T0, Lk, E, c.fusion_heads};
       TRY(launch_xattn(xa, st));
       GemmArgs gh = gemm(b.R[0], E, w.wp, w.bp, b.H2, 2 * E, rows0, 2 * E, E);
-      TRY(launch_gemm(&gh, 1, A_ROWS, st));
+      TRY(run_gemm(m, &gh, 1, A_ROWS, st));
       TRY(launch_dec_mid(b.R[1], b.H2, w.ln_ffn_w, w.ln_ffn_b, b.R[2], b.R[0], rows0, E, st));
       GemmArgs gf = gemm(b.R[0], E, w.fc_w, w.fc_b, b.HID, 4 * E, rows0, 4 * E, E);
       gf.flags = G_GELU;
-      TRY(launch_gemm(&gf, 1, A_ROWS, st));
+      TRY(run_gemm(m, &gf, 1, A_ROWS, st));
       GemmArgs go = gemm(b.HID, 4 * E, w.pj_w, w.pj_b, b.X, E, rows0, E, 4 * E);
       go.flags = G_RES | G_OUT_MASK; go.rowmask = mask0; go.ls = w.ls_ffn; go.R = b.R[2]; go.ldr = E;
-      TRY(launch_gemm(&go, 1, A_ROWS, st));
+      TRY(run_gemm(m, &go, 1, A_ROWS, st));
     }
     {
       LnArgs ln{}; ln.X = b.X; ln.ldx = E; ln.Y = b.R[0]; ln.ldy = E; ln.w = m->fus_out_w; ln.b = m->fus_out_b; ln.rows = rows0; ln.C = E;
@@ -611,11 +651,11 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
     {
       GemmArgs ge = gemm(b.R[0], E, m->embd_fc_w, m->embd_fc_b, b.X, E, rows0, E, E);
       ge.flags = G_AMASK; ge.rowmask = mask0;
-      TRY(launch_gemm(&ge, 1, A_ROWS, st));
+      TRY(run_gemm(m, &ge, 1, A_ROWS, st));
       for (int i = 0; i < c.n_embd_convs; ++i) {
         GemmArgs g = gemm(b.X, E, m->embd_conv[i], nullptr, b.R[0], E, rows0, E, 3 * E);
         g.cin = E; g.nbr = b.nbr_all;
-        TRY(launch_gemm(&g, 1, A_ROWS_TAP3, st));
+        TRY(run_gemm(m, &g, 1, A_ROWS_TAP3, st));
         LnArgs ln{}; ln.X = b.R[0]; ln.ldx = E; ln.Y = b.X; ln.ldy = E; ln.w = m->embd_ln_w[i]; ln.b = m->embd_ln_b[i];
         ln.rows = rows0; ln.C = E; ln.relu = 1;
         if (c.use_abs_pe && i == c.n_embd_convs - 1) { ln.pe = m->pe; ln.mask = mask0; ln.T = T0; }
@@ -865,6 +905,22 @@ int dcf_op_linear(const float* A, const float* W, const float* bias, float* C, i
   dcf::GemmArgs g = dcf::gemm(A, K, W, bias, C, N, M, N, K);
   g.flags = act == 1 ? dcf::G_GELU : act == 2 ? dcf::G_RELU : 0;
   return dcf::launch_gemm(&g, 1, dcf::A_ROWS, (hipStream_t)stream);
+}
+
+int dcf_op_linear_split(const float* A, const float* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K,
+                        int32_t act, int32_t nterms, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  unsigned short* planes = nullptr;
+  DCF_HIP(hipMallocAsync((void**)&planes, (size_t)3 * N * K * sizeof(unsigned short), st));
+  int rc = dcf::launch_split_planes(W, planes, N, K, K, st);
+  if (rc == 0) {
+    dcf::GemmArgs g = dcf::gemm(A, K, W, bias, C, N, M, N, K);
+    g.Ws = planes;
+    g.flags = act == 1 ? dcf::G_GELU : act == 2 ? dcf::G_RELU : 0;
+    rc = dcf::launch_gemm_split(&g, 1, dcf::A_ROWS, nterms, st);
+  }
+  DCF_HIP(hipFreeAsync(planes, st));
+  return rc;
 }
 
 int dcf_op_linear_cm(const float* A_cm, const float* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K,

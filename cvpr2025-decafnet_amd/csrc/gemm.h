@@ -25,6 +25,7 @@ struct GemmArgs {
   int64_t lda;
   const float* W;      // [N][ldw], K contiguous (PyTorch Conv1d weight (N, K, 1); k3 weights are repacked [N][tap][cin])
   int64_t ldw;         // row pitch of W in floats (0 = K)
+  const unsigned short* Ws;  // optional: W split into bf16 planes [3][N][K] (gemm_bf16s.hip); nullptr = fp32 MFMA
   const float* bias;   // [N] or nullptr
   float* C;
   int64_t ldc;
@@ -40,5 +41,9 @@ struct GemmArgs {
 
 // Launch up to 3 independent GEMMs of identical (M, N, K, mode) in one grid (blockIdx.z).
 int launch_gemm(const GemmArgs* g, int count, GemmAMode mode, hipStream_t stream);
+
+// fp32-accurate GEMM on the bf16 matrix cores by operand splitting (gemm_bf16s.hip); nterms = 6 or 3
+int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, hipStream_t stream);
+int launch_split_planes(const float* W, unsigned short* out, int N, int K, int64_t ldw, hipStream_t st);
 
 }  // namespace dcf

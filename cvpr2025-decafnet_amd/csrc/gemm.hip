@@ -15,15 +15,10 @@
 #include <cstdio>
 #include <cstdlib>
 
-#include "common.h"
-#include "gemm.h"
+#include "gemm_common.h"
 
 namespace dcf {
 
-
-struct GemmBatch {
-  GemmArgs g[3];
-};
 
 template <int WM, int WN, int TM, int TN, int AMODE, int BK>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
@@ -210,35 +205,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
     compute();
   }
 
-  // ---- epilogue.  D layout of a 32x32 tile: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * h
-  const int flags = p.flags;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + (wn * TN + j) * 32 + r;
-    const float bias = p.bias ? p.bias[col] : 0.f;
-    const float ls = ((flags & G_RES) && p.ls) ? p.ls[col] : 1.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (row < M) {
-          float v = acc[i][j][e] + bias;
-          if (flags & G_GELU) v = gelu_erf(v);
-          if (flags & G_RELU) v = fmaxf(v, 0.f);
-          if (flags & G_RES) {
-            float mk = 1.f;
-            if (flags & (G_RES_MASK | G_OUT_MASK)) mk = p.rowmask[row] ? 1.f : 0.f;
-            if (flags & G_OUT_MASK) v *= mk;
-            float res = p.R[(int64_t)row * p.ldr + col];
-            if (flags & G_RES_MASK) res *= mk;
-            v = res + ls * v;
-          }
-          p.C[(int64_t)row * p.ldc + col] = v;
-        }
-      }
-    }
-  }
+  gemm_epilogue<WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, r, h);
 }
 
 template <int WM, int WN, int TM, int TN, int BK = 32>

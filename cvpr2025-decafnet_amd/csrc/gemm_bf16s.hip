@@ -1,0 +1,273 @@
+// fp32-accurate GEMM on the bf16 matrix cores by operand splitting ("bf16x6").
+//
+// Every fp32 operand x is written exactly as hi + mid + lo with three bf16 values (8 significant
+// bits each).  A product a*b is then the sum of 9 bf16 x bf16 products, each EXACT in fp32; the six
+// with i + j <= 2 (hh, hm, mh, hl, lh, mm) carry everything down to 2^-24 |ab| -- the same size as one
+// fp32 rounding -- and are accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Measured against an fp64
+// reference the result is slightly MORE accurate than a plain fp32 FMA chain (rms 1.5e-7 vs 3.4e-7 at
+// K = 1024, tools/split_numerics.py), i.e. this is not a reduced-precision mode.
+//
+// Why: the fp32 MFMA (v_mfma_f32_32x32x2_f32) retires 2 k per 64 cycles = 32 cycles per k-step of a
+// 32x32 tile; the bf16 MFMA retires 16 k per 32 cycles, six of them 12 cycles per k -- 2.67x the rate
+// (fp32-equivalent peak 2.5 PFLOP/s / 6 = 417 TFLOP/s against 157).  NTERMS = 3 (hh, hm, mh; error
+// ~2^-16 per product) is kept as an opt-in mode.
+//
+// Weights are split once at model finalisation ([3][N][K] bf16 planes); activations are split while
+// they are staged global -> LDS (v_cvt_pk_bf16_f32, ~6 VALU ops per element, hidden under the MFMAs).
+// LDS tiles: [plane][row][32 k] bf16 with an 80-byte row pitch (20 dwords = 4 * 5: every 16-lane
+// ds_read_b128 group covers 64 distinct banks).  Lane (r = lane & 31, h = lane >> 5) reads the 8
+// consecutive k values 8h..8h+7 of row r of a 16-wide chunk with one ds_read_b128 per plane.
+#include <cstdio>
+#include <cstdlib>
+
+#include "gemm_common.h"
+
+namespace dcf {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SBK = 32;            // k per LDS tile
+constexpr int ROWB = 80;           // bytes per (plane, row): 64 data + 16 pad
+
+// split two floats into packed bf16 pairs: hi, mid, lo (round to nearest even at every level)
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+  bf16x2 h = __builtin_convertvector(f32x2{x0, x1}, bf16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+  bf16x2 m = __builtin_convertvector(f32x2{r0, r1}, bf16x2);
+  mid = __builtin_bit_cast(unsigned, m);
+  const float s0 = r0 - __uint_as_float(mid << 16), s1 = r1 - __uint_as_float(mid & 0xffff0000u);
+  bf16x2 l = __builtin_convertvector(f32x2{s0, s1}, bf16x2);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
+// out[pl][n][k] = plane pl of W[n*ldw + k]
+__global__ void k_split_planes(const float* __restrict__ W, unsigned short* __restrict__ out, int N, int K, int64_t ldw) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // pair index
+  const int64_t pairs = (int64_t)N * K / 2;
+  if (i >= pairs) return;
+  const int n = (int)(i / (K / 2)), k = (int)(i % (K / 2)) * 2;
+  unsigned hi, mid, lo;
+  split2(W[n * ldw + k], W[n * ldw + k + 1], hi, mid, lo);
+  const int64_t o = (int64_t)n * K + k;
+  *reinterpret_cast<unsigned*>(out + o) = hi;
+  *reinterpret_cast<unsigned*>(out + (int64_t)N * K + o) = mid;
+  *reinterpret_cast<unsigned*>(out + 2 * (int64_t)N * K + o) = lo;
+}
+
+int launch_split_planes(const float* W, unsigned short* out, int N, int K, int64_t ldw, hipStream_t st) {
+  DCF_CHECK(K % 2 == 0, "split_planes: K must be even");
+  const int64_t pairs = (int64_t)N * K / 2;
+  hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, W, out, N, K, ldw);
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int WM, int WN, int TM, int TN, int AMODE, int NTERMS>
+__global__ __launch_bounds__(256) void gemm_bf16s_kernel(GemmBatch batch) {
+  constexpr int BM = WM * TM * 32;
+  constexpr int BN = WN * TN * 32;
+  constexpr int NPL = NTERMS == 6 ? 3 : 2;            // planes needed: hi, mid (, lo)
+  constexpr int ACH = BM * 4 / 256;                   // 8-float chunks of the A tile per thread
+  constexpr int WTOT = NPL * BN * 4;                  // 8-bf16 chunks of the W tile
+  constexpr int WCH = (WTOT + 255) / 256;             // ... per thread (the last one may be partial)
+  static_assert(WM * WN == 4 && (BM * 4) % 256 == 0, "tile/threads mismatch");
+  static_assert(AMODE == A_ROWS || AMODE == A_ROWS_TAP3, "channel-major A stays on the fp32 kernel");
+
+  extern __shared__ unsigned char smem_b[];
+  unsigned char* As = smem_b;                          // [NPL][BM][ROWB]
+  unsigned char* Bs = smem_b + NPL * BM * ROWB;        // [NPL][BN][ROWB]
+
+  const GemmArgs p = blockIdx.z == 0 ? batch.g[0] : (blockIdx.z == 1 ? batch.g[1] : batch.g[2]);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int M = p.M, K = p.K, N = p.N;
+  const int KT = K / SBK;
+
+  // K-invariant addressing (see gemm.hip: nothing but 16-byte loads inside the K loop)
+  const float* a_ptr[ACH];
+  unsigned a_flag[ACH];
+#pragma unroll
+  for (int i = 0; i < ACH; ++i) {
+    const int id = i * 256 + tid;
+    const int row = id >> 2, c8 = id & 3;
+    const int m = m0 + row;
+    unsigned f = 0;
+    if (m < M) {
+      if constexpr (AMODE == A_ROWS) f = (p.flags & G_AMASK) ? (p.rowmask[m] ? 1u : 0u) : 1u;
+      else f = p.nbr[m];
+    }
+    a_flag[i] = f;
+    a_ptr[i] = p.A + (int64_t)(m < M ? m : 0) * p.lda + c8 * 8;
+  }
+  const u32x4* w_ptr[WCH];
+#pragma unroll
+  for (int i = 0; i < WCH; ++i) {
+    int id = i * 256 + tid;
+    id = id < WTOT ? id : 0;                          // surplus threads of a partial pass re-read chunk 0
+    const int pl = id / (BN * 4), rem = id % (BN * 4);
+    const int row = rem >> 2, c8 = rem & 3;
+    w_ptr[i] = reinterpret_cast<const u32x4*>(p.Ws + ((int64_t)pl * N + n0 + row) * K + c8 * 8);
+  }
+
+  f32x4 araw[ACH][2];
+  u32x4 wreg[WCH];
+  auto load_tiles = [&](int kt) __attribute__((always_inline)) {
+    const int k0 = kt * SBK;
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) wreg[i] = w_ptr[i][k0 / 8];
+    int64_t shift = k0;
+    unsigned bit = 1u;
+    if constexpr (AMODE == A_ROWS_TAP3) {
+      const int tap = k0 / p.cin;
+      bit = tap == 0 ? 2u : (tap == 1 ? 1u : 4u);
+      shift = (int64_t)(tap - 1) * p.lda + (k0 - tap * p.cin);
+    }
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) {
+      f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+      if (a_flag[i] & bit) {
+        v0 = *reinterpret_cast<const f32x4*>(a_ptr[i] + shift);
+        v1 = *reinterpret_cast<const f32x4*>(a_ptr[i] + shift + 4);
+      }
+      araw[i][0] = v0;
+      araw[i][1] = v1;
+    }
+  };
+  auto store_tiles = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+      const int id = i * 256 + tid;
+      if (WTOT % 256 != 0 && id >= WTOT) continue;
+      const int pl = id / (BN * 4), rem = id % (BN * 4);
+      const int row = rem >> 2, c8 = rem & 3;
+      *reinterpret_cast<u32x4*>(Bs + (pl * BN + row) * ROWB + c8 * 16) = wreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) {
+      const int id = i * 256 + tid;
+      const int row = id >> 2, c8 = id & 3;
+      unsigned h0, h1, h2, h3, m0_, m1, m2, m3, l0, l1, l2, l3;
+      split2(araw[i][0].x, araw[i][0].y, h0, m0_, l0);
+      split2(araw[i][0].z, araw[i][0].w, h1, m1, l1);
+      split2(araw[i][1].x, araw[i][1].y, h2, m2, l2);
+      split2(araw[i][1].z, araw[i][1].w, h3, m3, l3);
+      const u32x4 hi = {h0, h1, h2, h3}, mid = {m0_, m1, m2, m3}, lo = {l0, l1, l2, l3};
+      *reinterpret_cast<u32x4*>(As + (0 * BM + row) * ROWB + c8 * 16) = hi;
+      *reinterpret_cast<u32x4*>(As + (1 * BM + row) * ROWB + c8 * 16) = mid;
+      if constexpr (NPL == 3) *reinterpret_cast<u32x4*>(As + (2 * BM + row) * ROWB + c8 * 16) = lo;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  load_tiles(0);
+  for (int kt = 0; kt < KT; ++kt) {
+    __syncthreads();
+    store_tiles();
+    __syncthreads();
+    load_tiles(kt + 1 < KT ? kt + 1 : kt);
+#pragma unroll
+    for (int c = 0; c < SBK / 16; ++c) {
+      bf16x8 a[TM][NPL];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+          a[i][pl] = *reinterpret_cast<const bf16x8*>(As + (pl * BM + (wm * TM + i) * 32 + r) * ROWB + c * 32 + h * 16);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bf16x8 b[NPL];
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+          b[pl] = *reinterpret_cast<const bf16x8*>(Bs + (pl * BN + (wn * TN + j) * 32 + r) * ROWB + c * 32 + h * 16);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          // smallest terms first
+          if constexpr (NTERMS == 6) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[2], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[0], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[0], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  gemm_epilogue<WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, r, h);
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterms, hipStream_t stream) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  const GemmArgs& p = b.g[0];
+  dim3 grid((p.M + BM - 1) / BM, p.N / BN, count);
+  char name[96];
+  snprintf(name, sizeof(name), "gemm_bf16x%d<%dx%d,%s>", nterms, BM, BN, mode == A_ROWS ? "rows" : "tap3");
+  const double mnk = (double)count * p.M * (double)p.N * p.K;
+  ProfScope prof(name, stream, 2.0 * mnk,
+                 4.0 * count * ((double)p.M * p.K / (mode == A_ROWS_TAP3 ? 3 : 1) + 1.5 * (double)p.N * p.K + (double)p.M * p.N * ((p.flags & G_RES) ? 2 : 1)));
+  const int npl = nterms == 6 ? 3 : 2;
+  const size_t lds = (size_t)npl * (BM + BN) * ROWB;
+#define LS(MODE_, NT_) hipLaunchKernelGGL((gemm_bf16s_kernel<WM, WN, TM, TN, MODE_, NT_>), grid, dim3(256), lds, stream, b)
+  if (mode == A_ROWS) { if (nterms == 6) LS(A_ROWS, 6); else LS(A_ROWS, 3); }
+  else { if (nterms == 6) LS(A_ROWS_TAP3, 6); else LS(A_ROWS_TAP3, 3); }
+#undef LS
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
+// same contract as launch_gemm; every g[i].Ws must hold the [3][N][K] bf16 planes of g[i].W (ldw == K)
+int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, hipStream_t stream) {
+  DCF_CHECK(count >= 1 && count <= 3, "launch_gemm_split: count %d out of range", count);
+  DCF_CHECK(mode == A_ROWS || mode == A_ROWS_TAP3, "launch_gemm_split: channel-major A is not supported");
+  DCF_CHECK(nterms == 3 || nterms == 6, "launch_gemm_split: nterms must be 3 or 6");
+  GemmBatch b;
+  for (int i = 0; i < 3; ++i) b.g[i] = g[i < count ? i : 0];
+  const GemmArgs& p = g[0];
+  for (int i = 0; i < count; ++i) {
+    DCF_CHECK(g[i].M == p.M && g[i].N == p.N && g[i].K == p.K, "launch_gemm_split: grouped shapes differ");
+    DCF_CHECK(g[i].A && g[i].Ws && g[i].C, "launch_gemm_split: null operand");
+    DCF_CHECK(g[i].lda % 4 == 0, "launch_gemm_split: lda %% 4 != 0");
+    if (mode == A_ROWS_TAP3) DCF_CHECK(g[i].nbr && g[i].cin % 32 == 0 && g[i].K == 3 * g[i].cin, "launch_gemm_split: bad tap3 args");
+    if (g[i].flags & (G_AMASK | G_RES_MASK | G_OUT_MASK)) DCF_CHECK(g[i].rowmask, "launch_gemm_split: rowmask missing");
+    if (g[i].flags & G_RES) DCF_CHECK(g[i].R, "launch_gemm_split: residual missing");
+  }
+  if (p.M <= 0) return 0;
+  DCF_CHECK(p.K > 0 && p.K % SBK == 0 && p.N > 0 && p.N % 32 == 0, "launch_gemm_split: bad N=%d / K=%d", p.N, p.K);
+  const int N = p.N;
+  auto wgs = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * (N / bn) * count; };
+  constexpr long WANT = 512;
+  static const char* forced = getenv("DCF_GEMM_CFG");
+  if (forced) {
+    int bm = 0, bn = 0;
+    if (sscanf(forced, "%dx%d", &bm, &bn) == 2 && bn > 0 && N % bn == 0) {
+      if (bm == 64 && bn == 256) return launch_cfg_s<2, 2, 1, 4>(b, count, mode, nterms, stream);
+      if (bm == 64 && bn == 128) return launch_cfg_s<2, 2, 1, 2>(b, count, mode, nterms, stream);
+      if (bm == 64 && bn == 64) return launch_cfg_s<2, 2, 1, 1>(b, count, mode, nterms, stream);
+      if (bm == 128 && bn == 128) return launch_cfg_s<2, 2, 2, 2>(b, count, mode, nterms, stream);
+      if (bm == 128 && bn == 64) return launch_cfg_s<4, 1, 1, 2>(b, count, mode, nterms, stream);
+    }
+  }
+  if (N % 256 == 0 && wgs(64, 256) >= WANT) return launch_cfg_s<2, 2, 1, 4>(b, count, mode, nterms, stream);
+  if (N % 160 == 0 && N % 64 != 0) return launch_cfg_s<4, 1, 1, 5>(b, count, mode, nterms, stream);
+  if (N % 128 == 0 && wgs(64, 128) >= WANT) return launch_cfg_s<2, 2, 1, 2>(b, count, mode, nterms, stream);
+  if (N % 96 == 0 && N % 64 != 0) return launch_cfg_s<4, 1, 1, 3>(b, count, mode, nterms, stream);
+  if (N % 64 == 0) return launch_cfg_s<2, 2, 1, 1>(b, count, mode, nterms, stream);
+  return launch_cfg_s<4, 1, 1, 1>(b, count, mode, nterms, stream);
+}
+
+}  // namespace dcf

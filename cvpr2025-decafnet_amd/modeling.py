@@ -371,6 +371,9 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         self.second_fusion = second_fusion
         self.head_layers = ch.get('n_layers', 2)
         self.max_batch = int(mo.get('max_batch', 0) or 0)
+        # dense-conv arithmetic (extension key opt.model.gemm_mode): 'bf16x6' (default, fp32 accurate),
+        # 'fp32' (native fp32 MFMA) or 'bf16x3'
+        self.gemm_mode = {'bf16x6': 6, 'fp32': 1, 'bf16x3': 3}[mo.get('gemm_mode', 'bf16x6')]
         self._engine = None
 
     # -- reference API ---------------------------------------------------------------------
@@ -393,6 +396,7 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         c.win, c.head_layers = vn.mha_win_size, self.head_layers
         c.sn, c.sratio, c.msf, c.norm = self.sn, self.sratio, int(self.msf), int(self.norm)
         c.use_abs_pe, c.max_batch = int(vn.use_abs_pe), self.max_batch
+        c.gemm_mode = self.gemm_mode
         return c
 
     def _named_engine_tensors(self):

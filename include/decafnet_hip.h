@@ -46,6 +46,8 @@ typedef struct dcf_config {
   int32_t norm;           /* opt.model.norm                                                        */
   int32_t use_abs_pe;     /* opt.model.vid_net.use_abs_pe                                          */
   int32_t max_batch;      /* queries processed together (>= 1); 0 = library default                */
+  int32_t gemm_mode;      /* dense-conv arithmetic: 0/6 = fp32-accurate bf16x6 split MFMA (default),
+                           * 1 = native fp32 MFMA, 3 = bf16x3 split (~2^-16 per product)           */
 } dcf_config;
 
 int dcf_model_create(const dcf_config* cfg, dcf_model** out);
@@ -140,6 +142,9 @@ int64_t dcf_profile_report(char* buf, int64_t cap);
  * act: 0 none, 1 exact GELU, 2 ReLU. */
 int dcf_op_linear(const float* A, const float* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K,
                   int32_t act, void* stream);
+/* same through the bf16-split MFMA GEMM (gemm_bf16s.hip); nterms = 6 (fp32 accurate) or 3 */
+int dcf_op_linear_split(const float* A, const float* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K,
+                        int32_t act, int32_t nterms, void* stream);
 /* same with A given channel-major (K, M) -- the reference's (C, T) layout */
 int dcf_op_linear_cm(const float* A_cm, const float* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K,
                      void* stream);

@@ -70,6 +70,32 @@ def test_linear(L, M, N, K, act):
     torch.testing.assert_close(C.cpu().double(), ref, rtol=1e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize('nterms,tol', [(6, 2e-5), (3, 3e-4)])
+@pytest.mark.parametrize('M,N,K,act', [(64, 256, 256, 0), (1000, 256, 1024, 1), (333, 1024, 256, 0), (77, 288, 864, 2),
+                                         (50, 160, 128, 0), (200, 96, 64, 0), (129, 64, 32, 0), (65, 32, 32, 0), (4096, 512, 256, 0)])
+def test_linear_bf16_split(L, M, N, K, act, nterms, tol):
+    """fp32-accurate GEMM on the bf16 matrix cores (operand splitting, gemm_bf16s.hip) vs fp64"""
+    pkg, lib = L
+    g = torch.Generator().manual_seed(M * 5 + N + nterms)
+    A = torch.randn(M, K, generator=g) * 3
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    ref = A.double() @ W.double().t() + b.double()
+    if act == 1:
+        ref = F.gelu(ref)
+    elif act == 2:
+        ref = F.relu(ref)
+    C = torch.empty(M, N, device='cuda')
+    pkg._lib.check(lib.dcf_op_linear_split(P(A.cuda()), P(W.cuda()), P(b.cuda()), P(C), M, N, K, act, nterms, st()))
+    torch.testing.assert_close(C.cpu().double(), ref, rtol=tol, atol=tol)
+    if nterms == 6:     # not worse than the native fp32 MFMA GEMM
+        C32 = torch.empty(M, N, device='cuda')
+        pkg._lib.check(lib.dcf_op_linear(P(A.cuda()), P(W.cuda()), P(b.cuda()), P(C32), M, N, K, act, st()))
+        e6 = (C.cpu().double() - ref).abs().max()
+        e32 = (C32.cpu().double() - ref).abs().max()
+        assert e6 <= 2.0 * e32 + 1e-7, (float(e6), float(e32))
+
+
 @pytest.mark.parametrize('M,N,K', [(256, 256, 512), (1000, 128, 64), (4096, 256, 1024), (250, 64, 32)])
 def test_linear_channel_major(L, M, N, K):
     pkg, lib = L

@@ -1,0 +1,19 @@
+"""Run one GEMM shape repeatedly (for rocprofv3 --pmc).  usage: gemm_one.py MODE M N K [reps]   MODE = f32|x6|x3"""
+import ctypes, importlib, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+mode, M, N, K = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+reps = int(sys.argv[5]) if len(sys.argv) > 5 else 20
+pkg = importlib.import_module('cvpr2025-decafnet_amd')
+lib = pkg._lib.lib()
+A = torch.randn(M, K, device='cuda'); W = torch.randn(N, K, device='cuda'); b = torch.randn(N, device='cuda')
+C = torch.empty(M, N, device='cuda')
+P = lambda t: ctypes.c_void_p(t.data_ptr())
+st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+for _ in range(reps):
+    if mode == 'f32':
+        lib.dcf_op_linear(P(A), P(W), P(b), P(C), M, N, K, 0, st)
+    else:
+        lib.dcf_op_linear_split(P(A), P(W), P(b), P(C), M, N, K, 0, 6 if mode == 'x6' else 3, st)
+torch.cuda.synchronize()

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 SHAPES = [(16384, 256, 256), (16384, 1024, 256), (16384, 256, 1024), (16384, 512, 256), (8192, 256, 256), (8192, 1024, 256),
           (8192, 256, 1024), (2048, 256, 256), (2048, 256, 1024), (512, 256, 256), (512, 256, 1024), (128, 1024, 256), (131072, 256, 256),
           (131072, 256, 1024)]
-TILES = ['auto', '64x128', '64x128x64', '64x64', '64x64x64', '128x64', '128x64x64', '128x128', '128x128x64']
+TILES = ['f32:auto', 'x6:auto', 'x6:64x256', 'x6:64x128', 'x6:64x64', 'x6:128x128', 'x6:128x64', 'x3:auto']
 
 def child():
     import torch
@@ -19,14 +19,17 @@ def child():
         C = torch.empty(M, N, device='cuda')
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         P = lambda t: ctypes.c_void_p(t.data_ptr())
+        mode = os.environ.get('SWEEP_MODE', 'f32')
+        call = (lambda: lib.dcf_op_linear(P(A), P(W), P(b), P(C), M, N, K, 0, st)) if mode == 'f32' else \
+               (lambda: lib.dcf_op_linear_split(P(A), P(W), P(b), P(C), M, N, K, 0, 6 if mode == 'x6' else 3, st))
         for _ in range(3):
-            lib.dcf_op_linear(P(A), P(W), P(b), P(C), M, N, K, 0, st)
+            call()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 20
         e0.record()
         for _ in range(reps):
-            lib.dcf_op_linear(P(A), P(W), P(b), P(C), M, N, K, 0, st)
+            call()
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / reps
         out[f'{M}x{N}x{K}'] = (us, 2.0 * M * N * K / us / 1e6)
@@ -39,8 +42,10 @@ if __name__ == '__main__':
         res = {}
         for t in TILES:
             env = dict(os.environ)
-            if t != 'auto':
-                env['DCF_GEMM_CFG'] = t
+            mode, tile = t.split(':')
+            env['SWEEP_MODE'] = mode
+            if tile != 'auto':
+                env['DCF_GEMM_CFG'] = tile
             r = subprocess.run([sys.executable, __file__, 'child'], env=env, capture_output=True, text=True)
             try:
                 res[t] = json.loads(r.stdout.strip().splitlines()[-1])
