@@ -25,7 +25,7 @@ struct GemmArgs {
   int64_t lda;
   const float* W;      // [N][ldw], K contiguous (PyTorch Conv1d weight (N, K, 1); k3 weights are repacked [N][tap][cin])
   int64_t ldw;         // row pitch of W in floats (0 = K)
-  const unsigned short* Ws;  // optional: W split into bf16 planes [3][N][K] (gemm_bf16s.hip); nullptr = fp32 MFMA
+  const unsigned short* Ws;  // optional: W split into pre-tiled bf16 planes (gemm_bf16s.hip); nullptr = fp32 MFMA
   const float* bias;   // [N] or nullptr
   float* C;
   int64_t ldc;

@@ -22,6 +22,7 @@
 
 #include "gemm_common.h"
 
+
 namespace dcf {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -44,7 +45,10 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
   lo = __builtin_bit_cast(unsigned, l);
 }
 
-// out[pl][n][k] = plane pl of W[n*ldw + k]
+// Weight planes are stored pre-tiled in exactly the order the GEMM stages them: one contiguous 6 KiB block
+// per (32 output rows, 32-wide K tile):  Wt[(n/32 * K/32 + k/32)][plane][n % 32][k % 32]  (bf16).
+// A workgroup then fetches its W tile as a few fully coalesced 6 KiB runs instead of 64-byte row
+// pieces (half cache lines, fetched twice) -- the L2 -> CU weight stream is what bounds this kernel.
 __global__ void k_split_planes(const float* __restrict__ W, unsigned short* __restrict__ out, int N, int K, int64_t ldw) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // pair index
   const int64_t pairs = (int64_t)N * K / 2;
@@ -52,14 +56,15 @@ __global__ void k_split_planes(const float* __restrict__ W, unsigned short* __re
   const int n = (int)(i / (K / 2)), k = (int)(i % (K / 2)) * 2;
   unsigned hi, mid, lo;
   split2(W[n * ldw + k], W[n * ldw + k + 1], hi, mid, lo);
-  const int64_t o = (int64_t)n * K + k;
+  const int64_t blk = (int64_t)(n >> 5) * (K >> 5) + (k >> 5);
+  const int64_t o = blk * (3 * 32 * 32) + (n & 31) * 32 + (k & 31);
   *reinterpret_cast<unsigned*>(out + o) = hi;
-  *reinterpret_cast<unsigned*>(out + (int64_t)N * K + o) = mid;
-  *reinterpret_cast<unsigned*>(out + 2 * (int64_t)N * K + o) = lo;
+  *reinterpret_cast<unsigned*>(out + o + 32 * 32) = mid;
+  *reinterpret_cast<unsigned*>(out + o + 2 * 32 * 32) = lo;
 }
 
 int launch_split_planes(const float* W, unsigned short* out, int N, int K, int64_t ldw, hipStream_t st) {
-  DCF_CHECK(K % 2 == 0, "split_planes: K must be even");
+  DCF_CHECK(K % 32 == 0 && N % 32 == 0, "split_planes: N and K must be multiples of 32");
   const int64_t pairs = (int64_t)N * K / 2;
   hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, W, out, N, K, ldw);
   DCF_HIP(hipGetLastError());
@@ -110,17 +115,14 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kernel(GemmBatch batch) {
   for (int i = 0; i < WCH; ++i) {
     int id = i * 256 + tid;
     id = id < WTOT ? id : 0;                          // surplus threads of a partial pass re-read chunk 0
-    const int pl = id / (BN * 4), rem = id % (BN * 4);
-    const int row = rem >> 2, c8 = rem & 3;
-    w_ptr[i] = reinterpret_cast<const u32x4*>(p.Ws + ((int64_t)pl * N + n0 + row) * K + c8 * 8);
+    const int blk = id / (NPL * 128), within = id % (NPL * 128);     // 32-row block, 16-byte chunk inside its planes
+    w_ptr[i] = reinterpret_cast<const u32x4*>(p.Ws + ((int64_t)(n0 / 32 + blk) * KT) * (3 * 32 * 32) + within * 8);
   }
 
-  f32x4 araw[ACH][2];
-  u32x4 wreg[WCH];
-  auto load_tiles = [&](int kt) __attribute__((always_inline)) {
+  auto load_tiles = [&](int kt, f32x4 (&araw)[ACH][2], u32x4 (&wreg)[WCH]) __attribute__((always_inline)) {
     const int k0 = kt * SBK;
 #pragma unroll
-    for (int i = 0; i < WCH; ++i) wreg[i] = w_ptr[i][k0 / 8];
+    for (int i = 0; i < WCH; ++i) wreg[i] = w_ptr[i][kt * (3 * 32 * 32 / 8)];
     int64_t shift = k0;
     unsigned bit = 1u;
     if constexpr (AMODE == A_ROWS_TAP3) {
@@ -139,14 +141,14 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kernel(GemmBatch batch) {
       araw[i][1] = v1;
     }
   };
-  auto store_tiles = [&]() __attribute__((always_inline)) {
+  auto store_tiles = [&](const f32x4 (&araw)[ACH][2], const u32x4 (&wreg)[WCH]) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
       const int id = i * 256 + tid;
       if (WTOT % 256 != 0 && id >= WTOT) continue;
-      const int pl = id / (BN * 4), rem = id % (BN * 4);
-      const int row = rem >> 2, c8 = rem & 3;
-      *reinterpret_cast<u32x4*>(Bs + (pl * BN + row) * ROWB + c8 * 16) = wreg[i];
+      const int blk = id / (NPL * 128), within = id % (NPL * 128);
+      const int pl = within >> 7, row = (within & 127) >> 2, c8 = within & 3;
+      *reinterpret_cast<u32x4*>(Bs + (pl * BN + blk * 32 + row) * ROWB + c8 * 16) = wreg[i];
     }
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
@@ -172,12 +174,7 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kernel(GemmBatch batch) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  load_tiles(0);
-  for (int kt = 0; kt < KT; ++kt) {
-    __syncthreads();
-    store_tiles();
-    __syncthreads();
-    load_tiles(kt + 1 < KT ? kt + 1 : kt);
+  auto compute = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int c = 0; c < SBK / 16; ++c) {
       bf16x8 a[TM][NPL];
@@ -206,6 +203,20 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kernel(GemmBatch batch) {
         }
       }
     }
+  };
+
+  // One K tile in flight.  Two register sets (two tiles in flight) were measured: the extra ~60 VGPRs halve the
+  // occupancy and lose 15-40 %; occupancy (2 workgroups per CU alternating store and MFMA phases) is what hides
+  // the L2 round trip here.
+  f32x4 a0[ACH][2];
+  u32x4 w0[WCH];
+  load_tiles(0, a0, w0);
+  for (int kt = 0; kt < KT; ++kt) {
+    __syncthreads();
+    store_tiles(a0, w0);
+    __syncthreads();
+    load_tiles(kt + 1 < KT ? kt + 1 : kt, a0, w0);
+    compute();
   }
   gemm_epilogue<WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, r, h);
 }
@@ -230,7 +241,7 @@ static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterm
   return 0;
 }
 
-// same contract as launch_gemm; every g[i].Ws must hold the [3][N][K] bf16 planes of g[i].W (ldw == K)
+// same contract as launch_gemm; every g[i].Ws must hold the pre-tiled bf16 planes of g[i].W (launch_split_planes)
 int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, hipStream_t stream) {
   DCF_CHECK(count >= 1 && count <= 3, "launch_gemm_split: count %d out of range", count);
   DCF_CHECK(mode == A_ROWS || mode == A_ROWS_TAP3, "launch_gemm_split: channel-major A is not supported");

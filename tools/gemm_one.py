@@ -11,9 +11,15 @@ A = torch.randn(M, K, device='cuda'); W = torch.randn(N, K, device='cuda'); b = 
 C = torch.empty(M, N, device='cuda')
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+import time
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
 for _ in range(reps):
     if mode == 'f32':
         lib.dcf_op_linear(P(A), P(W), P(b), P(C), M, N, K, 0, st)
     else:
         lib.dcf_op_linear_split(P(A), P(W), P(b), P(C), M, N, K, 0, 6 if mode == 'x6' else 3, st)
 torch.cuda.synchronize()
+e1.record(); torch.cuda.synchronize()
+print(mode, M, N, K, 'us/launch (incl. weight split for x6/x3):', round(e0.elapsed_time(e1) * 1e3 / reps, 1))
