@@ -45,10 +45,12 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
   lo = __builtin_bit_cast(unsigned, l);
 }
 
-// Weight planes are stored pre-tiled in exactly the order the GEMM stages them: one contiguous 6 KiB block
-// per (32 output rows, 32-wide K tile):  Wt[(n/32 * K/32 + k/32)][plane][n % 32][k % 32]  (bf16).
-// A workgroup then fetches its W tile as a few fully coalesced 6 KiB runs instead of 64-byte row
-// pieces (half cache lines, fetched twice) -- the L2 -> CU weight stream is what bounds this kernel.
+// Weight image = MFMA B fragments in the order the kernel consumes them.  One 6 KiB block per (32 output
+// rows n32, 32-wide K tile kt), blocks ordered [n32][kt]; inside a block
+//   [16-wide K chunk c = 0,1][plane][lane = h * 32 + r][8 bf16]  =  W[n32*32 + r][kt*32 + c*16 + h*8 .. +7]
+// so ONE fully coalesced 1 KiB wave load (global_load_dwordx4) delivers the bf16x8 B operand of every lane
+// for one (chunk, plane).  W never touches LDS: staging the 60 KiB W tile per K step through ds_write_b128
+// (~79 B/clk/CU) was the co-bottleneck of the first version of this kernel (MFMA busy 25 %).
 __global__ void k_split_planes(const float* __restrict__ W, unsigned short* __restrict__ out, int N, int K, int64_t ldw) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // pair index
   const int64_t pairs = (int64_t)N * K / 2;
@@ -57,10 +59,11 @@ __global__ void k_split_planes(const float* __restrict__ W, unsigned short* __re
   unsigned hi, mid, lo;
   split2(W[n * ldw + k], W[n * ldw + k + 1], hi, mid, lo);
   const int64_t blk = (int64_t)(n >> 5) * (K >> 5) + (k >> 5);
-  const int64_t o = blk * (3 * 32 * 32) + (n & 31) * 32 + (k & 31);
+  const int kk = k & 31, c = kk >> 4, h = (kk >> 3) & 1, j = kk & 7, r = n & 31;
+  const int64_t o = blk * (2 * 3 * 64 * 8) + ((int64_t)(c * 3) * 64 + h * 32 + r) * 8 + j;
   *reinterpret_cast<unsigned*>(out + o) = hi;
-  *reinterpret_cast<unsigned*>(out + o + 32 * 32) = mid;
-  *reinterpret_cast<unsigned*>(out + o + 2 * 32 * 32) = lo;
+  *reinterpret_cast<unsigned*>(out + o + 64 * 8) = mid;
+  *reinterpret_cast<unsigned*>(out + o + 2 * 64 * 8) = lo;
 }
 
 int launch_split_planes(const float* W, unsigned short* out, int N, int K, int64_t ldw, hipStream_t st) {
@@ -75,23 +78,21 @@ template <int WM, int WN, int TM, int TN, int AMODE, int NTERMS>
 __global__ __launch_bounds__(256) void gemm_bf16s_kernel(GemmBatch batch) {
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
-  constexpr int NPL = NTERMS == 6 ? 3 : 2;            // planes needed: hi, mid (, lo)
+  constexpr int NPL = NTERMS == 6 ? 3 : 2;            // planes used: hi, mid (, lo)
   constexpr int ACH = BM * 4 / 256;                   // 8-float chunks of the A tile per thread
-  constexpr int WTOT = NPL * BN * 4;                  // 8-bf16 chunks of the W tile
-  constexpr int WCH = (WTOT + 255) / 256;             // ... per thread (the last one may be partial)
+  constexpr int BLK = 2 * 3 * 64 * 8;                 // bf16 elements of one weight block (6 KiB)
   static_assert(WM * WN == 4 && (BM * 4) % 256 == 0, "tile/threads mismatch");
   static_assert(AMODE == A_ROWS || AMODE == A_ROWS_TAP3, "channel-major A stays on the fp32 kernel");
 
   extern __shared__ unsigned char smem_b[];
-  unsigned char* As = smem_b;                          // [NPL][BM][ROWB]
-  unsigned char* Bs = smem_b + NPL * BM * ROWB;        // [NPL][BN][ROWB]
+  unsigned char* As = smem_b;                          // [NPL][BM][ROWB]: the only LDS tile (A is shared by the N-waves)
 
   const GemmArgs p = blockIdx.z == 0 ? batch.g[0] : (blockIdx.z == 1 ? batch.g[1] : batch.g[2]);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int M = p.M, K = p.K, N = p.N;
+  const int M = p.M, K = p.K;
   const int KT = K / SBK;
 
   // K-invariant addressing (see gemm.hip: nothing but 16-byte loads inside the K loop)
@@ -110,19 +111,15 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kernel(GemmBatch batch) {
     a_flag[i] = f;
     a_ptr[i] = p.A + (int64_t)(m < M ? m : 0) * p.lda + c8 * 8;
   }
-  const u32x4* w_ptr[WCH];
+  // B fragments of this wave's TN column tiles: block (n32, kt) at ((n32 * KT + kt) * BLK), lane slot lane*8
+  const bf16x8* w_ptr[TN];
 #pragma unroll
-  for (int i = 0; i < WCH; ++i) {
-    int id = i * 256 + tid;
-    id = id < WTOT ? id : 0;                          // surplus threads of a partial pass re-read chunk 0
-    const int blk = id / (NPL * 128), within = id % (NPL * 128);     // 32-row block, 16-byte chunk inside its planes
-    w_ptr[i] = reinterpret_cast<const u32x4*>(p.Ws + ((int64_t)(n0 / 32 + blk) * KT) * (3 * 32 * 32) + within * 8);
-  }
+  for (int j = 0; j < TN; ++j)
+    w_ptr[j] = reinterpret_cast<const bf16x8*>(p.Ws + ((int64_t)(n0 / 32 + wn * TN + j) * KT) * BLK) + lane;
 
-  auto load_tiles = [&](int kt, f32x4 (&araw)[ACH][2], u32x4 (&wreg)[WCH]) __attribute__((always_inline)) {
+  f32x4 araw[ACH][2];
+  auto load_a = [&](int kt) __attribute__((always_inline)) {
     const int k0 = kt * SBK;
-#pragma unroll
-    for (int i = 0; i < WCH; ++i) wreg[i] = w_ptr[i][kt * (3 * 32 * 32 / 8)];
     int64_t shift = k0;
     unsigned bit = 1u;
     if constexpr (AMODE == A_ROWS_TAP3) {
@@ -141,15 +138,7 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kernel(GemmBatch batch) {
       araw[i][1] = v1;
     }
   };
-  auto store_tiles = [&](const f32x4 (&araw)[ACH][2], const u32x4 (&wreg)[WCH]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < WCH; ++i) {
-      const int id = i * 256 + tid;
-      if (WTOT % 256 != 0 && id >= WTOT) continue;
-      const int blk = id / (NPL * 128), within = id % (NPL * 128);
-      const int pl = within >> 7, row = (within & 127) >> 2, c8 = within & 3;
-      *reinterpret_cast<u32x4*>(Bs + (pl * BN + blk * 32 + row) * ROWB + c8 * 16) = wreg[i];
-    }
+  auto store_a = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
       const int id = i * 256 + tid;
@@ -165,6 +154,16 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kernel(GemmBatch batch) {
       if constexpr (NPL == 3) *reinterpret_cast<u32x4*>(As + (2 * BM + row) * ROWB + c8 * 16) = lo;
     }
   };
+  // B fragments of one K tile: [chunk][tile][plane]
+  bf16x8 bfr[2][TN][NPL];
+  auto load_b = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) bfr[c][j][pl] = w_ptr[j][(int64_t)kt * (BLK / 8) + (c * 3 + pl) * 64];
+  };
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -174,7 +173,22 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kernel(GemmBatch batch) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  auto compute = [&]() __attribute__((always_inline)) {
+  load_a(0);
+  load_b(0);
+  for (int kt = 0; kt < KT; ++kt) {
+    __syncthreads();                    // every wave finished reading As (tile kt-1)
+    store_a();
+    __syncthreads();
+    load_a(kt + 1 < KT ? kt + 1 : kt);
+    // the B fragments of tile kt are in registers; copy them so the next tile's loads can be issued now
+    bf16x8 bc[2][TN][NPL];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) bc[c][j][pl] = bfr[c][j][pl];
+    load_b(kt + 1 < KT ? kt + 1 : kt);
 #pragma unroll
     for (int c = 0; c < SBK / 16; ++c) {
       bf16x8 a[TM][NPL];
@@ -185,38 +199,20 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kernel(GemmBatch batch) {
           a[i][pl] = *reinterpret_cast<const bf16x8*>(As + (pl * BM + (wm * TM + i) * 32 + r) * ROWB + c * 32 + h * 16);
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        bf16x8 b[NPL];
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl)
-          b[pl] = *reinterpret_cast<const bf16x8*>(Bs + (pl * BN + (wn * TN + j) * 32 + r) * ROWB + c * 32 + h * 16);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           // smallest terms first
           if constexpr (NTERMS == 6) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[1], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[2], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bc[c][j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bc[c][j][2], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], bc[c][j][0], acc[i][j], 0, 0, 0);
           }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[1], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bc[c][j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bc[c][j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bc[c][j][0], acc[i][j], 0, 0, 0);
         }
       }
     }
-  };
-
-  // One K tile in flight.  Two register sets (two tiles in flight) were measured: the extra ~60 VGPRs halve the
-  // occupancy and lose 15-40 %; occupancy (2 workgroups per CU alternating store and MFMA phases) is what hides
-  // the L2 round trip here.
-  f32x4 a0[ACH][2];
-  u32x4 w0[WCH];
-  load_tiles(0, a0, w0);
-  for (int kt = 0; kt < KT; ++kt) {
-    __syncthreads();
-    store_tiles(a0, w0);
-    __syncthreads();
-    load_tiles(kt + 1 < KT ? kt + 1 : kt, a0, w0);
-    compute();
   }
   gemm_epilogue<WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, r, h);
 }
@@ -232,7 +228,7 @@ static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterm
   ProfScope prof(name, stream, 2.0 * mnk,
                  4.0 * count * ((double)p.M * p.K / (mode == A_ROWS_TAP3 ? 3 : 1) + 1.5 * (double)p.N * p.K + (double)p.M * p.N * ((p.flags & G_RES) ? 2 : 1)));
   const int npl = nterms == 6 ? 3 : 2;
-  const size_t lds = (size_t)npl * (BM + BN) * ROWB;
+  const size_t lds = (size_t)npl * BM * ROWB;
 #define LS(MODE_, NT_) hipLaunchKernelGGL((gemm_bf16s_kernel<WM, WN, TM, TN, MODE_, NT_>), grid, dim3(256), lds, stream, b)
   if (mode == A_ROWS) { if (nterms == 6) LS(A_ROWS, 6); else LS(A_ROWS, 3); }
   else { if (nterms == 6) LS(A_ROWS_TAP3, 6); else LS(A_ROWS_TAP3, 3); }
@@ -259,25 +255,16 @@ int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, 
   }
   if (p.M <= 0) return 0;
   DCF_CHECK(p.K > 0 && p.K % SBK == 0 && p.N > 0 && p.N % 32 == 0, "launch_gemm_split: bad N=%d / K=%d", p.N, p.K);
+  // Tiles put all four waves side by side along N (WM = 1): every B fragment is then fetched by exactly one wave
+  // and the 64-row A tile in LDS is shared by all of them.
   const int N = p.N;
   auto wgs = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * (N / bn) * count; };
-  constexpr long WANT = 512;
-  static const char* forced = getenv("DCF_GEMM_CFG");
-  if (forced) {
-    int bm = 0, bn = 0;
-    if (sscanf(forced, "%dx%d", &bm, &bn) == 2 && bn > 0 && N % bn == 0) {
-      if (bm == 64 && bn == 256) return launch_cfg_s<2, 2, 1, 4>(b, count, mode, nterms, stream);
-      if (bm == 64 && bn == 128) return launch_cfg_s<2, 2, 1, 2>(b, count, mode, nterms, stream);
-      if (bm == 64 && bn == 64) return launch_cfg_s<2, 2, 1, 1>(b, count, mode, nterms, stream);
-      if (bm == 128 && bn == 128) return launch_cfg_s<2, 2, 2, 2>(b, count, mode, nterms, stream);
-      if (bm == 128 && bn == 64) return launch_cfg_s<4, 1, 1, 2>(b, count, mode, nterms, stream);
-    }
-  }
-  if (N % 256 == 0 && wgs(64, 256) >= WANT) return launch_cfg_s<2, 2, 1, 4>(b, count, mode, nterms, stream);
-  if (N % 160 == 0 && N % 64 != 0) return launch_cfg_s<4, 1, 1, 5>(b, count, mode, nterms, stream);
-  if (N % 128 == 0 && wgs(64, 128) >= WANT) return launch_cfg_s<2, 2, 1, 2>(b, count, mode, nterms, stream);
-  if (N % 96 == 0 && N % 64 != 0) return launch_cfg_s<4, 1, 1, 3>(b, count, mode, nterms, stream);
-  if (N % 64 == 0) return launch_cfg_s<2, 2, 1, 1>(b, count, mode, nterms, stream);
+  constexpr long WANT = 512;            // >= 2 workgroups per CU
+  if (N % 256 == 0 && wgs(64, 256) >= WANT) return launch_cfg_s<1, 4, 2, 2>(b, count, mode, nterms, stream);   // 64x256, 64x64 per wave
+  if (N % 96 == 0 && N % 64 != 0) return launch_cfg_s<4, 1, 1, 3>(b, count, mode, nterms, stream);              // 128x96 (N = 288)
+  if (N % 160 == 0 && N % 64 != 0) return launch_cfg_s<4, 1, 1, 5>(b, count, mode, nterms, stream);             // 128x160
+  if (N % 128 == 0 && wgs(64, 128) >= WANT) return launch_cfg_s<1, 4, 2, 1>(b, count, mode, nterms, stream);   // 64x128
+  if (N % 64 == 0) return launch_cfg_s<2, 2, 1, 1>(b, count, mode, nterms, stream);                             // 64x64
   return launch_cfg_s<4, 1, 1, 1>(b, count, mode, nterms, stream);
 }
 
