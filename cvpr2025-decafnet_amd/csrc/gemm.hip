@@ -45,8 +45,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
   const int wn = wave % WN;
   const int r = lane & 31;
   const int h = lane >> 5;
-  const int m0 = blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  int m0, n0;
+  if (!tile_origin<BM, BN>(p, m0, n0)) return;
   const int M = p.M, K = p.K;
   const int KT = K / BK;
 
@@ -212,7 +212,7 @@ template <int WM, int WN, int TM, int TN, int BK = 32>
 static int launch_cfg(const GemmBatch& b, int count, GemmAMode mode, hipStream_t stream) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const GemmArgs& p = b.g[0];
-  dim3 grid((p.M + BM - 1) / BM, p.N / BN, count);
+  dim3 grid(tile_grid<BM, BN>(p), 1, count);
   char name[96];
   snprintf(name, sizeof(name), "gemm_f32<%dx%dx%d,%s>", BM, BN, BK, mode == A_ROWS ? "rows" : mode == A_ROWS_TAP3 ? "tap3" : "chanmajor");
   const double mnk = (double)count * p.M * (double)p.N * p.K;

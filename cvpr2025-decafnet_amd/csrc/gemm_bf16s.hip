@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kernel(GemmBatch batch) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  int m0, n0;
+  if (!tile_origin<BM, BN>(p, m0, n0)) return;
   const int M = p.M, K = p.K;
   const int KT = K / SBK;
 
@@ -221,7 +222,7 @@ template <int WM, int WN, int TM, int TN>
 static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterms, hipStream_t stream) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const GemmArgs& p = b.g[0];
-  dim3 grid((p.M + BM - 1) / BM, p.N / BN, count);
+  dim3 grid(tile_grid<BM, BN>(p), 1, count);
   char name[96];
   snprintf(name, sizeof(name), "gemm_bf16x%d<%dx%d,%s>", nterms, BM, BN, mode == A_ROWS ? "rows" : "tap3");
   const double mnk = (double)count * p.M * (double)p.N * p.K;
