@@ -15,6 +15,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -165,7 +166,16 @@ struct dcf_model {
   static constexpr int META_SLOTS = 64;      // ring of pinned/device TextMeta slots (one per forward chunk)
   TextMeta* h_meta = nullptr;                // pinned host [META_SLOTS]
   TextMeta* d_meta = nullptr;                // device      [META_SLOTS]
-  int meta_next = 0;
+  int meta_next = GRAPH_META_SLOTS;
+  static constexpr int GRAPH_META_SLOTS = 8; // slots [0, 8) belong to the captured graph (one per forward chunk)
+  // HIP graph of the last repeated forward (same pointers and sizes): one graph launch replaces ~135 kernel launches,
+  // so a busy host cannot starve the GPU.  Captured on the second identical call, dropped whenever anything it bakes
+  // in changes (weights, position encoding, workspace).
+  std::vector<uint64_t> last_key, graph_key;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  bool capturing = false;
+  int capture_chunk = 0;
   // last-forward bookkeeping for dcf_debug_copy
   struct {
     float *correl = nullptr, *gate = nullptr, *vidmap = nullptr, *fused = nullptr, *F = nullptr;
@@ -178,7 +188,17 @@ struct dcf_model {
 
 namespace dcf {
 
+static void drop_graph(dcf_model* m) {
+  if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+  if (m->graph) (void)hipGraphDestroy(m->graph);
+  m->graph_exec = nullptr;
+  m->graph = nullptr;
+  m->graph_key.clear();
+  m->last_key.clear();
+}
+
 static int free_model(dcf_model* m) {
+  drop_graph(m);
   for (float* p : m->owned) (void)hipFree(p);
   m->owned.clear();
   m->wsplit.clear();
@@ -366,6 +386,7 @@ static int finalize(dcf_model* m, hipStream_t st) {
   DCF_HIP(hipStreamSynchronize(st));
   for (auto& pl : m->plans) if (pl.d_lt) (void)hipFree(pl.d_lt);
   m->plans.clear();                           // reg scales live in the level tables
+  drop_graph(m);
   m->finalized = true;
   return 0;
 }
@@ -497,24 +518,29 @@ static int run_encoder(dcf_model* m, const EncW& w, Buffers& b, const float* Xin
 }
 
 // one head trunk (n x [k3 conv, LN, ReLU]) + output conv over the whole pyramid
+// rows [row0, row0 + rows) of the pyramid (a whole pyramid, or one level)
 static int run_head(dcf_model* m, const HeadW& h, Buffers& b, const Plan& pl, int Cin, int NO, int mode, int query_major,
-                    float* out, hipStream_t st) {
-  const int rowsAll = pl.B * pl.lt.S;
+                    float* out, hipStream_t st, int row0 = 0, int rows = -1) {
+  const int rowsAll = rows >= 0 ? rows : pl.B * pl.lt.S;
   const int ldf = m->cfg.E + TCN_HID;
-  const float* in = b.F;
+  const float* in = b.F + (int64_t)row0 * ldf;
   int64_t ldin = ldf;
+  float* HA = b.HA + (int64_t)row0 * Cin;
+  float* HB = b.HB + (int64_t)row0 * Cin;
+  const uint8_t* nbr = b.nbr_all + row0;
   for (size_t i = 0; i < h.conv.size(); ++i) {
-    GemmArgs g = gemm(in, ldin, h.conv[i], nullptr, b.HA, Cin, rowsAll, Cin, 3 * Cin);
-    g.cin = Cin; g.nbr = b.nbr_all;
+    GemmArgs g = gemm(in, ldin, h.conv[i], nullptr, HA, Cin, rowsAll, Cin, 3 * Cin);
+    g.cin = Cin; g.nbr = nbr;
     TRY(run_gemm(m, &g, 1, A_ROWS_TAP3, st));
-    LnArgs ln{}; ln.X = b.HA; ln.ldx = Cin; ln.Y = b.HB; ln.ldy = Cin; ln.w = h.ln_w[i]; ln.b = h.ln_b[i];
+    LnArgs ln{}; ln.X = HA; ln.ldx = Cin; ln.Y = HB; ln.ldy = Cin; ln.w = h.ln_w[i]; ln.b = h.ln_b[i];
     ln.rows = rowsAll; ln.C = Cin; ln.relu = 1;
     TRY(launch_ln(ln, st));
-    in = b.HB; ldin = Cin;
+    in = HB; ldin = Cin;
   }
   ConvOutArgs co{};
-  co.X = in; co.ldx = ldin; co.nbr = b.nbr_all; co.W = h.out_w; co.bias = h.out_b; co.lt = pl.d_lt; co.out = out;
-  co.rows = rowsAll; co.C = Cin; co.NO = NO; co.mode = mode; co.query_major = query_major;
+  co.X = in; co.ldx = ldin; co.nbr = nbr; co.W = h.out_w; co.bias = h.out_b; co.lt = pl.d_lt;
+  co.out = query_major ? out : out + row0;
+  co.rows = rowsAll; co.C = Cin; co.NO = NO; co.row0 = row0; co.mode = mode; co.query_major = query_major;
   TRY(launch_conv_out(co, st));
   return 0;
 }
@@ -547,6 +573,8 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
     Arena dry{nullptr, 0, 0, true};
     carve(dry, c, T0, Bmax, nq, S, Lk, b);
     if (dry.off > m->arena_bytes) {
+      DCF_CHECK(!m->capturing, "internal: workspace growth during graph capture");
+      drop_graph(m);
       DCF_HIP(hipStreamSynchronize(st));
       if (m->arena) DCF_HIP(hipFree(m->arena));
       m->arena = nullptr; m->arena_bytes = 0;
@@ -595,8 +623,7 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
       GateArgs ga{b.correl, vid_mask, b.gate, b.mask_all, T0, B, q0, c.sn, c.msf, (double)c.sratio};
       TRY(launch_gate(ga, st));
     }
-    for (int l = 1; l < L; ++l) TRY(launch_mask_down(b.mask_all + lt.start[l - 1], b.mask_all + lt.start[l], B * lt.T[l], st));
-    for (int l = 0; l < L; ++l) TRY(launch_rowflags(b.mask_all + lt.start[l], b.nbr_all + lt.start[l], lt.T[l], B * lt.T[l], st));
+    TRY(launch_pyramid_masks(b.mask_all, b.nbr_all, B, T0, L, rowsAll, st));
     const uint8_t* mask0 = b.mask_all;
 
     // ---- vid_map (model.py:543-555)
@@ -604,13 +631,21 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
     if (m->keep_debug && m->dbg_vidmap) DCF_HIP(hipMemcpyAsync(m->dbg_vidmap, b.X, (size_t)rows0 * E * 4, hipMemcpyDeviceToDevice, st));
 
     // ---- text side: pointers of this chunk
-    if (m->meta_next == dcf_model::META_SLOTS) {   // ring wrapped: make sure the old slots were consumed
-      DCF_HIP(hipStreamSynchronize(st));
-      m->meta_next = 0;
+    TextMeta *hm, *dm;
+    if (m->capturing) {                              // the graph owns fixed slots: replays re-read the same pinned memory
+      DCF_CHECK(m->capture_chunk < dcf_model::GRAPH_META_SLOTS, "internal: too many chunks for a captured forward");
+      hm = m->h_meta + m->capture_chunk;
+      dm = m->d_meta + m->capture_chunk;
+      m->capture_chunk++;
+    } else {
+      if (m->meta_next == dcf_model::META_SLOTS) {   // ring wrapped: make sure the old slots were consumed
+        DCF_HIP(hipStreamSynchronize(st));
+        m->meta_next = dcf_model::GRAPH_META_SLOTS;
+      }
+      hm = m->h_meta + m->meta_next;
+      dm = m->d_meta + m->meta_next;
+      m->meta_next++;
     }
-    TextMeta* hm = m->h_meta + m->meta_next;
-    TextMeta* dm = m->d_meta + m->meta_next;
-    m->meta_next++;
     for (int i = 0; i < B; ++i) {
       hm->text[i] = text[q0 + i];
       hm->text_mask[i] = text_mask ? text_mask[q0 + i] : nullptr;
@@ -684,7 +719,9 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
       }
     }
 
-    // ---- heads: fuse_and_predict (model.py:442-471)
+    // ---- heads: fuse_and_predict (model.py:442-471).  (Running cls_head level by level on a side stream while the
+    // main stream continues with the small upper-level encoders was measured: 40 small launches instead of 5 big
+    // ones and CU contention cost more than the overlap gained, 3.45 vs 3.30 ms per step.)
     TRY(run_head(m, m->cls1, b, *pl, E, 1, 0, 0, b.logits1, st));
     {
       RefineArgs ra{};
@@ -753,6 +790,65 @@ int dcf_model_bind(dcf_model* m, const char* name, const float* data, const int6
   return 0;
 }
 
+namespace dcf {
+// eager on the first call with a given argument set, capture + replay from the second identical call on
+static int forward_maybe_graph(dcf_model* m, const float* vid, const float* shallow, const uint8_t* vid_mask, int T0, int nq,
+                               const float* const* text, const uint8_t* const* text_mask, const int32_t* text_len,
+                               const float* text_cls, const float* gate, float* lo, float* oo, uint8_t* mo, hipStream_t st) {
+  static const bool no_graph = getenv("DCF_NO_GRAPH") != nullptr;
+  const int Bmax = std::min(nq, m->cfg.max_batch > 0 ? m->cfg.max_batch : 8);
+  const bool eligible = !no_graph && !g_prof_on && !m->keep_debug && nq > 0 && (nq + Bmax - 1) / Bmax <= dcf_model::GRAPH_META_SLOTS;
+  if (!eligible) return forward(m, vid, shallow, vid_mask, T0, nq, text, text_mask, text_len, text_cls, gate, lo, oo, mo, st);
+  std::vector<uint64_t> key = {(uint64_t)vid, (uint64_t)shallow, (uint64_t)vid_mask, (uint64_t)T0, (uint64_t)nq, (uint64_t)text_cls,
+                               (uint64_t)gate, (uint64_t)lo, (uint64_t)oo, (uint64_t)mo, (uint64_t)st, (uint64_t)m->pe, (uint64_t)m->pe_T};
+  for (int q = 0; q < nq; ++q) {
+    key.push_back((uint64_t)text[q]);
+    key.push_back(text_mask ? (uint64_t)text_mask[q] : 0);
+    key.push_back((uint64_t)text_len[q]);
+  }
+  if (m->graph_exec && key == m->graph_key) {
+    DCF_HIP(hipGraphLaunch(m->graph_exec, st));
+    return 0;
+  }
+  if (key != m->last_key) {                          // first sighting: run eagerly (allocates workspace / plans)
+    m->last_key = key;
+    return forward(m, vid, shallow, vid_mask, T0, nq, text, text_mask, text_len, text_cls, gate, lo, oo, mo, st);
+  }
+  // second identical call: capture
+  drop_graph(m);
+  m->last_key = key;
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    return forward(m, vid, shallow, vid_mask, T0, nq, text, text_mask, text_len, text_cls, gate, lo, oo, mo, st);
+  }
+  m->capturing = true;
+  m->capture_chunk = 0;
+  const int rc = forward(m, vid, shallow, vid_mask, T0, nq, text, text_mask, text_len, text_cls, gate, lo, oo, mo, st);
+  m->capturing = false;
+  hipGraph_t g = nullptr;
+  const hipError_t ec = hipStreamEndCapture(st, &g);
+  if (rc != 0 || ec != hipSuccess || !g) {           // capture failed: nothing ran; fall back to an eager forward
+    (void)hipGetLastError();
+    if (g) (void)hipGraphDestroy(g);
+    const std::string err = g_err;
+    const int rc2 = forward(m, vid, shallow, vid_mask, T0, nq, text, text_mask, text_len, text_cls, gate, lo, oo, mo, st);
+    if (rc2 != 0 && !err.empty()) g_err = err;
+    return rc2;
+  }
+  hipGraphExec_t ge = nullptr;
+  if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipGraphDestroy(g);
+    return forward(m, vid, shallow, vid_mask, T0, nq, text, text_mask, text_len, text_cls, gate, lo, oo, mo, st);
+  }
+  m->graph = g;
+  m->graph_exec = ge;
+  m->graph_key = key;
+  DCF_HIP(hipGraphLaunch(ge, st));
+  return 0;
+}
+}  // namespace dcf
+
 int dcf_model_set_pe(dcf_model* m, const float* pe_tokens, int64_t T) {
   DCF_CHECK(m, "dcf_model_set_pe: null model");
   m->pe = pe_tokens;
@@ -777,8 +873,8 @@ int dcf_forward_eval(dcf_model* m, const float* vid, const float* shallow_vid, c
   DCF_CHECK(m && vid && shallow_vid && vid_mask && text && text_len && text_cls && logits_out && offsets_out && masks_out,
             "dcf_forward_eval: null argument");
   DCF_CHECK(T < (1ll << 24), "T too large");
-  return dcf::forward(m, vid, shallow_vid, vid_mask, (int)T, nq, text, text_mask, text_len, text_cls, nullptr, logits_out,
-                      offsets_out, masks_out, (hipStream_t)stream);
+  return dcf::forward_maybe_graph(m, vid, shallow_vid, vid_mask, (int)T, nq, text, text_mask, text_len, text_cls, nullptr,
+                                  logits_out, offsets_out, masks_out, (hipStream_t)stream);
 }
 
 int dcf_forward_eval_gated(dcf_model* m, const float* vid, const float* shallow_vid, const uint8_t* vid_mask, int64_t T,
@@ -787,8 +883,8 @@ int dcf_forward_eval_gated(dcf_model* m, const float* vid, const float* shallow_
   DCF_CHECK(m && vid && shallow_vid && vid_mask && text && text_len && gate && logits_out && offsets_out && masks_out,
             "dcf_forward_eval_gated: null argument");
   DCF_CHECK(T < (1ll << 24), "T too large");
-  return dcf::forward(m, vid, shallow_vid, vid_mask, (int)T, nq, text, text_mask, text_len, nullptr, gate, logits_out,
-                      offsets_out, masks_out, (hipStream_t)stream);
+  return dcf::forward_maybe_graph(m, vid, shallow_vid, vid_mask, (int)T, nq, text, text_mask, text_len, nullptr, gate,
+                                  logits_out, offsets_out, masks_out, (hipStream_t)stream);
 }
 
 int dcf_debug_copy(dcf_model* m, int32_t what, float* dst, int64_t max_floats, void* stream) {

@@ -75,13 +75,14 @@ int launch_split_planes(const float* W, unsigned short* out, int N, int K, int64
 }
 
 template <int WM, int WN, int TM, int TN, int AMODE, int NTERMS>
-__global__ __launch_bounds__(256) void gemm_bf16s_kernel(GemmBatch batch) {
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16s_kernel(GemmBatch batch) {
+  constexpr int NT = WM * WN * 64;                    // 4 or 8 wavefronts
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
   constexpr int NPL = NTERMS == 6 ? 3 : 2;            // planes used: hi, mid (, lo)
-  constexpr int ACH = BM * 4 / 256;                   // 8-float chunks of the A tile per thread
+  constexpr int ACH = BM * 4 / NT;                    // 8-float chunks of the A tile per thread
   constexpr int BLK = 2 * 3 * 64 * 8;                 // bf16 elements of one weight block (6 KiB)
-  static_assert(WM * WN == 4 && (BM * 4) % 256 == 0, "tile/threads mismatch");
+  static_assert((WM * WN == 4 || WM * WN == 8) && (BM * 4) % NT == 0, "tile/threads mismatch");
   static_assert(AMODE == A_ROWS || AMODE == A_ROWS_TAP3, "channel-major A stays on the fp32 kernel");
 
   extern __shared__ unsigned char smem_b[];
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kernel(GemmBatch batch) {
   unsigned a_flag[ACH];
 #pragma unroll
   for (int i = 0; i < ACH; ++i) {
-    const int id = i * 256 + tid;
+    const int id = i * NT + tid;
     const int row = id >> 2, c8 = id & 3;
     const int m = m0 + row;
     unsigned f = 0;
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kernel(GemmBatch batch) {
   auto store_a = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
-      const int id = i * 256 + tid;
+      const int id = i * NT + tid;
       const int row = id >> 2, c8 = id & 3;
       unsigned h0, h1, h2, h3, m0_, m1, m2, m3, l0, l1, l2, l3;
       split2(araw[i][0].x, araw[i][0].y, h0, m0_, l0);
@@ -230,7 +231,7 @@ static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterm
                  4.0 * count * ((double)p.M * p.K / (mode == A_ROWS_TAP3 ? 3 : 1) + 1.5 * (double)p.N * p.K + (double)p.M * p.N * ((p.flags & G_RES) ? 2 : 1)));
   const int npl = nterms == 6 ? 3 : 2;
   const size_t lds = (size_t)npl * BM * ROWB;
-#define LS(MODE_, NT_) hipLaunchKernelGGL((gemm_bf16s_kernel<WM, WN, TM, TN, MODE_, NT_>), grid, dim3(256), lds, stream, b)
+#define LS(MODE_, NT_) hipLaunchKernelGGL((gemm_bf16s_kernel<WM, WN, TM, TN, MODE_, NT_>), grid, dim3(WM * WN * 64), lds, stream, b)
   if (mode == A_ROWS) { if (nterms == 6) LS(A_ROWS, 6); else LS(A_ROWS, 3); }
   else { if (nterms == 6) LS(A_ROWS_TAP3, 6); else LS(A_ROWS_TAP3, 3); }
 #undef LS
@@ -261,6 +262,16 @@ int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, 
   const int N = p.N;
   auto wgs = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * (N / bn) * count; };
   constexpr long WANT = 512;            // >= 2 workgroups per CU
+  static const char* forced = getenv("DCF_GEMM_CFG");      // experiments: tools/gemm_sweep.py
+  if (forced) {
+    int bm = 0, bn = 0;
+    if (sscanf(forced, "%dx%d", &bm, &bn) == 2 && bn > 0 && N % bn == 0) {
+      if (bm == 64 && bn == 256) return launch_cfg_s<1, 4, 2, 2>(b, count, mode, nterms, stream);
+      if (bm == 64 && bn == 128) return launch_cfg_s<1, 4, 2, 1>(b, count, mode, nterms, stream);
+      if (bm == 64 && bn == 64) return launch_cfg_s<2, 2, 1, 1>(b, count, mode, nterms, stream);
+      if (bm == 128 && bn == 128) return launch_cfg_s<2, 2, 2, 2>(b, count, mode, nterms, stream);
+    }
+  }
   if (N % 256 == 0 && wgs(64, 256) >= WANT) return launch_cfg_s<1, 4, 2, 2>(b, count, mode, nterms, stream);   // 64x256, 64x64 per wave
   if (N % 96 == 0 && N % 64 != 0) return launch_cfg_s<4, 1, 1, 3>(b, count, mode, nterms, stream);              // 128x96 (N = 288)
   if (N % 160 == 0 && N % 64 != 0) return launch_cfg_s<4, 1, 1, 5>(b, count, mode, nterms, stream);             // 128x160

@@ -27,6 +27,7 @@ struct ConvOutArgs {
   const LevelTable* lt;
   float* out;
   int rows, C, NO;
+  int row0;                           // pyramid row of X[0] (X, nbr and, for internal order, out are pre-offset by it)
   int mode;                           // 0: raw logits   1: relu(scale_l * y)  (RegHead, head.py:102-103)
   int query_major;                    // 0: out[row*NO+o] (internal order)   1: out[(b*S + off_l + t)*NO + o]
 };

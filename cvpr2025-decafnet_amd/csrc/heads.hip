@@ -50,10 +50,10 @@ __global__ __launch_bounds__(256) void k_conv_out(ConvOutArgs p) {
   for (int o = 0; o < NO; ++o) acc[o] = wave_sum(acc[o]);
   if (lane == 0) {
     const LevelTable* lt = p.lt;
-    const int l = find_level(lt, r);
+    const int l = find_level(lt, p.row0 + r);
     int64_t dst = r;
     if (p.query_major) {
-      const int rel = r - lt->start[l];
+      const int rel = p.row0 + r - lt->start[l];
       const int b = rel / lt->T[l], t = rel - b * lt->T[l];
       dst = (int64_t)b * lt->S + lt->off[l] + t;
     }

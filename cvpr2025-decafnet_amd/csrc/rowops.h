@@ -57,6 +57,7 @@ struct TextLnArgs {
 };
 
 int launch_rowflags(const uint8_t* mask, uint8_t* nbr, int T, int rows, hipStream_t st);
+int launch_pyramid_masks(uint8_t* mask_all, uint8_t* nbr_all, int B, int T0, int L, int rows_all, hipStream_t st);
 int launch_mask_down(const uint8_t* in, uint8_t* out, int rows_out, hipStream_t st);
 int launch_vidmap_combine(const float* P1, const float* P2, const float* bias, const float* gate, const uint8_t* mask,
                           float* X, int T, int rows, int E, hipStream_t st);

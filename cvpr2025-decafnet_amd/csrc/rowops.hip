@@ -32,6 +32,26 @@ __global__ void k_rowflags(const uint8_t* __restrict__ mask, uint8_t* __restrict
   nbr[r] = (uint8_t)f;
 }
 
+// All pyramid levels at once: mask_l[b][i] = mask_0[b][i << l] (l applications of the stride-2 MaskedConv1D mask rule
+// mask[2i], blocks.py:101-105) and the k3 neighbour flags of every level.  rows are ordered [level][b][t]; start[l] =
+// B * sum_{j<l} (T0 >> j).  One launch instead of 2L - 1.
+__global__ void k_pyramid_masks(uint8_t* __restrict__ mask_all, uint8_t* __restrict__ nbr_all, int B, int T0, int L, int rows_all) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows_all) return;
+  int l = 0, start = 0;
+  while (l + 1 < L && r >= start + B * (T0 >> l)) { start += B * (T0 >> l); ++l; }
+  const int T = T0 >> l;
+  const int rel = r - start, b = rel / T, t = rel - b * T;
+  const uint8_t* m0 = mask_all + (size_t)b * T0;            // level 0 occupies rows [0, B*T0)
+  auto at = [&](int tt) { return m0[(size_t)tt << l] != 0; };
+  const bool self = at(t);
+  unsigned f = self ? 1u : 0u;
+  if (t > 0 && at(t - 1)) f |= 2u;
+  if (t < T - 1 && at(t + 1)) f |= 4u;
+  nbr_all[r] = (uint8_t)f;
+  if (l > 0) mask_all[r] = self ? 1 : 0;
+}
+
 // stride-2 MaskedConv1D mask: nearest downsample == mask[2i] (libs/modeling/blocks.py:101-105)
 __global__ void k_mask_down(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int rows_out) {
   int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -296,6 +316,13 @@ __global__ __launch_bounds__(64) void k_text_ln(TextLnArgs p) {
 int launch_rowflags(const uint8_t* mask, uint8_t* nbr, int T, int rows, hipStream_t st) {
   if (rows <= 0) return 0;
   hipLaunchKernelGGL(k_rowflags, dim3((rows + 255) / 256), dim3(256), 0, st, mask, nbr, T, rows);
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_pyramid_masks(uint8_t* mask_all, uint8_t* nbr_all, int B, int T0, int L, int rows_all, hipStream_t st) {
+  if (rows_all <= 0) return 0;
+  hipLaunchKernelGGL(k_pyramid_masks, dim3((rows_all + 255) / 256), dim3(256), 0, st, mask_all, nbr_all, B, T0, L, rows_all);
   DCF_HIP(hipGetLastError());
   return 0;
 }

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 SHAPES = [(16384, 256, 256), (16384, 1024, 256), (16384, 256, 1024), (16384, 512, 256), (8192, 256, 256), (8192, 1024, 256),
           (8192, 256, 1024), (2048, 256, 256), (2048, 256, 1024), (512, 256, 256), (512, 256, 1024), (128, 1024, 256), (131072, 256, 256),
           (131072, 256, 1024)]
-TILES = ['f32:auto', 'x6:auto', 'x6:64x256', 'x6:64x128', 'x6:64x64', 'x6:128x128', 'x6:128x64', 'x3:auto']
+TILES = ['f32:auto', 'x6:auto', 'x6:64x256', 'x6:128x256', 'x6:256x128', 'x6:128x128', 'x6:64x128', 'x3:auto']
 
 def child():
     import torch
