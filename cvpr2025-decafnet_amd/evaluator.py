@@ -5,17 +5,75 @@
     GroundingEvaluator.predict   _forward (930-1026) + _generate_proposals (1063-1129):
         pad -> encode_text -> model(..., eval=True) -> collect_segments -> batched NMS -> seconds
 
-The metric loop (R@k / IoU counting, worker_v2.py:857-910) and data loading are out of scope.
+    iou, RecallCounter  libs/train_utils.py:81-96 and the metric loop of Evaluator.run, worker_v2.py:857-878, 890-901
+    load_features       feature-file formats of libs/data/dataset.py:128-135, 398-399 ((T, C) on disk -> (C, T))
 """
 from __future__ import annotations
 
 import time
 from collections import defaultdict
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
 from . import nms as _nms
+
+
+def iou(pred_segs, gt_segs):
+    """libs/train_utils.py:81-96: 1-D IoU of (..., 2) segments (no epsilon)."""
+    ps, pe = pred_segs[..., 0], pred_segs[..., 1]
+    gs, ge = gt_segs[..., 0], gt_segs[..., 1]
+    overlap = (torch.minimum(pe, ge) - torch.maximum(ps, gs)).clamp(min=0)
+    union = (pe - ps) + (ge - gs) - overlap
+    return overlap / union
+
+
+class RecallCounter:
+    """Rank@k / IoU@t counting of Evaluator.run (worker_v2.py:857-878) and its report (890-901)."""
+
+    def __init__(self, ranks=(1, 5), iou_threshs=(0.3, 0.5)):
+        self.ranks = tuple(ranks)
+        self.topk = max(self.ranks)
+        self.iou_threshs = np.array(iou_threshs)
+        self.counts = np.zeros((len(self.ranks), len(self.iou_threshs)))
+        self.text_cnt = 0
+
+    def update(self, results, targets):
+        assert len(results) == len(targets)
+        for result, target in zip(results, targets):
+            segs, scores = result['segments'].cpu(), result['scores'].cpu()
+            idx = scores.argsort(descending=True)
+            segs = segs[idx[:self.topk]]
+            target = torch.as_tensor(target, dtype=torch.float).expand(len(segs), -1)
+            iou_topk = iou(segs, target)
+            iou_n = np.array([iou_topk[:k].max().item() if len(iou_topk[:k]) > 0 else 0 for k in self.ranks])
+            self.counts += (iou_n[:, None] >= self.iou_threshs[None])
+        self.text_cnt += len(targets)
+
+    def metrics(self):
+        return self.counts / max(self.text_cnt, 1)
+
+    def report(self):
+        m = self.metrics()
+        s = "\nFinal:"
+        for i, rank in enumerate(self.ranks):
+            s += "\n-----"
+            for j, thresh in enumerate(self.iou_threshs):
+                s += f"\nRank@{rank}, IoU@{thresh:.1f}: {(m[i, j] * 100):.2f}"
+        return s + "\n-----\n"
+
+
+def load_features(path_without_ext: str, fmt: str = 'npy'):
+    """Pre-extracted clip features as the reference stores them (libs/data/dataset.py:128-135): (T, C) on disk,
+    returned channel-major (C, T) float32 like ``_load_vid_feats`` (:398-399)."""
+    if fmt == 'npy':
+        a = np.load(path_without_ext + '.npy').astype(np.float32)
+    elif fmt == 'pt':
+        a = torch.load(path_without_ext + '.pt').numpy().astype(np.float32)
+    else:
+        raise NotImplementedError(f'feature format {fmt!r}')
+    return torch.from_numpy(np.ascontiguousarray(a.transpose()))
 
 
 def min_chunk_size(num_fpn_levels: int, mha_win_size: int) -> int:
@@ -109,3 +167,11 @@ class GroundingEvaluator:
     def predict(self, data):
         flat, T = self.forward(data)
         return self.generate_proposals(flat, T, data)
+
+    def run(self, dataset, counter: RecallCounter = None):
+        """Evaluator.run (worker_v2.py:815-910) over an iterable of per-video dicts (keys as in
+        libs/data/dataset.py:977-994: vid, shallow_vid, text, text_cls, segment, fps, clip_stride, clip_size, duration)."""
+        counter = counter or RecallCounter(self.opt['eval'].get('ranks', (1, 5)), self.opt['eval'].get('iou_threshs', (0.3, 0.5)))
+        for data in dataset:
+            counter.update(self.predict(data), data['segment'])
+        return counter

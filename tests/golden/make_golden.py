@@ -318,6 +318,25 @@ def gen_postproc():
             sec = (sec * 16 + 0.5 * 32) / 30.0
             sec = torch.clamp(sec, min=0, max=1000.0)
         out[f'{k}/seconds'] = sec
+    # metric loop of Evaluator.run (worker_v2.py:857-878, 890-901) on the soft_novote results against synthetic targets
+    from libs.train_utils import iou
+    import numpy as np
+    segs, scores = out['soft_novote/seconds'], out['soft_novote/scores']
+    ranks, iou_threshs = (1, 5), np.array((0.3, 0.5))
+    targets = [(float(segs[0, 0]) - 1.0, float(segs[0, 1]) + 2.0), (float(segs[3, 0]), float(segs[3, 1])), (500.0, 510.0)]
+    counts = np.zeros((len(ranks), len(iou_threshs)))
+    iou_rows = []
+    for tgt in targets:
+        idx = scores.argsort(descending=True)
+        s = segs[idx[:max(ranks)]]
+        t = torch.as_tensor(tgt, dtype=torch.float).expand(len(s), -1)
+        iou_topk = iou(s, t)
+        iou_n = np.array([iou_topk[:i].max().item() if len(iou_topk[:i]) > 0 else 0 for i in ranks])
+        counts += (iou_n[:, None] >= iou_threshs[None])
+        iou_rows.append(iou_topk)
+    out['metric/targets'] = torch.tensor(targets)
+    out['metric/iou_topk'] = torch.stack(iou_rows)
+    out['metric/counts'] = torch.from_numpy(counts)
     save('postproc.npz', out)
 
 

@@ -119,3 +119,25 @@ def test_padded_length_rule():
     assert ev.padded_length(16000, 2304, 8, 9) == 16384
     assert ev.padded_length(16384, 2304, 8, 9) == 16384
     assert ev.padded_length(65530, 2304, 8, 9) == 65536
+
+
+def test_metric_loop_matches_reference(tmp_path):
+    """R@k / IoU counting (worker_v2.py:857-878) and the (T,C)->(C,T) feature loader against the reference fixture"""
+    import numpy as np
+    pkg = load_pkg()
+    ev = pkg.evaluator
+    g = Golden('postproc.npz')
+    segs, scores = g.t('soft_novote/seconds'), g.t('soft_novote/scores')
+    targets = [tuple(t.tolist()) for t in g.t('metric/targets')]
+    c = ev.RecallCounter((1, 5), (0.3, 0.5))
+    for tgt in targets:
+        c.update([{'segments': segs, 'scores': scores}], [tgt])
+    assert np.array_equal(c.counts, g.t('metric/counts').numpy())
+    assert c.text_cnt == 3 and 'Rank@1, IoU@0.3' in c.report()
+    idx = scores.argsort(descending=True)
+    t0 = torch.as_tensor(targets[0]).expand(5, -1)
+    torch.testing.assert_close(ev.iou(segs[idx[:5]], t0), g.t('metric/iou_topk')[0])
+    a = np.random.RandomState(0).randn(7, 3).astype(np.float32)
+    np.save(tmp_path / 'v.npy', a)
+    f = ev.load_features(str(tmp_path / 'v'), 'npy')
+    assert f.shape == (3, 7) and torch.equal(f, torch.from_numpy(a.T.copy()))
