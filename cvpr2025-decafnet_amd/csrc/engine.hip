@@ -311,7 +311,11 @@ static int finalize(dcf_model* m, hipStream_t st) {
   m->tcn_wd.clear(); m->tcn_bd.clear(); m->tcn_wp.clear(); m->tcn_bp.clear(); m->tcn_lnw.clear(); m->tcn_lnb.clear();
   const float* t;
 
-  GET("vid_map.conv.weight", SH(E, Din), m->vid_map_w); GET("vid_map.conv.bias", SH(E), m->vid_map_b);
+  if (c.model_kind == 1) {   // PtTransformer: vid_net.embd_fc takes the (2)D-wide gated input itself (model.py:43-48)
+    GET("vid_net.embd_fc.conv.weight", SH(E, Din), m->vid_map_w); GET("vid_net.embd_fc.conv.bias", SH(E), m->vid_map_b);
+  } else {
+    GET("vid_map.conv.weight", SH(E, Din), m->vid_map_w); GET("vid_map.conv.bias", SH(E), m->vid_map_b);
+  }
   for (int i = 0; i < c.fusion_layers; ++i) {
     const std::string p = "fusion.layers." + std::to_string(i);
     DecW w{};
@@ -332,8 +336,10 @@ static int finalize(dcf_model* m, hipStream_t st) {
     m->dec.push_back(w);
   }
   GET("fusion.ln_out.weight", SH(E), m->fus_out_w); GET("fusion.ln_out.bias", SH(E), m->fus_out_b);
-  GET("vid_net.embd_fc.conv.weight", SH(E, E), m->embd_fc_w); GET("vid_net.embd_fc.conv.bias", SH(E), m->embd_fc_b);
-  SPLIT(m->embd_fc_w, E, E);
+  if (c.model_kind == 0) {
+    GET("vid_net.embd_fc.conv.weight", SH(E, E), m->embd_fc_w); GET("vid_net.embd_fc.conv.bias", SH(E), m->embd_fc_b);
+    SPLIT(m->embd_fc_w, E, E);
+  }
   for (int i = 0; i < c.n_embd_convs; ++i) {
     const std::string s = std::to_string(i);
     GET("vid_net.embd_convs." + s + ".conv.weight", SH(E, E, 3), t);
@@ -356,13 +362,15 @@ static int finalize(dcf_model* m, hipStream_t st) {
     m->branch.push_back(w);
   }
   if (resolve_head(m, "cls_head", "cls_head", E, 1, c.head_layers, st, m->cls1)) return -1;
-  if (resolve_head(m, "cls_head2", "cls_head", E + TCN_HID, 1, c.head_layers, st, m->cls2)) return -1;
-  if (resolve_head(m, "reg_head", "reg_head", E + TCN_HID, 2, c.head_layers, st, m->reg)) return -1;
+  const int EH = c.model_kind == 1 ? E : E + TCN_HID;
+  if (c.model_kind == 0 && resolve_head(m, "cls_head2", "cls_head", EH, 1, c.head_layers, st, m->cls2)) return -1;
+  if (resolve_head(m, "reg_head", "reg_head", EH, 2, c.head_layers, st, m->reg)) return -1;
   m->reg_scales.assign(L, 1.f);
   for (int l = 0; l < L; ++l) {
     GET("reg_head.scales." + std::to_string(l) + ".scale", SH(1), t);
     DCF_HIP(hipMemcpyAsync(&m->reg_scales[l], t, sizeof(float), hipMemcpyDeviceToHost, st));
   }
+  if (c.model_kind == 0) {
   // TCN (refine): in (32, L, 1) -> [L][32]; dilated (32,32,3) -> [3][ci][co]; 1x1 (32,32,1) -> [ci][co]
   GET("refine.conv_1x1.weight", SH(TCN_HID, L), t); if (pack3(m, t, 1, TCN_HID, L, 0, 2, 1, st, &m->tcn_in_w)) return -1;
   GET("refine.conv_1x1.bias", SH(TCN_HID), m->tcn_in_b);
@@ -383,6 +391,7 @@ static int finalize(dcf_model* m, hipStream_t st) {
   GET("refine.conv_out.weight", SH(TCN_HID, TCN_HID), t);
   if (pack3(m, t, 1, TCN_HID, TCN_HID, 0, 2, 1, st, &m->tcn_out_w)) return -1;
   GET("refine.conv_out.bias", SH(TCN_HID), m->tcn_out_b);
+  }
   DCF_HIP(hipStreamSynchronize(st));
   for (auto& pl : m->plans) if (pl.d_lt) (void)hipFree(pl.d_lt);
   m->plans.clear();                           // reg scales live in the level tables
@@ -413,6 +422,7 @@ struct Buffers {
 
 static void carve(Arena& a, const dcf_config& c, int T0, int B, int nq, int S, int Lk, Buffers& b) {
   const size_t rows0 = (size_t)B * T0, rowsAll = (size_t)B * S;
+  const size_t rowsF = (c.model_kind == 1 || c.second_fusion) ? rowsAll : rows0;   // rows the fusion stack sees
   const int E = c.E, EH = c.E + TCN_HID;
   b.P1 = a.take<float>((size_t)T0 * E);
   b.P2 = a.take<float>((size_t)T0 * E);
@@ -424,9 +434,9 @@ static void carve(Arena& a, const dcf_config& c, int T0, int B, int nq, int S, i
   b.nbr_all = a.take<uint8_t>(rowsAll);
   b.kvmask = a.take<uint8_t>((size_t)B * Lk);
   b.X = a.take<float>(rows0 * E);
-  for (int i = 0; i < 7; ++i) b.R[i] = a.take<float>(rows0 * E);
-  b.H2 = a.take<float>(rows0 * 2 * E);
-  b.HID = a.take<float>(rows0 * 4 * E);
+  for (int i = 0; i < 7; ++i) b.R[i] = a.take<float>((i < 3 ? rowsF : rows0) * E);
+  b.H2 = a.take<float>(rowsF * 2 * E);
+  b.HID = a.take<float>(rowsF * 4 * E);
   b.F = a.take<float>(rowsAll * EH);
   b.HA = a.take<float>(rowsAll * EH);
   b.HB = a.take<float>(rowsAll * EH);
@@ -545,6 +555,50 @@ static int run_head(dcf_model* m, const HeadW& h, Buffers& b, const Plan& pl, in
   return 0;
 }
 
+// XAttNFusion._forward (fusion.py:56-66): n x TransformerDecoder (blocks.py:632-650) + ln_out.
+// X [rows][ldx] is updated in place; the final ln_out goes to out [rows][ld_out].  Either one level of B sequences
+// of T rows (lt == nullptr) or the whole pyramid (lt != nullptr: rows ordered [level][b][t], neighbour flags `nbr`
+// delimit the sequences for the depthwise conv, the attention core is launched per level).
+static int run_fusion(dcf_model* m, Buffers& b, float* X, int64_t ldx, int B, int T, const LevelTable* lt, const uint8_t* mask,
+                      const uint8_t* nbr, TextMeta* dm, int Lk, float* out, int64_t ld_out, hipStream_t st) {
+  const dcf_config& c = m->cfg;
+  const int E = c.E;
+  const int rows = lt ? lt->start[lt->n_levels] : B * T;
+  for (size_t li = 0; li < m->dec.size(); ++li) {
+    const DecW& w = m->dec[li];
+    DecPreArgs dp{X, ldx, mask, w.ln_q_w, w.ln_q_b, w.dw, w.qn_w, w.qn_b, b.R[0], b.R[1], lt ? 1 : B, lt ? rows : T, E};
+    dp.nbr = lt ? nbr : nullptr;
+    TRY(launch_dec_pre(dp, st));
+    GemmArgs gq = gemm(b.R[0], E, w.wq, w.bq, b.R[2], E, rows, E, E);
+    TRY(run_gemm(m, &gq, 1, A_ROWS, st));
+    TextLnArgs tl{dm, b.kvn, b.kvmask, w.ln_kv_w, w.ln_kv_b, Lk, c.TE};
+    TRY(launch_text_ln(tl, B, st));
+    GemmArgs gkv[2] = {gemm(b.kvn, c.TE, w.wk, w.bk, b.Kt, E, B * Lk, E, c.TE), gemm(b.kvn, c.TE, w.wv, w.bv, b.Vt, E, B * Lk, E, c.TE)};
+    TRY(run_gemm(m, gkv, 2, A_ROWS, st));
+    if (lt) {
+      for (int l = 0; l < lt->n_levels; ++l) {
+        XAttnArgs xa{b.R[2] + (int64_t)lt->start[l] * E, b.Kt, b.Vt, b.kvmask, b.R[0] + (int64_t)lt->start[l] * E, B, lt->T[l], Lk, E, c.fusion_heads};
+        TRY(launch_xattn(xa, st));
+      }
+    } else {
+      XAttnArgs xa{b.R[2], b.Kt, b.Vt, b.kvmask, b.R[0], B, T, Lk, E, c.fusion_heads};
+      TRY(launch_xattn(xa, st));
+    }
+    GemmArgs gh = gemm(b.R[0], E, w.wp, w.bp, b.H2, 2 * E, rows, 2 * E, E);
+    TRY(run_gemm(m, &gh, 1, A_ROWS, st));
+    TRY(launch_dec_mid(b.R[1], b.H2, w.ln_ffn_w, w.ln_ffn_b, b.R[2], b.R[0], rows, E, st));
+    GemmArgs gf = gemm(b.R[0], E, w.fc_w, w.fc_b, b.HID, 4 * E, rows, 4 * E, E);
+    gf.flags = G_GELU;
+    TRY(run_gemm(m, &gf, 1, A_ROWS, st));
+    GemmArgs go = gemm(b.HID, 4 * E, w.pj_w, w.pj_b, X, ldx, rows, E, 4 * E);
+    go.flags = G_RES | G_OUT_MASK; go.rowmask = mask; go.ls = w.ls_ffn; go.R = b.R[2]; go.ldr = E;
+    TRY(run_gemm(m, &go, 1, A_ROWS, st));
+  }
+  LnArgs ln{}; ln.X = X; ln.ldx = ldx; ln.Y = out; ln.ldy = ld_out; ln.w = m->fus_out_w; ln.b = m->fus_out_b; ln.rows = rows; ln.C = E;
+  TRY(launch_ln(ln, st));
+  return 0;
+}
+
 static int forward(dcf_model* m, const float* vid, const float* shallow, const uint8_t* vid_mask, int T0, int nq,
                    const float* const* text, const uint8_t* const* text_mask, const int32_t* text_len,
                    const float* text_cls, const float* gate_override, float* logits_out, float* offsets_out,
@@ -653,40 +707,19 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
     }
     DCF_HIP(hipMemcpyAsync(dm, hm, sizeof(TextMeta), hipMemcpyHostToDevice, st));
 
-    // ---- fusion: XAttNFusion (fusion.py:56-66)
-    for (size_t li = 0; li < m->dec.size(); ++li) {
-      const DecW& w = m->dec[li];
-      DecPreArgs dp{b.X, E, mask0, w.ln_q_w, w.ln_q_b, w.dw, w.qn_w, w.qn_b, b.R[0], b.R[1], B, T0, E};
-      TRY(launch_dec_pre(dp, st));
-      GemmArgs gq = gemm(b.R[0], E, w.wq, w.bq, b.R[2], E, rows0, E, E);
-      TRY(run_gemm(m, &gq, 1, A_ROWS, st));
-      TextLnArgs tl{dm, b.kvn, b.kvmask, w.ln_kv_w, w.ln_kv_b, Lk, c.TE};
-      TRY(launch_text_ln(tl, B, st));
-      GemmArgs gkv[2] = {gemm(b.kvn, c.TE, w.wk, w.bk, b.Kt, E, B * Lk, E, c.TE), gemm(b.kvn, c.TE, w.wv, w.bv, b.Vt, E, B * Lk, E, c.TE)};
-      TRY(run_gemm(m, gkv, 2, A_ROWS, st));
-      XAttnArgs xa{b.R[2], b.Kt, b.Vt, b.kvmask, b.R[0], B, T0, Lk, E, c.fusion_heads};
-      TRY(launch_xattn(xa, st));
-      GemmArgs gh = gemm(b.R[0], E, w.wp, w.bp, b.H2, 2 * E, rows0, 2 * E, E);
-      TRY(run_gemm(m, &gh, 1, A_ROWS, st));
-      TRY(launch_dec_mid(b.R[1], b.H2, w.ln_ffn_w, w.ln_ffn_b, b.R[2], b.R[0], rows0, E, st));
-      GemmArgs gf = gemm(b.R[0], E, w.fc_w, w.fc_b, b.HID, 4 * E, rows0, 4 * E, E);
-      gf.flags = G_GELU;
-      TRY(run_gemm(m, &gf, 1, A_ROWS, st));
-      GemmArgs go = gemm(b.HID, 4 * E, w.pj_w, w.pj_b, b.X, E, rows0, E, 4 * E);
-      go.flags = G_RES | G_OUT_MASK; go.rowmask = mask0; go.ls = w.ls_ffn; go.R = b.R[2]; go.ldr = E;
-      TRY(run_gemm(m, &go, 1, A_ROWS, st));
-    }
-    {
-      LnArgs ln{}; ln.X = b.X; ln.ldx = E; ln.Y = b.R[0]; ln.ldy = E; ln.w = m->fus_out_w; ln.b = m->fus_out_b; ln.rows = rows0; ln.C = E;
-      TRY(launch_ln(ln, st));
+    // ---- early fusion: XAttNFusion on the level-0 sequence (fusion.py:56-66)
+    if (c.model_kind == 0) {
+      TRY(run_fusion(m, b, b.X, E, B, T0, nullptr, mask0, nullptr, dm, Lk, b.R[0], E, st));
       if (m->keep_debug && m->dbg_fused) DCF_HIP(hipMemcpyAsync(m->dbg_fused, b.R[0], (size_t)rows0 * E * 4, hipMemcpyDeviceToDevice, st));
     }
 
     // ---- vid_net: VideoTransformer.forward (video_net.py:123-164)
     {
-      GemmArgs ge = gemm(b.R[0], E, m->embd_fc_w, m->embd_fc_b, b.X, E, rows0, E, E);
-      ge.flags = G_AMASK; ge.rowmask = mask0;
-      TRY(run_gemm(m, &ge, 1, A_ROWS, st));
+      if (c.model_kind == 0) {
+        GemmArgs ge = gemm(b.R[0], E, m->embd_fc_w, m->embd_fc_b, b.X, E, rows0, E, E);
+        ge.flags = G_AMASK; ge.rowmask = mask0;
+        TRY(run_gemm(m, &ge, 1, A_ROWS, st));
+      }   // late fusion (PtTransformer): b.X already IS embd_fc([gate*vid ; shallow] * mask), model.py:132-140
       for (int i = 0; i < c.n_embd_convs; ++i) {
         GemmArgs g = gemm(b.X, E, m->embd_conv[i], nullptr, b.R[0], E, rows0, E, 3 * E);
         g.cin = E; g.nbr = b.nbr_all;
@@ -719,6 +752,15 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
       }
     }
 
+    // ---- second / late fusion over the whole pyramid (model.py:443-444, :66-67; fusion.py:68-78), in place on F
+    if (c.model_kind == 1 || c.second_fusion)
+      TRY(run_fusion(m, b, b.F, E + TCN_HID, B, T0, &lt, b.mask_all, b.nbr_all, dm, Lk, b.F, E + TCN_HID, st));
+
+    if (c.model_kind == 1) {
+      // ---- PtTransformer.fuse_and_predict (model.py:65-69): cls_head / reg_head on the fused pyramid
+      TRY(run_head(m, m->cls1, b, *pl, E, 1, 0, 1, logits_out + (int64_t)q0 * S, st));
+      TRY(run_head(m, m->reg, b, *pl, E, 2, 1, 1, offsets_out + (int64_t)q0 * S * 2, st));
+    } else {
     // ---- heads: fuse_and_predict (model.py:442-471).  (Running cls_head level by level on a side stream while the
     // main stream continues with the small upper-level encoders was measured: 40 small launches instead of 5 big
     // ones and CU contention cost more than the overlap gained, 3.45 vs 3.30 ms per step.)
@@ -736,6 +778,7 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
     }
     TRY(run_head(m, m->cls2, b, *pl, E + TCN_HID, 1, 0, 1, logits_out + (int64_t)q0 * S, st));
     TRY(run_head(m, m->reg, b, *pl, E + TCN_HID, 2, 1, 1, offsets_out + (int64_t)q0 * S * 2, st));
+    }
     hipLaunchKernelGGL(k_masks_out, dim3((rowsAll + 255) / 256), dim3(256), 0, st, (const uint8_t*)b.mask_all,
                        masks_out + (int64_t)q0 * S, (const LevelTable*)pl->d_lt);
     DCF_HIP(hipGetLastError());
@@ -765,6 +808,7 @@ int dcf_model_create(const dcf_config* cfg, dcf_model** out) {
   DCF_CHECK(cfg->win > 0 && (cfg->win & 1), "mha_win_size=%d must be odd and > 0 (global self-attention over clips is not on the hot path)", cfg->win);
   DCF_CHECK(cfg->fusion_layers >= 0 && cfg->head_layers >= 0 && cfg->n_embd_convs >= 0 && cfg->n_stem >= 0, "negative layer count");
   DCF_CHECK(cfg->sn >= 1, "sn must be >= 1");
+  DCF_CHECK(cfg->model_kind == 0 || cfg->model_kind == 1, "model_kind must be 0 (iterative early fusion) or 1 (late fusion)");
   int ndev = 0;
   DCF_HIP(hipGetDeviceCount(&ndev));
   DCF_CHECK(ndev > 0, "no HIP device");

@@ -28,6 +28,7 @@ struct DecPreArgs {
   float* Qc; float* Xa;             // [B*T][C]
   int B, T, C;
   int strip;                        // rows per wavefront (filled in by the launcher)
+  const uint8_t* nbr;               // optional [B*T] neighbour flags: several sequences laid back to back (pyramid)
 };
 
 struct EncPreArgs {

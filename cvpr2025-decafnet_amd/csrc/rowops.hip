@@ -171,7 +171,15 @@ __global__ __launch_bounds__(256) void k_dec_pre(DecPreArgs p) {
   for (int t = t0; t < t1; ++t) {
     conv_in(t + 1, raw_n, nxt);
     Row<NCH> q;
-    axpy3(q, prev, cur, nxt, p.dw, C, lane);
+    if (p.nbr) {      // pyramid mode: rows of several sequences back to back, the flags of row t say which neighbours belong to it
+      const unsigned f = p.nbr[base + t];
+      Row<NCH> pz = prev, nz = nxt;
+      if (!(f & 2u)) pz.zero();
+      if (!(f & 4u)) nz.zero();
+      axpy3(q, pz, cur, nz, p.dw, C, lane);
+    } else {
+      axpy3(q, prev, cur, nxt, p.dw, C, lane);
+    }
     row_layernorm(q, C, lane, p.qn_w, p.qn_b);
     q.store(p.Qc + (base + t) * (int64_t)C, C, lane);
     Row<NCH> xa = raw_c;                       // already zero where masked

@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from . import _lib
 
-__all__ = ['PtTransformerEarlyFusionIterative', 'PtGenerator', 'create_model', 'sinusoid_encoding']
+__all__ = ['PtTransformerEarlyFusionIterative', 'PtTransformer', 'PtGenerator', 'create_model', 'sinusoid_encoding']
 
 
 # ------------------------------------------------------------------------------------------
@@ -335,14 +335,13 @@ class PtTransformerEarlyFusionIterative(nn.Module):
     (attribute or item access).  Unlike the reference the constructor does not mutate ``opt``.
     """
 
+    MODEL_KIND = 0
+
     def __init__(self, opt, second_fusion=True):
         super().__init__()
         mo = opt['model'] if isinstance(opt, dict) else opt.model
         mo = copy.deepcopy(mo)
         self.opt = opt
-        if second_fusion:
-            raise NotImplementedError('second_fusion=True (per-level fusion) is not on the hot path; '
-                                      'create_model() uses second_fusion=False (libs/worker_v2.py:191-193)')
         if mo.get('scat', False) or mo.get('sfonly', False):
             raise NotImplementedError('opt.model.scat / sfonly are not supported by the HIP path')
         vn, tn, fu = dict(mo['vid_net']), dict(mo['text_net']), dict(mo['fusion'])
@@ -402,6 +401,7 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         c.sn, c.sratio, c.msf, c.norm = self.sn, self.sratio, int(self.msf), int(self.norm)
         c.use_abs_pe, c.max_batch = int(vn.use_abs_pe), self.max_batch
         c.gemm_mode = self.gemm_mode
+        c.model_kind, c.second_fusion = self.MODEL_KIND, int(bool(self.second_fusion))
         return c
 
     def _named_engine_tensors(self):
@@ -496,6 +496,44 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         of = [tuple(x.unsqueeze(0) for x in offsets[q].split(sizes)) for q in range(nq)]
         mk = [tuple(x.unsqueeze(0) for x in masks[q].split(sizes)) for q in range(nq)]
         return lg, of, mk
+
+
+class PtTransformer(PtTransformerEarlyFusionIterative):
+    """Drop-in for the late-fusion model libs/modeling/model.py:30-161 (exported by libs/modeling/__init__.py:2): the gated
+    [vid ; shallow] features feed ``vid_net`` directly (``vid_net.embd_fc`` is (E, 2D, 1)), the fusion stack is applied to
+    every pyramid level and ``cls_head`` / ``reg_head`` predict from the fused pyramid.  Same forward signature."""
+
+    MODEL_KIND = 1
+
+    def __init__(self, opt):
+        nn.Module.__init__(self)
+        mo = copy.deepcopy(opt['model'] if isinstance(opt, dict) else opt.model)
+        self.opt = opt
+        if mo.get('scat', False) or mo.get('sfonly', False):
+            raise NotImplementedError('opt.model.scat / sfonly are not supported by the HIP path')
+        vn, tn, fu = dict(mo['vid_net']), dict(mo['text_net']), dict(mo['fusion'])
+        self.sn, self.sratio = int(mo['sn']), float(mo['sratio'])
+        self.msf, self.norm = bool(mo['msf']), bool(mo['norm'])
+        D, E = int(vn['in_dim']), int(vn['embd_dim'])
+        self.D, self.E = D, E
+        tn.pop('name', None)
+        self.text_net = TextTransformer(**tn)
+        vn.pop('name', None)
+        vn['in_dim'] = 2 * D if self.msf else D
+        self.vid_net = VideoTransformer(**vn)
+        fu.pop('name', None)
+        self.fusion = XAttNFusion(**fu)
+        ch, rh = dict(mo['cls_head']), dict(mo['reg_head'])
+        n_levels = self.vid_net.arch[2]
+        self.cls_head = ConvHead(ch['embd_dim'], 'cls_head', 1, ch.get('n_layers', 2), None, ch.get('prior_prob', 0.0))
+        self.reg_head = ConvHead(rh['embd_dim'], 'reg_head', 2, rh.get('n_layers', 2), rh.get('num_fpn_levels', n_levels))
+        self.second_fusion = False
+        self.head_layers = ch.get('n_layers', 2)
+        self.max_batch = int(mo.get('max_batch', 0) or 0)
+        self.gemm_mode = {'bf16x6': 6, 'fp32': 1, 'bf16x3': 3}[mo.get('gemm_mode', 'bf16x6')]
+        self._engine = None
+        self.reuse_output_buffers = False
+        self._out_cache = {}
 
 
 def create_model(opt):

@@ -48,6 +48,9 @@ typedef struct dcf_config {
   int32_t max_batch;      /* queries processed together (>= 1); 0 = library default                */
   int32_t gemm_mode;      /* dense-conv arithmetic: 0/6 = fp32-accurate bf16x6 split MFMA (default),
                            * 1 = native fp32 MFMA, 3 = bf16x3 split (~2^-16 per product)           */
+  int32_t model_kind;     /* 0 = PtTransformerEarlyFusionIterative (libs/modeling/model.py:397),
+                           * 1 = PtTransformer, late fusion (model.py:30)                            */
+  int32_t second_fusion;  /* model_kind 0: also fuse every pyramid level before the heads (model.py:443) */
 } dcf_config;
 
 int dcf_model_create(const dcf_config* cfg, dcf_model** out);

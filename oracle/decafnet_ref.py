@@ -256,6 +256,16 @@ def xattn_fusion(sd: SD, cfg, vid: Tensor, vid_mask: Tensor, text: Tensor, text_
     return _ln(sd, p + '.ln_out', vid), vid_mask
 
 
+def xattn_fusion_pyramid(sd: SD, cfg, fpn, fpn_masks, text: Tensor, text_mask: Tensor, p: str = 'fusion'):
+    """XAttNFusion.forward on an FPN tuple, fusion.py:68-78: the same decoder stack applied to every level."""
+    out, out_masks = tuple(), tuple()
+    for x, m in zip(fpn, fpn_masks):
+        y, ym = xattn_fusion(sd, cfg, x, m, text, text_mask, p)
+        out += (y,)
+        out_masks += (ym,)
+    return out, out_masks
+
+
 def video_transformer(sd: SD, cfg, x: Tensor, mask: Tensor, p: str = 'vid_net', pe_override=None):
     """VideoTransformer.forward video_net.py:123-164 (eval, stride-1 embedding convs).
     ``pe_override`` (E, T): a window's slice of a longer video's position encoding (T-sharding tests)."""
@@ -381,9 +391,11 @@ def gate_reference_formula(pooled: Tensor, vid_len: int, sratio: float) -> Tenso
 # ----------------------------------------------------------------------------------
 # full model: PtTransformerEarlyFusionIterative eval forward
 # ----------------------------------------------------------------------------------
-def fuse_and_predict(sd: SD, cfg, fpn, fpn_masks):
-    """model.py:442-471 with second_fusion=False."""
+def fuse_and_predict(sd: SD, cfg, fpn, fpn_masks, text=None, text_masks=None, second_fusion: bool = False):
+    """model.py:442-471; ``second_fusion`` re-applies the (shared) fusion stack to every pyramid level (:443-444)."""
     n_levels = cfg['vid_net']['arch'][2]
+    if second_fusion:
+        fpn, fpn_masks = xattn_fusion_pyramid(sd, cfg['fusion'], fpn, fpn_masks, text, text_masks)
     logits1, _ = cls_head(sd, 'cls_head', fpn, fpn_masks, cfg['cls_head'].get('n_layers', 2))
     ref_len = logits1[0].shape[1]
     expand = [logits1[0]]
@@ -429,7 +441,7 @@ def gated_video_input(cfg, vid, shallow_vid, vid_masks, correl, b):
 
 def forward_eval(sd: SD, cfg, vid: Tensor, shallow_vid: Tensor, vid_masks: Tensor,
                  text: Sequence[Tensor], text_cls: Tensor, text_masks: Sequence[Tensor],
-                 return_intermediates: bool = False):
+                 return_intermediates: bool = False, second_fusion: bool = False):
     """PtTransformerEarlyFusionIterative._drop_forward_eval, model.py:480-565.
 
     vid, shallow_vid (1, D, T); vid_masks (1, T) bool; text: NQ encoded texts (1,TE,Lk);
@@ -446,7 +458,7 @@ def forward_eval(sd: SD, cfg, vid: Tensor, shallow_vid: Tensor, vid_masks: Tenso
         x, m = masked_conv1d(x, m, sd['vid_map.conv.weight'], sd['vid_map.conv.bias'])
         fused, fm = xattn_fusion(sd, cfg['fusion'], x, m, txt, txt_mask)
         fpn, fpn_masks = video_transformer(sd, cfg['vid_net'], fused, fm)
-        l1, l2, off, om = fuse_and_predict(sd, cfg, fpn, fpn_masks)
+        l1, l2, off, om = fuse_and_predict(sd, cfg, fpn, fpn_masks, txt, txt_mask, second_fusion)
         logits_list.append(l2)
         offsets_list.append(off)
         masks_list.append(om)
@@ -454,6 +466,26 @@ def forward_eval(sd: SD, cfg, vid: Tensor, shallow_vid: Tensor, vid_masks: Tenso
             inter.append(dict(vid_map=x, fused=fused, fpn=fpn, logits1=l1))
     if return_intermediates:
         return logits_list, offsets_list, masks_list, dict(correl=correl, per_query=inter)
+    return logits_list, offsets_list, masks_list
+
+
+def forward_eval_late_fusion(sd: SD, cfg, vid: Tensor, shallow_vid: Tensor, vid_masks: Tensor,
+                             text: Sequence[Tensor], text_cls: Tensor, text_masks: Sequence[Tensor]):
+    """PtTransformer._drop_forward with eval=True (late fusion), model.py:83-161: the gated, concatenated features go
+    straight into vid_net (in_dim = 2D); the fusion stack is applied to every pyramid level; cls_head / reg_head only."""
+    assert vid.size(0) == 1
+    correl = sidekick_scores(shallow_vid, text_cls, cfg['norm'])
+    vn = dict(cfg['vid_net'])
+    logits_list, offsets_list, masks_list = [], [], []
+    for b, (txt, txt_mask) in enumerate(zip(text, text_masks)):
+        x, masks = gated_video_input(cfg, vid, shallow_vid, vid_masks, correl, b)
+        fpn, fpn_masks = video_transformer(sd, vn, x, masks)
+        fpn, fpn_masks = xattn_fusion_pyramid(sd, cfg['fusion'], fpn, fpn_masks, txt, txt_mask)
+        lg, _ = cls_head(sd, 'cls_head', fpn, fpn_masks, cfg['cls_head'].get('n_layers', 2))
+        off, om = reg_head(sd, 'reg_head', fpn, fpn_masks, cfg['reg_head'].get('n_layers', 2))
+        logits_list.append(lg)
+        offsets_list.append(off)
+        masks_list.append(om)
     return logits_list, offsets_list, masks_list
 
 

@@ -232,6 +232,46 @@ E2E_CASES = {
 }
 
 
+# secondary compositions of the same blocks: late fusion (PtTransformer) and second_fusion=True
+E2E_VARIANTS = {
+    'late': dict(cls='PtTransformer', opt=dict(D=64, E=64, TE=32, text_in=32, n_levels=4, win=5, n_heads=4, sn=16, sratio=0.3,
+                                               msf=True, norm=True, max_seq_len=128, text_layers=1, text_max_len=24),
+                 T=256, vid_len=230, nq=2, lq=7, wseed=51, iseed=52),
+    'second': dict(cls='iter2', opt=dict(D=64, E=64, TE=32, text_in=32, n_levels=4, win=5, n_heads=4, sn=16, sratio=0.3,
+                                         msf=True, norm=True, max_seq_len=256, text_layers=1, text_max_len=24),
+                   T=256, vid_len=256, nq=2, lq=5, wseed=61, iseed=62),
+}
+
+
+@torch.no_grad()
+def gen_e2e_variants():
+    from libs.modeling.model import PtTransformerEarlyFusionIterative, PtTransformer
+    for name, c in E2E_VARIANTS.items():
+        opt = make_opt(**c['opt'])
+        if c['cls'] == 'PtTransformer':
+            model = PtTransformer(opt.clone()).eval()
+        else:
+            model = PtTransformerEarlyFusionIterative(opt.clone(), second_fusion=True).eval()
+        shapes = {k: list(v.shape) for k, v in model.state_dict().items()}
+        sd = synth.make_state_dict(shapes, c['wseed'])
+        model.load_state_dict(sd)
+        inp = synth.make_inputs(c['opt']['D'], c['T'], c['vid_len'], c['nq'], c['opt']['text_in'], c['lq'], c['iseed'])
+        texts, tmasks = [], []
+        for tok in inp['tokens']:
+            t, m = model.encode_text(tok[None], torch.ones(1, 1, tok.size(-1), dtype=torch.bool))
+            texts.append(t)
+            tmasks.append(m)
+        logits, offsets, masks = model(inp['vid'], inp['shallow_vid'], inp['vid_masks'], tuple(texts), inp['text_cls'], tuple(tmasks), eval=True)
+        out = dict(opt_kwargs=c['opt'], meta=dict(T=c['T'], vid_len=c['vid_len'], nq=c['nq'], lq=c['lq'], wseed=c['wseed'],
+                                                  iseed=c['iseed'], cls=c['cls']), shapes=shapes)
+        for q in range(c['nq']):
+            for l in range(len(logits[q])):
+                out[f'q{q}/l{l}/logits'] = logits[q][l]
+                out[f'q{q}/l{l}/offsets'] = offsets[q][l]
+                out[f'q{q}/l{l}/mask'] = masks[q][l]
+        save(f'e2e_{name}.npz', out)
+
+
 @torch.no_grad()
 def gen_e2e():
     from libs.modeling.model import PtTransformerEarlyFusionIterative, PtGenerator
@@ -403,6 +443,8 @@ if __name__ == '__main__':
         gen_gate()
     if 'e2e' in which:
         gen_e2e()
+    if 'variants' in which or 'e2e' in which:
+        gen_e2e_variants()
     if 'postproc' in which:
         gen_postproc()
     if 'nms' in which:

@@ -210,3 +210,25 @@ def test_nms_vs_compiled_reference_random():
             i2 = ext.softnms(segs, scores, d2, iou_thresh=thr, sigma=0.5, min_score=0.01, method=method)
             assert torch.equal(i1, i2)
             assert torch.equal(d1[:len(i1)], d2[:len(i2)])
+
+
+@pytest.mark.parametrize('name', ['late', 'second'])
+def test_secondary_compositions(name):
+    """PtTransformer (late fusion, model.py:30-161) and second_fusion=True (model.py:443-444) restatements"""
+    g = Golden(f'e2e_{name}.npz')
+    pkg = load_pkg()
+    meta, kw = g.js('meta'), g.js('opt_kwargs')
+    opt = pkg.config.make_opt(**kw)
+    sd = pkg.synth.make_state_dict(g.js('shapes'), meta['wseed'])
+    inp = pkg.synth.make_inputs(kw['D'], meta['T'], meta['vid_len'], meta['nq'], kw['text_in'], meta['lq'], meta['iseed'])
+    texts, tmasks = zip(*[R.encode_text(sd, opt.model, t[None], torch.ones(1, 1, t.size(-1), dtype=torch.bool)) for t in inp['tokens']])
+    if meta['cls'] == 'PtTransformer':
+        out = R.forward_eval_late_fusion(sd, opt.model, inp['vid'], inp['shallow_vid'], inp['vid_masks'], list(texts), inp['text_cls'], list(tmasks))
+    else:
+        out = R.forward_eval(sd, opt.model, inp['vid'], inp['shallow_vid'], inp['vid_masks'], list(texts), inp['text_cls'], list(tmasks),
+                             second_fusion=True)
+    for q in range(meta['nq']):
+        for l in range(kw['n_levels']):
+            close(out[0][q][l], g.t(f'q{q}/l{l}/logits'), atol=1e-4, rtol=1e-4)
+            close(out[1][q][l], g.t(f'q{q}/l{l}/offsets'), atol=1e-4, rtol=1e-4)
+            assert torch.equal(out[2][q][l], g.t(f'q{q}/l{l}/mask'))
