@@ -21,7 +21,7 @@ namespace dcf {
 
 
 template <int WM, int WN, int TM, int TN, int AMODE, int BK>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
+__global__ __launch_bounds__(256, (TM * TN >= 3 ? 2 : 3)) void gemm_f32_kernel(GemmBatch batch) {
   constexpr int PITCH = BK + 4;             // 36 = 4*9 / 68 = 4*17: odd multiples of 4 keep b128 reads conflict free
   constexpr int C4 = BK / 4;                // f32x4 per tile row
   constexpr int BM = WM * TM * 32;

@@ -74,8 +74,9 @@ int launch_split_planes(const float* W, unsigned short* out, int N, int K, int64
   return 0;
 }
 
+// 3 waves per SIMD (<= 168 registers): measured 3.16 -> 3.00 ms per step over the compiler's default of 2
 template <int WM, int WN, int TM, int TN, int AMODE, int NTERMS>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16s_kernel(GemmBatch batch) {
+__global__ __launch_bounds__(WM * WN * 64, (TM * TN >= 5 ? 2 : 3)) void gemm_bf16s_kernel(GemmBatch batch) {
   constexpr int NT = WM * WN * 64;                    // 4 or 8 wavefronts
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
