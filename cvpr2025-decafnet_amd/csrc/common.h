@@ -158,8 +158,16 @@ __device__ __forceinline__ void row_layernorm(Row<NCH>& r, int C, int lane, cons
 }
 
 __device__ __forceinline__ float gelu_erf(float x) {
-  // exact GELU (nn.GELU default), libs/modeling/blocks.py:531
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  // exact (erf) GELU, nn.GELU default (libs/modeling/blocks.py:531): 0.5 x (1 + erf(x / sqrt 2)).
+  // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 rounding level) on one v_exp_f32 and one
+  // v_rcp_f32 instead of ocml's erff (~40 instructions; it was 10-13 % of the FFN fc GEMM).  1 + erf is formed
+  // without cancellation on the negative side: 1 + erf(-z) = poly(t) e^{-z^2}.
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float pe = poly * __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+  const float one_plus_erf = x >= 0.f ? 2.0f - pe : pe;
+  return 0.5f * x * one_plus_erf;
 }
 
 }  // namespace dcf

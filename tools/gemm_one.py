@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 mode, M, N, K = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 reps = int(sys.argv[5]) if len(sys.argv) > 5 else 20
+act = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 pkg = importlib.import_module('cvpr2025-decafnet_amd')
 lib = pkg._lib.lib()
 A = torch.randn(M, K, device='cuda'); W = torch.randn(N, K, device='cuda'); b = torch.randn(N, device='cuda')
@@ -17,9 +18,9 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record()
 for _ in range(reps):
     if mode == 'f32':
-        lib.dcf_op_linear(P(A), P(W), P(b), P(C), M, N, K, 0, st)
+        lib.dcf_op_linear(P(A), P(W), P(b), P(C), M, N, K, act, st)
     else:
-        lib.dcf_op_linear_split(P(A), P(W), P(b), P(C), M, N, K, 0, 6 if mode == 'x6' else 3, st)
+        lib.dcf_op_linear_split(P(A), P(W), P(b), P(C), M, N, K, act, 6 if mode == 'x6' else 3, st)
 torch.cuda.synchronize()
 e1.record(); torch.cuda.synchronize()
 print(mode, M, N, K, 'us/launch (incl. weight split for x6/x3):', round(e0.elapsed_time(e1) * 1e3 / reps, 1))
