@@ -190,6 +190,24 @@ def main():
         result['stages'] = stages
         result['event_ms_per_step'] = tot_ms / args.steps
 
+        # ---- the same video with 8 queries per forward (how Evaluator calls the model: all queries of a video at once)
+        if not args.no_post and args.nq == 1:
+            inp8 = pkg.synth.make_inputs(kw['D'], T, vid_len, 8, kw['text_in'], 32, 2025 + 11)
+            cls8 = inp8['text_cls'].to(dev)
+            t8, m8 = zip(*[model.encode_text(tok[None].to(dev), torch.ones(1, 1, tok.size(-1), dtype=torch.bool, device=dev))
+                           for tok in inp8['tokens']])
+            for _ in range(3):
+                model(vid, shallow, vmask, t8, cls8, m8, eval=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                model(vid, shallow, vmask, t8, cls8, m8, eval=True)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / 5
+            result['nq8'] = {'value': vid_len * 8 / dt, 'unit': 'clips/s', 'ms_per_step': 1e3 * dt,
+                             'note': 'one forward over the same video with 8 queries (batched through every kernel), rank 0 only'}
+            model(vid, shallow, vmask, texts, text_cls, tmasks, eval=True)      # restore _last_flat for the post-processing leg
+
         # ---- proposal decode + NMS (reported separately) and the NMS index match
         if not args.no_post:
             from oracle import nms_oracle

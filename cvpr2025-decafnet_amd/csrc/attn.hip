@@ -359,7 +359,7 @@ static int launch_xattn_mfma(const XAttnArgs& a, hipStream_t st) {
   // keys = 16 * nkt + rem: up to 2 trailing keys go to the vector ALU instead of a mostly empty MFMA tile
   int nkt = a.Lk / 16, rem = a.Lk % 16;
   if (rem > 2) { nkt += 1; rem = 0; }
-  const int n_groups = (a.T + (D16 <= 4 ? 127 : 63)) / (D16 <= 4 ? 128 : 64);
+  const int n_groups = (a.T + (D16 <= 2 ? 127 : 63)) / (D16 <= 2 ? 128 : 64);
   // enough workgroups to fill the chip, few enough that K/V staging (2*Lk*d floats) is amortised
   int gx = n_groups;
   const int per = a.heads * a.B;
@@ -367,7 +367,7 @@ static int launch_xattn_mfma(const XAttnArgs& a, hipStream_t st) {
   if (gx > cap) gx = cap;
   dim3 grid(gx, a.heads, a.B);
   constexpr int D = 16 * D16;
-  constexpr int QT = D16 <= 4 ? 2 : 1;
+  constexpr int QT = D16 <= 2 ? 2 : 1;
   const size_t lds = (size_t)((16 * nkt + rem) * (D + 4) + D * (16 * nkt + 4) + (rem > 0 ? rem : 1) * D + 16 * nkt + rem) * sizeof(float);
 #define XL(NKT_, REM_) hipLaunchKernelGGL((k_xattn_mfma<D16, NKT_, REM_, QT>), grid, dim3(256), lds, st, a)
   switch (nkt * 4 + rem) {
