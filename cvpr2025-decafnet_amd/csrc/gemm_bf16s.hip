@@ -220,13 +220,156 @@ __global__ __launch_bounds__(WM * WN * 64, (TM * TN >= 5 ? 2 : 3)) void gemm_bf1
   gemm_epilogue<WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, r, h);
 }
 
+// ---- k-sliced variant for grids that cannot fill the chip --------------------------------------------------
+// The upper pyramid levels (128 .. 4096 rows) give at most a few hundred 64x64 tiles, one workgroup per CU or
+// less, and the kernel above then runs one K tile per ~1.2 us: nothing but the latency of the loads issued one
+// tile earlier (12 MFMAs of work per wave in between).  Here the four waves of a workgroup split K instead of
+// the tile: each wave owns the whole 64x64 tile for a quarter of the K tiles, loads its A fragments straight
+// from global memory (8 consecutive k per lane = the MFMA A operand, no LDS, no barrier in the loop) and its B
+// fragments from the weight image, so four independent load streams with 48 MFMAs per tile are in flight per
+// workgroup and the K loop is 4x shorter.  The partial tiles are summed through LDS in a fixed order (wave 0, 1,
+// 2, 3 -- deterministic), wave q finishing quadrant q with the common epilogue.
+template <int NTERMS>
+__global__ __launch_bounds__(256) void gemm_bf16s_kslice_kernel(GemmBatch batch) {
+  constexpr int NPL = NTERMS == 6 ? 3 : 2;
+  constexpr int BLK = 2 * 3 * 64 * 8;
+  __shared__ f32x4 red[4][3][4][64];                   // [owner quadrant][source slot][quarter][lane], 48 KiB
+
+  const GemmArgs p = blockIdx.z == 0 ? batch.g[0] : (blockIdx.z == 1 ? batch.g[1] : batch.g[2]);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  int m0, n0;
+  if (!tile_origin<64, 64>(p, m0, n0)) return;
+  const int M = p.M;
+  const int KT = p.K / SBK;
+  const int kb = KT * wave / 4, ke = KT * (wave + 1) / 4;
+
+  const float* a_ptr[2];
+  bool a_ok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + i * 32 + r;
+    a_ok[i] = m < M && (!(p.flags & G_AMASK) || p.rowmask[m]);
+    a_ptr[i] = p.A + (int64_t)(m < M ? m : 0) * p.lda + h * 8;
+  }
+  const bf16x8* w_ptr[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) w_ptr[j] = reinterpret_cast<const bf16x8*>(p.Ws + ((int64_t)(n0 / 32 + j) * KT) * BLK) + lane;
+
+  f32x4 araw[2][2][2];                                  // [row tile][chunk][half]
+  bf16x8 bfr[2][2][NPL];                                // [chunk][col tile][plane]
+  auto load = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+        if (a_ok[i]) {
+          v0 = *reinterpret_cast<const f32x4*>(a_ptr[i] + kt * SBK + c * 16);
+          v1 = *reinterpret_cast<const f32x4*>(a_ptr[i] + kt * SBK + c * 16 + 4);
+        }
+        araw[i][c][0] = v0;
+        araw[i][c][1] = v1;
+      }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) bfr[c][j][pl] = w_ptr[j][(int64_t)kt * (BLK / 8) + (c * 3 + pl) * 64];
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (kb < ke) load(kb);
+  for (int kt = kb; kt < ke; ++kt) {
+    bf16x8 a[2][2][NPL];                                // [row tile][chunk][plane]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        unsigned h0, h1, h2, h3, m0_, m1, m2, m3, l0, l1, l2, l3;
+        split2(araw[i][c][0].x, araw[i][c][0].y, h0, m0_, l0);
+        split2(araw[i][c][0].z, araw[i][c][0].w, h1, m1, l1);
+        split2(araw[i][c][1].x, araw[i][c][1].y, h2, m2, l2);
+        split2(araw[i][c][1].z, araw[i][c][1].w, h3, m3, l3);
+        a[i][c][0] = __builtin_bit_cast(bf16x8, (u32x4){h0, h1, h2, h3});
+        a[i][c][1] = __builtin_bit_cast(bf16x8, (u32x4){m0_, m1, m2, m3});
+        if constexpr (NPL == 3) a[i][c][2] = __builtin_bit_cast(bf16x8, (u32x4){l0, l1, l2, l3});
+      }
+    bf16x8 bc[2][2][NPL];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) bc[c][j][pl] = bfr[c][j][pl];
+    if (kt + 1 < ke) load(kt + 1);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          if constexpr (NTERMS == 6) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][c][1], bc[c][j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][c][0], bc[c][j][2], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][c][2], bc[c][j][0], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][c][0], bc[c][j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][c][1], bc[c][j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][c][0], bc[c][j][0], acc[i][j], 0, 0, 0);
+        }
+  }
+
+  // hand the three quadrants this wave does not finish to their owners
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (q == wave) continue;
+    const int slot = wave < q ? wave : wave - 1;
+#pragma unroll
+    for (int e4 = 0; e4 < 4; ++e4) {
+      const f32x16& t = acc[q >> 1][q & 1];
+      red[q][slot][e4][lane] = f32x4{t[e4 * 4 + 0], t[e4 * 4 + 1], t[e4 * 4 + 2], t[e4 * 4 + 3]};
+    }
+  }
+  __syncthreads();
+  f32x16 own = wave == 0 ? acc[0][0] : (wave == 1 ? acc[0][1] : (wave == 2 ? acc[1][0] : acc[1][1]));
+  f32x16 fin[1][1];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) fin[0][0][e] = 0.f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {                          // fixed order: wave 0, 1, 2, 3
+    if (s == wave) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) fin[0][0][e] += own[e];
+    } else {
+      const int slot = s < wave ? s : s - 1;
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) {
+        const f32x4 t = red[wave][slot][e4][lane];
+        fin[0][0][e4 * 4 + 0] += t.x; fin[0][0][e4 * 4 + 1] += t.y; fin[0][0][e4 * 4 + 2] += t.z; fin[0][0][e4 * 4 + 3] += t.w;
+      }
+    }
+  }
+  gemm_epilogue<2, 2, 1, 1>(p, fin, m0, n0, wave >> 1, wave & 1, r, h);
+}
+
 template <int WM, int WN, int TM, int TN>
 static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterms, hipStream_t stream) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const GemmArgs& p = b.g[0];
   dim3 grid(tile_grid<BM, BN>(p), 1, count);
   char name[96];
-  snprintf(name, sizeof(name), "gemm_bf16x%d<%dx%d,%s>", nterms, BM, BN, mode == A_ROWS ? "rows" : "tap3");
+  static const bool shapes = getenv("DCF_PROF_SHAPES") != nullptr;   // per-shape labels for tools/ (not used by bench.py)
+  if (shapes) snprintf(name, sizeof(name), "gemm_bf16x%d<%dx%d,%s>[%dx%dx%dx%d]", nterms, BM, BN, mode == A_ROWS ? "rows" : "tap3", count, p.M, p.N, p.K);
+  else snprintf(name, sizeof(name), "gemm_bf16x%d<%dx%d,%s>", nterms, BM, BN, mode == A_ROWS ? "rows" : "tap3");
   const double mnk = (double)count * p.M * (double)p.N * p.K;
   ProfScope prof(name, stream, 2.0 * mnk,
                  4.0 * count * ((double)p.M * p.K / (mode == A_ROWS_TAP3 ? 3 : 1) + 1.5 * (double)p.N * p.K + (double)p.M * p.N * ((p.flags & G_RES) ? 2 : 1)));
@@ -236,6 +379,21 @@ static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterm
   if (mode == A_ROWS) { if (nterms == 6) LS(A_ROWS, 6); else LS(A_ROWS, 3); }
   else { if (nterms == 6) LS(A_ROWS_TAP3, 6); else LS(A_ROWS_TAP3, 3); }
 #undef LS
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
+static int launch_kslice(const GemmBatch& b, int count, int nterms, hipStream_t stream) {
+  const GemmArgs& p = b.g[0];
+  dim3 grid(tile_grid<64, 64>(p), 1, count);
+  char name[96];
+  static const bool shapes = getenv("DCF_PROF_SHAPES") != nullptr;
+  if (shapes) snprintf(name, sizeof(name), "gemm_bf16x%d<64x64,kslice>[%dx%dx%dx%d]", nterms, count, p.M, p.N, p.K);
+  else snprintf(name, sizeof(name), "gemm_bf16x%d<64x64,kslice>", nterms);
+  const double mnk = (double)count * p.M * (double)p.N * p.K;
+  ProfScope prof(name, stream, 2.0 * mnk, 4.0 * count * ((double)p.M * p.K + 1.5 * (double)p.N * p.K + (double)p.M * p.N * ((p.flags & G_RES) ? 2 : 1)));
+  if (nterms == 6) hipLaunchKernelGGL((gemm_bf16s_kslice_kernel<6>), grid, dim3(256), 0, stream, b);
+  else hipLaunchKernelGGL((gemm_bf16s_kslice_kernel<3>), grid, dim3(256), 0, stream, b);
   DCF_HIP(hipGetLastError());
   return 0;
 }
@@ -273,6 +431,9 @@ int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, 
       if (bm == 128 && bn == 128) return launch_cfg_s<2, 2, 2, 2>(b, count, mode, nterms, stream);
     }
   }
+  // small grids: split K over the waves instead of the tile (see gemm_bf16s_kslice_kernel)
+  static const long kslice_max = getenv("DCF_KSLICE_MAX") ? atol(getenv("DCF_KSLICE_MAX")) : 512;
+  if (mode == A_ROWS && N % 64 == 0 && p.K >= 4 * SBK && wgs(64, 64) <= kslice_max) return launch_kslice(b, count, nterms, stream);
   if (N % 256 == 0 && wgs(64, 256) >= WANT) return launch_cfg_s<1, 4, 2, 2>(b, count, mode, nterms, stream);   // 64x256, 64x64 per wave
   if (N % 96 == 0 && N % 64 != 0) return launch_cfg_s<4, 1, 1, 3>(b, count, mode, nterms, stream);              // 128x96 (N = 288)
   if (N % 160 == 0 && N % 64 != 0) return launch_cfg_s<4, 1, 1, 5>(b, count, mode, nterms, stream);             // 128x160

@@ -32,38 +32,71 @@ static inline unsigned tile_grid(const GemmArgs& p) {
 
 // Fused epilogue of one workgroup tile.  acc[i][j] is the 32x32 D fragment of wave tile (i, j):
 // col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)  (same map for f32 and bf16 MFMA).
-template <int WM, int WN, int TM, int TN>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int r,
-                                              int h) {
-  const int M = p.M;
+// Written for instruction count: with K = 256 the K loop is only 8 tiles long and a per-element epilogue (row
+// bound branch + 64-bit address arithmetic per store, ~25 vector instructions per element) was 4/5 of all vector
+// instructions of the kernel (rocprofv3 SQ_INSTS_VALU).  Here full tiles skip the row tests (FULL), addresses are
+// 32-bit offsets from a uniform tile base, and the residual / row-mask loads are issued together before the
+// first store (stores to C may alias R for the compiler: interleaved they were 16 dependent round trips).
+template <bool FULL, int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_body(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
+                                                   int r, int h) {
   const int flags = p.flags;
+  const int rows_left = p.M - m0;                                   // > 0
+  float* __restrict__ Cb = p.C + (int64_t)m0 * p.ldc + n0;          // uniform tile bases
+  const float* __restrict__ Rb = (flags & G_RES) ? p.R + (int64_t)m0 * p.ldr + n0 : nullptr;
+  const uint8_t* __restrict__ Mb = (flags & (G_RES_MASK | G_OUT_MASK)) ? p.rowmask + m0 : nullptr;
+  const unsigned ldc = (unsigned)p.ldc, ldr = (unsigned)p.ldr;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + (wn * TN + j) * 32 + r;
-    const float bias = p.bias ? p.bias[col] : 0.f;
-    const float ls = ((flags & G_RES) && p.ls) ? p.ls[col] : 1.f;
+  for (int i = 0; i < TM; ++i) {
+    const unsigned row0 = (unsigned)((wm * TM + i) * 32 + 4 * h);   // + (e & 3) + 8 * (e >> 2)
+    float mk[16];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int e = 0; e < 16; ++e) mk[e] = 1.f;
+    if (Mb) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int row = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (row < M) {
-          float v = acc[i][j][e] + bias;
-          if (flags & G_GELU) v = gelu_erf(v);
-          if (flags & G_RELU) v = fmaxf(v, 0.f);
-          if (flags & G_RES) {
-            float mk = 1.f;
-            if (flags & (G_RES_MASK | G_OUT_MASK)) mk = p.rowmask[row] ? 1.f : 0.f;
-            if (flags & G_OUT_MASK) v *= mk;
-            float res = p.R[(int64_t)row * p.ldr + col];
-            if (flags & G_RES_MASK) res *= mk;
-            v = res + ls * v;
-          }
-          p.C[(int64_t)row * p.ldc + col] = v;
+        const unsigned row = row0 + (e & 3) + 8 * (e >> 2);
+        if (FULL || (int)row < rows_left) mk[e] = Mb[row] ? 1.f : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const unsigned col = (unsigned)((wn * TN + j) * 32 + r);
+      const float bias = p.bias ? p.bias[n0 + col] : 0.f;
+      const float ls = ((flags & G_RES) && p.ls) ? p.ls[n0 + col] : 1.f;
+      float res[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) res[e] = 0.f;
+      if (Rb) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const unsigned row = row0 + (e & 3) + 8 * (e >> 2);
+          if (FULL || (int)row < rows_left) res[e] = Rb[row * ldr + col];
         }
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const unsigned row = row0 + (e & 3) + 8 * (e >> 2);
+        float v = acc[i][j][e] + bias;
+        if (flags & G_GELU) v = gelu_erf(v);
+        if (flags & G_RELU) v = fmaxf(v, 0.f);
+        if (flags & G_RES) {
+          if (flags & G_OUT_MASK) v *= mk[e];
+          float r_ = res[e];
+          if (flags & G_RES_MASK) r_ *= mk[e];
+          v = r_ + ls * v;
+        }
+        if (FULL || (int)row < rows_left) Cb[row * ldc + col] = v;
       }
     }
   }
+}
+
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int r,
+                                              int h) {
+  if (m0 + WM * TM * 32 <= p.M) gemm_epilogue_body<true, WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, r, h);
+  else gemm_epilogue_body<false, WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, r, h);
 }
 
 }  // namespace dcf

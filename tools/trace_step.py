@@ -1,0 +1,31 @@
+"""Summarise one steady-state forward from a rocprofv3 --kernel-trace CSV: per-dispatch kernel, grid, duration and the
+gap to the previous kernel.  usage: python tools/trace_step.py <kernel_trace.csv> [kernels_per_step]"""
+import csv, sys, re
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+names = [r['Kernel_Name'] for r in rows]
+# one step starts at the sidekick partial kernel
+starts = [i for i, n in enumerate(names) if 'k_sidekick_partial' in n]
+if len(starts) < 3:
+    print('not enough steps', len(starts)); sys.exit(1)
+# steady-state = the step with the smallest wall time (graph replay inside the timed region)
+best = None
+for a, b in zip(starts[:-1], starts[1:]):
+    w = int(rows[b - 1]['End_Timestamp']) - int(rows[a]['Start_Timestamp'])
+    if best is None or w < best[0]: best = (w, a, b)
+_, a, b = best
+step = rows[a:b]
+t0 = int(step[0]['Start_Timestamp'])
+prev_end = t0
+tot = 0
+short = lambda n: re.sub(r'\(.*$', '', n.replace('dcf::', '').replace('void ', ''))[:70]
+print(f'{len(step)} kernels, wall {(int(step[-1]["End_Timestamp"]) - t0) / 1e3:.1f} us')
+for r in step:
+    s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+    g = r.get('Grid_Size_X', r.get('Grid_Size', '?'))
+    gz = r.get('Grid_Size_Z', '')
+    wg = r.get('Workgroup_Size_X', r.get('Workgroup_Size', '?'))
+    print(f'{(s - t0) / 1e3:9.1f} us  dur {(e - s) / 1e3:7.1f}  gap {(s - prev_end) / 1e3:6.1f}  grid {g}x{gz} wg {wg}  {short(r["Kernel_Name"])}')
+    prev_end = e
+    tot += e - s
+print(f'sum of kernel durations {tot / 1e3:.1f} us')
