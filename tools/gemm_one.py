@@ -12,8 +12,11 @@ A = torch.randn(M, K, device='cuda'); W = torch.randn(N, K, device='cuda'); b = 
 C = torch.empty(M, N, device='cuda')
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-import time
+import time, json
+for _ in range(3):
+    lib.dcf_op_linear_split(P(A), P(W), P(b), P(C), M, N, K, act, 6, st) if mode != 'f32' else lib.dcf_op_linear(P(A), P(W), P(b), P(C), M, N, K, act, st)
 torch.cuda.synchronize()
+lib.dcf_profile_enable(1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(reps):
@@ -24,3 +27,9 @@ for _ in range(reps):
 torch.cuda.synchronize()
 e1.record(); torch.cuda.synchronize()
 print(mode, M, N, K, 'us/launch (incl. weight split for x6/x3):', round(e0.elapsed_time(e1) * 1e3 / reps, 1))
+
+need = lib.dcf_profile_report(None, 0)
+buf = ctypes.create_string_buffer(int(need) + 16)
+lib.dcf_profile_report(buf, len(buf))
+for k, v in json.loads(buf.value.decode()).items():
+    if 'gemm' in k: print('   kernel only:', k, round(1e3 * v['ms'] / v['count'], 1), 'us', round(v['flops'] / v['ms'] / 1e9, 1), 'TF')
