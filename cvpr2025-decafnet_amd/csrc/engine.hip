@@ -176,6 +176,9 @@ struct dcf_model {
   hipGraphExec_t graph_exec = nullptr;
   bool capturing = false;
   int capture_chunk = 0;
+  // second stream for the two independent branches of the forward (fork_side / join_side)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
   // last-forward bookkeeping for dcf_debug_copy
   struct {
     float *correl = nullptr, *gate = nullptr, *vidmap = nullptr, *fused = nullptr, *F = nullptr;
@@ -207,6 +210,11 @@ static int free_model(dcf_model* m) {
   if (m->arena) (void)hipFree(m->arena);
   if (m->h_meta) (void)hipHostFree(m->h_meta);
   if (m->d_meta) (void)hipFree(m->d_meta);
+  for (int i = 0; i < 2; ++i) {
+    if (m->ev_fork[i]) (void)hipEventDestroy(m->ev_fork[i]);
+    if (m->ev_join[i]) (void)hipEventDestroy(m->ev_join[i]);
+  }
+  if (m->side) (void)hipStreamDestroy(m->side);
   return 0;
 }
 
@@ -482,6 +490,35 @@ static GemmArgs gemm(const float* A, int64_t lda, const float* W, const float* b
 
 #define TRY(x) do { if ((x) != 0) return -1; } while (0)
 
+// Two places of the forward have a branch that does not depend on the main chain (bit 0: the sidekick scoring
+// next to the vid_map GEMMs; bit 1: the first classification head on the two finest levels next to the
+// latency-bound encoders of the coarse levels).  DCF_FORK=<mask> runs them on a second stream between fork_side and
+// join_side (plain event dependencies, which stream capture turns into parallel graph branches).  OFF by default:
+// measured on MI355X (same box, 3 runs each, ms per step) none 2.63 / bit 0 2.67 / bit 1 2.70 / both 2.71 -- the
+// kernels of two queues slow each other down by more than the overlap gains (rocprofv3: sidekick 34 -> 144 us
+// beside the GEMM, the level-2 GEMMs 18 -> 58 us beside the head convolution).
+static bool fork_enabled(int which) {
+  static const int mask = getenv("DCF_FORK") ? atoi(getenv("DCF_FORK")) : 0;
+  return ((mask >> which) & 1) && !g_prof_on;
+}
+static int fork_side(dcf_model* m, int which, hipStream_t st) {
+  if (!m->side) {
+    DCF_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      DCF_HIP(hipEventCreateWithFlags(&m->ev_fork[i], hipEventDisableTiming));
+      DCF_HIP(hipEventCreateWithFlags(&m->ev_join[i], hipEventDisableTiming));
+    }
+  }
+  DCF_HIP(hipEventRecord(m->ev_fork[which], st));
+  DCF_HIP(hipStreamWaitEvent(m->side, m->ev_fork[which], 0));
+  return 0;
+}
+static int join_side(dcf_model* m, int which, hipStream_t st) {
+  DCF_HIP(hipEventRecord(m->ev_join[which], m->side));
+  DCF_HIP(hipStreamWaitEvent(st, m->ev_join[which], 0));
+  return 0;
+}
+
 // dense GEMM dispatch: bf16-split MFMA when the weight has split planes, fp32 MFMA otherwise
 static int run_gemm(dcf_model* m, GemmArgs* g, int count, GemmAMode mode, hipStream_t st) {
   bool split = m->gemm_terms != 0 && mode != A_CHANMAJOR;
@@ -644,20 +681,26 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
   }
 
   // ---- per video: sidekick scores and the query-independent halves of vid_map
+  bool forked = false;
   if (!gate_override) {
+    // HBM-bound scoring of the shallow features next to the MFMA-bound vid_map GEMMs
     ScoreArgs sa{shallow, text_cls, b.tn, b.partial, b.correl, D, T0, nq, c.norm};
-    TRY(launch_sidekick(sa, st));
+    if (fork_enabled(0)) {
+      TRY(fork_side(m, 0, st));
+      forked = true;
+      TRY(launch_sidekick(sa, m->side));
+    } else {
+      TRY(launch_sidekick(sa, st));
+    }
   }
   const int Din = c.msf ? 2 * D : D;
   {
-    GemmArgs g = gemm(vid, T0, m->vid_map_w, nullptr, b.P1, E, T0, E, D);
-    g.ldw = Din;
-    TRY(run_gemm(m, &g, 1, A_CHANMAJOR, st));
-    if (c.msf) {
-      GemmArgs g2 = gemm(shallow, T0, m->vid_map_w + D, nullptr, b.P2, E, T0, E, D);
-      g2.ldw = Din;
-      TRY(run_gemm(m, &g2, 1, A_CHANMAJOR, st));
-    }
+    // deep and shallow halves of vid_map share one grid (same shape, blockIdx.z selects the operand set)
+    GemmArgs g[2] = {gemm(vid, T0, m->vid_map_w, nullptr, b.P1, E, T0, E, D),
+                     gemm(shallow, T0, m->vid_map_w + D, nullptr, b.P2, E, T0, E, D)};
+    g[0].ldw = g[1].ldw = Din;
+    TRY(run_gemm(m, g, c.msf ? 2 : 1, A_CHANMAJOR, st));
+    if (forked) TRY(join_side(m, 0, st));
   }
 
   for (int q0 = 0; q0 < nq; q0 += Bmax) {
@@ -714,6 +757,7 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
     }
 
     // ---- vid_net: VideoTransformer.forward (video_net.py:123-164)
+    const bool head_split = c.model_kind == 0 && !c.second_fusion && L >= 3 && fork_enabled(1);
     {
       if (c.model_kind == 0) {
         GemmArgs ge = gemm(b.R[0], E, m->embd_fc_w, m->embd_fc_b, b.X, E, rows0, E, E);
@@ -749,7 +793,14 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
         float* xo = b.F + (int64_t)lt.start[l] * ldf;
         TRY(run_encoder(m, m->branch[l], b, xin, ldx, mi, mo, B, l > 0 ? lt.T[l - 1] : T0, stride, xo, ldf, st));
         xin = xo; ldx = ldf;
+        if (l == 1 && head_split) {
+          // levels 0-1 (3/4 of the pyramid rows) are final: their first classification head runs beside the
+          // encoders of levels 2.. (a few hundred workgroups at most, latency bound)
+          TRY(fork_side(m, 1, st));
+          TRY(run_head(m, m->cls1, b, *pl, E, 1, 0, 0, b.logits1, m->side, 0, lt.start[2]));
+        }
       }
+      if (head_split) TRY(join_side(m, 1, st));
     }
 
     // ---- second / late fusion over the whole pyramid (model.py:443-444, :66-67; fusion.py:68-78), in place on F
@@ -761,10 +812,12 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
       TRY(run_head(m, m->cls1, b, *pl, E, 1, 0, 1, logits_out + (int64_t)q0 * S, st));
       TRY(run_head(m, m->reg, b, *pl, E, 2, 1, 1, offsets_out + (int64_t)q0 * S * 2, st));
     } else {
-    // ---- heads: fuse_and_predict (model.py:442-471).  (Running cls_head level by level on a side stream while the
-    // main stream continues with the small upper-level encoders was measured: 40 small launches instead of 5 big
-    // ones and CU contention cost more than the overlap gained, 3.45 vs 3.30 ms per step.)
-    TRY(run_head(m, m->cls1, b, *pl, E, 1, 0, 0, b.logits1, st));
+    // ---- heads: fuse_and_predict (model.py:442-471).  (Running cls_head level by level on a side stream was
+    // measured slower, 40 small launches instead of 5 big ones; the split above is one extra set of 5 launches.)
+    if (head_split)
+      TRY(run_head(m, m->cls1, b, *pl, E, 1, 0, 0, b.logits1, st, lt.start[2], rowsAll - lt.start[2]));   // levels 0-1: above
+    else
+      TRY(run_head(m, m->cls1, b, *pl, E, 1, 0, 0, b.logits1, st));
     {
       RefineArgs ra{};
       ra.logits1 = b.logits1; ra.lt = pl->d_lt; ra.mask_all = b.mask_all;
