@@ -142,6 +142,7 @@ struct dcf_model {
   std::unordered_map<std::string, Bound> bound;
   std::vector<float*> owned;                 // packed weights
   std::unordered_map<const float*, const unsigned short*> wsplit;   // fp32 weight -> [3][N][K] bf16 planes
+  std::unordered_map<const float*, int64_t> wsplit_ldw;             // row pitch of the fp32 weight the planes were made from
   int gemm_terms = 6;                        // 6 / 3: bf16-split MFMA GEMM; 0: fp32 MFMA
   bool finalized = false;
   const float* pe = nullptr;
@@ -205,6 +206,7 @@ static int free_model(dcf_model* m) {
   for (float* p : m->owned) (void)hipFree(p);
   m->owned.clear();
   m->wsplit.clear();
+  m->wsplit_ldw.clear();
   for (auto& pl : m->plans) if (pl.d_lt) (void)hipFree(pl.d_lt);
   m->plans.clear();
   if (m->arena) (void)hipFree(m->arena);
@@ -244,13 +246,14 @@ static int pack3(dcf_model* m, const float* src, int d0, int d1, int d2, int p0,
 }
 
 // bf16 planes of a GEMM weight [N][K] (row pitch K); owned by the model
-static int split_weight(dcf_model* m, const float* W, int N, int K, hipStream_t st) {
+static int split_weight(dcf_model* m, const float* W, int N, int K, hipStream_t st, int64_t ldw = 0) {
   if (m->gemm_terms == 0 || m->wsplit.count(W)) return 0;
   unsigned short* planes = nullptr;
   DCF_HIP(hipMalloc(&planes, (size_t)3 * N * K * sizeof(unsigned short)));
   m->owned.push_back(reinterpret_cast<float*>(planes));
-  if (launch_split_planes(W, planes, N, K, K, st)) return -1;
+  if (launch_split_planes(W, planes, N, K, ldw ? ldw : K, st)) return -1;
   m->wsplit[W] = planes;
+  m->wsplit_ldw[W] = ldw ? ldw : K;
   return 0;
 }
 #define SPLIT(W, N, K) do { if (split_weight(m, (W), (N), (K), st)) return -1; } while (0)
@@ -308,6 +311,7 @@ static int finalize(dcf_model* m, hipStream_t st) {
   for (float* p : m->owned) (void)hipFree(p);
   m->owned.clear();
   m->wsplit.clear();
+  m->wsplit_ldw.clear();
   {
     const int gm = c.gemm_mode;
     m->gemm_terms = gm == 1 ? 0 : (gm == 3 ? 3 : 6);
@@ -323,6 +327,11 @@ static int finalize(dcf_model* m, hipStream_t st) {
     GET("vid_net.embd_fc.conv.weight", SH(E, Din), m->vid_map_w); GET("vid_net.embd_fc.conv.bias", SH(E), m->vid_map_b);
   } else {
     GET("vid_map.conv.weight", SH(E, Din), m->vid_map_w); GET("vid_map.conv.bias", SH(E), m->vid_map_b);
+  }
+  // the deep / shallow column halves of the (E, [2]D) weight are separate GEMM operands with row pitch Din
+  if (D % 32 == 0 && E % 32 == 0) {
+    if (split_weight(m, m->vid_map_w, E, D, st, Din)) return -1;
+    if (c.msf && split_weight(m, m->vid_map_w + D, E, D, st, Din)) return -1;
   }
   for (int i = 0; i < c.fusion_layers; ++i) {
     const std::string p = "fusion.layers." + std::to_string(i);
@@ -521,12 +530,13 @@ static int join_side(dcf_model* m, int which, hipStream_t st) {
 
 // dense GEMM dispatch: bf16-split MFMA when the weight has split planes, fp32 MFMA otherwise
 static int run_gemm(dcf_model* m, GemmArgs* g, int count, GemmAMode mode, hipStream_t st) {
-  bool split = m->gemm_terms != 0 && mode != A_CHANMAJOR;
+  bool split = m->gemm_terms != 0;
   for (int i = 0; i < count && split; ++i) {
     auto it = m->wsplit.find(g[i].W);
-    if (it == m->wsplit.end() || (g[i].ldw != 0 && g[i].ldw != g[i].K)) split = false;
+    if (it == m->wsplit.end() || (g[i].ldw ? g[i].ldw : g[i].K) != m->wsplit_ldw[g[i].W]) split = false;
     else g[i].Ws = it->second;
   }
+  if (split && mode == A_CHANMAJOR && (g[0].N % 128 != 0 || g[0].M % 4 != 0)) split = false;
   return split ? launch_gemm_split(g, count, mode, m->gemm_terms, st) : launch_gemm(g, count, mode, st);
 }
 

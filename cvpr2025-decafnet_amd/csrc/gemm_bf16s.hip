@@ -84,7 +84,7 @@ __global__ __launch_bounds__(WM * WN * 64, (TM * TN >= 5 ? 2 : 3)) void gemm_bf1
   constexpr int ACH = BM * 4 / NT;                    // 8-float chunks of the A tile per thread
   constexpr int BLK = 2 * 3 * 64 * 8;                 // bf16 elements of one weight block (6 KiB)
   static_assert((WM * WN == 4 || WM * WN == 8) && (BM * 4) % NT == 0, "tile/threads mismatch");
-  static_assert(AMODE == A_ROWS || AMODE == A_ROWS_TAP3, "channel-major A stays on the fp32 kernel");
+  static_assert(AMODE == A_ROWS || AMODE == A_ROWS_TAP3 || AMODE == A_CHANMAJOR, "unknown A mode");
 
   extern __shared__ unsigned char smem_b[];
   unsigned char* As = smem_b;                          // [NPL][BM][ROWB]: the only LDS tile (A is shared by the N-waves)
@@ -99,20 +99,28 @@ __global__ __launch_bounds__(WM * WN * 64, (TM * TN >= 5 ? 2 : 3)) void gemm_bf1
   const int KT = K / SBK;
 
   // K-invariant addressing (see gemm.hip: nothing but 16-byte loads inside the K loop)
+  // A_ROWS / TAP3: thread -> (row, 8-float piece); A_CHANMAJOR (A[m][k] = X[k*lda + m]): thread -> (k pair p, 4 rows)
   const float* a_ptr[ACH];
   unsigned a_flag[ACH];
 #pragma unroll
   for (int i = 0; i < ACH; ++i) {
     const int id = i * NT + tid;
-    const int row = id >> 2, c8 = id & 3;
-    const int m = m0 + row;
-    unsigned f = 0;
-    if (m < M) {
-      if constexpr (AMODE == A_ROWS) f = (p.flags & G_AMASK) ? (p.rowmask[m] ? 1u : 0u) : 1u;
-      else f = p.nbr[m];
+    if constexpr (AMODE == A_CHANMAJOR) {
+      const int pk = id & 15, m4 = id >> 4;
+      const int m = m0 + m4 * 4;
+      a_flag[i] = m < M ? 1u : 0u;                     // M % 4 == 0 (checked by the launcher)
+      a_ptr[i] = p.A + (int64_t)(2 * pk) * p.lda + (m < M ? m : 0);
+    } else {
+      const int row = id >> 2, c8 = id & 3;
+      const int m = m0 + row;
+      unsigned f = 0;
+      if (m < M) {
+        if constexpr (AMODE == A_ROWS) f = (p.flags & G_AMASK) ? (p.rowmask[m] ? 1u : 0u) : 1u;
+        else f = p.nbr[m];
+      }
+      a_flag[i] = f;
+      a_ptr[i] = p.A + (int64_t)(m < M ? m : 0) * p.lda + c8 * 8;
     }
-    a_flag[i] = f;
-    a_ptr[i] = p.A + (int64_t)(m < M ? m : 0) * p.lda + c8 * 8;
   }
   // B fragments of this wave's TN column tiles: block (n32, kt) at ((n32 * KT + kt) * BLK), lane slot lane*8
   const bf16x8* w_ptr[TN];
@@ -130,12 +138,14 @@ __global__ __launch_bounds__(WM * WN * 64, (TM * TN >= 5 ? 2 : 3)) void gemm_bf1
       bit = tap == 0 ? 2u : (tap == 1 ? 1u : 4u);
       shift = (int64_t)(tap - 1) * p.lda + (k0 - tap * p.cin);
     }
+    if constexpr (AMODE == A_CHANMAJOR) shift = (int64_t)k0 * p.lda;
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
       f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
       if (a_flag[i] & bit) {
         v0 = *reinterpret_cast<const f32x4*>(a_ptr[i] + shift);
-        v1 = *reinterpret_cast<const f32x4*>(a_ptr[i] + shift + 4);
+        if constexpr (AMODE == A_CHANMAJOR) v1 = *reinterpret_cast<const f32x4*>(a_ptr[i] + shift + p.lda);   // k + 1
+        else v1 = *reinterpret_cast<const f32x4*>(a_ptr[i] + shift + 4);
       }
       araw[i][0] = v0;
       araw[i][1] = v1;
@@ -145,16 +155,31 @@ __global__ __launch_bounds__(WM * WN * 64, (TM * TN >= 5 ? 2 : 3)) void gemm_bf1
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
       const int id = i * NT + tid;
-      const int row = id >> 2, c8 = id & 3;
-      unsigned h0, h1, h2, h3, m0_, m1, m2, m3, l0, l1, l2, l3;
-      split2(araw[i][0].x, araw[i][0].y, h0, m0_, l0);
-      split2(araw[i][0].z, araw[i][0].w, h1, m1, l1);
-      split2(araw[i][1].x, araw[i][1].y, h2, m2, l2);
-      split2(araw[i][1].z, araw[i][1].w, h3, m3, l3);
-      const u32x4 hi = {h0, h1, h2, h3}, mid = {m0_, m1, m2, m3}, lo = {l0, l1, l2, l3};
-      *reinterpret_cast<u32x4*>(As + (0 * BM + row) * ROWB + c8 * 16) = hi;
-      *reinterpret_cast<u32x4*>(As + (1 * BM + row) * ROWB + c8 * 16) = mid;
-      if constexpr (NPL == 3) *reinterpret_cast<u32x4*>(As + (2 * BM + row) * ROWB + c8 * 16) = lo;
+      if constexpr (AMODE == A_CHANMAJOR) {
+        // araw[i][0] = rows m..m+3 at k = 2 pk, araw[i][1] the same rows at k + 1: one packed bf16 pair per row and
+        // plane.  Lanes run over pk first: the 32 lanes of a ds_write_b32 group hit 32 distinct banks.
+        const int pk = id & 15, m4 = id >> 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          unsigned hi, mid, lo;
+          split2(araw[i][0][e], araw[i][1][e], hi, mid, lo);
+          const int row = m4 * 4 + e;
+          *reinterpret_cast<unsigned*>(As + (0 * BM + row) * ROWB + pk * 4) = hi;
+          *reinterpret_cast<unsigned*>(As + (1 * BM + row) * ROWB + pk * 4) = mid;
+          if constexpr (NPL == 3) *reinterpret_cast<unsigned*>(As + (2 * BM + row) * ROWB + pk * 4) = lo;
+        }
+      } else {
+        const int row = id >> 2, c8 = id & 3;
+        unsigned h0, h1, h2, h3, m0_, m1, m2, m3, l0, l1, l2, l3;
+        split2(araw[i][0].x, araw[i][0].y, h0, m0_, l0);
+        split2(araw[i][0].z, araw[i][0].w, h1, m1, l1);
+        split2(araw[i][1].x, araw[i][1].y, h2, m2, l2);
+        split2(araw[i][1].z, araw[i][1].w, h3, m3, l3);
+        const u32x4 hi = {h0, h1, h2, h3}, mid = {m0_, m1, m2, m3}, lo = {l0, l1, l2, l3};
+        *reinterpret_cast<u32x4*>(As + (0 * BM + row) * ROWB + c8 * 16) = hi;
+        *reinterpret_cast<u32x4*>(As + (1 * BM + row) * ROWB + c8 * 16) = mid;
+        if constexpr (NPL == 3) *reinterpret_cast<u32x4*>(As + (2 * BM + row) * ROWB + c8 * 16) = lo;
+      }
     }
   };
   // B fragments of one K tile: [chunk][tile][plane]
@@ -368,8 +393,8 @@ static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterm
   dim3 grid(tile_grid<BM, BN>(p), 1, count);
   char name[96];
   static const bool shapes = getenv("DCF_PROF_SHAPES") != nullptr;   // per-shape labels for tools/ (not used by bench.py)
-  if (shapes) snprintf(name, sizeof(name), "gemm_bf16x%d<%dx%d,%s>[%dx%dx%dx%d]", nterms, BM, BN, mode == A_ROWS ? "rows" : "tap3", count, p.M, p.N, p.K);
-  else snprintf(name, sizeof(name), "gemm_bf16x%d<%dx%d,%s>", nterms, BM, BN, mode == A_ROWS ? "rows" : "tap3");
+  if (shapes) snprintf(name, sizeof(name), "gemm_bf16x%d<%dx%d,%s>[%dx%dx%dx%d]", nterms, BM, BN, mode == A_ROWS ? "rows" : mode == A_ROWS_TAP3 ? "tap3" : "chanmajor", count, p.M, p.N, p.K);
+  else snprintf(name, sizeof(name), "gemm_bf16x%d<%dx%d,%s>", nterms, BM, BN, mode == A_ROWS ? "rows" : mode == A_ROWS_TAP3 ? "tap3" : "chanmajor");
   const double mnk = (double)count * p.M * (double)p.N * p.K;
   ProfScope prof(name, stream, 2.0 * mnk,
                  4.0 * count * ((double)p.M * p.K / (mode == A_ROWS_TAP3 ? 3 : 1) + 1.5 * (double)p.N * p.K + (double)p.M * p.N * ((p.flags & G_RES) ? 2 : 1)));
@@ -377,7 +402,12 @@ static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterm
   const size_t lds = (size_t)npl * BM * ROWB;
 #define LS(MODE_, NT_) hipLaunchKernelGGL((gemm_bf16s_kernel<WM, WN, TM, TN, MODE_, NT_>), grid, dim3(WM * WN * 64), lds, stream, b)
   if (mode == A_ROWS) { if (nterms == 6) LS(A_ROWS, 6); else LS(A_ROWS, 3); }
-  else { if (nterms == 6) LS(A_ROWS_TAP3, 6); else LS(A_ROWS_TAP3, 3); }
+  else if (mode == A_ROWS_TAP3) { if (nterms == 6) LS(A_ROWS_TAP3, 6); else LS(A_ROWS_TAP3, 3); }
+  else {
+    // channel-major A is only instantiated for the 64-row tiles the vid_map shapes use
+    if constexpr (WM == 1 && WN == 4 && TM == 2) { if (nterms == 6) LS(A_CHANMAJOR, 6); else LS(A_CHANMAJOR, 3); }
+    else DCF_CHECK(false, "launch_gemm_split: channel-major A needs a 64-row tile");
+  }
 #undef LS
   DCF_HIP(hipGetLastError());
   return 0;
@@ -401,7 +431,6 @@ static int launch_kslice(const GemmBatch& b, int count, int nterms, hipStream_t 
 // same contract as launch_gemm; every g[i].Ws must hold the pre-tiled bf16 planes of g[i].W (launch_split_planes)
 int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, hipStream_t stream) {
   DCF_CHECK(count >= 1 && count <= 3, "launch_gemm_split: count %d out of range", count);
-  DCF_CHECK(mode == A_ROWS || mode == A_ROWS_TAP3, "launch_gemm_split: channel-major A is not supported");
   DCF_CHECK(nterms == 3 || nterms == 6, "launch_gemm_split: nterms must be 3 or 6");
   GemmBatch b;
   for (int i = 0; i < 3; ++i) b.g[i] = g[i < count ? i : 0];
@@ -410,6 +439,7 @@ int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, 
     DCF_CHECK(g[i].M == p.M && g[i].N == p.N && g[i].K == p.K, "launch_gemm_split: grouped shapes differ");
     DCF_CHECK(g[i].A && g[i].Ws && g[i].C, "launch_gemm_split: null operand");
     DCF_CHECK(g[i].lda % 4 == 0, "launch_gemm_split: lda %% 4 != 0");
+    if (mode == A_CHANMAJOR) DCF_CHECK(g[i].M % 4 == 0 && !(g[i].flags & G_AMASK), "launch_gemm_split: channel-major A needs M %% 4 == 0, no row mask");
     if (mode == A_ROWS_TAP3) DCF_CHECK(g[i].nbr && g[i].cin % 32 == 0 && g[i].K == 3 * g[i].cin, "launch_gemm_split: bad tap3 args");
     if (g[i].flags & (G_AMASK | G_RES_MASK | G_OUT_MASK)) DCF_CHECK(g[i].rowmask, "launch_gemm_split: rowmask missing");
     if (g[i].flags & G_RES) DCF_CHECK(g[i].R, "launch_gemm_split: residual missing");
@@ -434,6 +464,11 @@ int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, 
   // small grids: split K over the waves instead of the tile (see gemm_bf16s_kslice_kernel)
   static const long kslice_max = getenv("DCF_KSLICE_MAX") ? atol(getenv("DCF_KSLICE_MAX")) : 512;
   if (mode == A_ROWS && N % 64 == 0 && p.K >= 4 * SBK && wgs(64, 64) <= kslice_max) return launch_kslice(b, count, nterms, stream);
+  if (mode == A_CHANMAJOR) {
+    DCF_CHECK(N % 128 == 0, "launch_gemm_split: channel-major A needs N %% 128 == 0");
+    if (N % 256 == 0 && wgs(64, 256) >= WANT) return launch_cfg_s<1, 4, 2, 2>(b, count, mode, nterms, stream);
+    return launch_cfg_s<1, 4, 2, 1>(b, count, mode, nterms, stream);
+  }
   if (N % 256 == 0 && wgs(64, 256) >= WANT) return launch_cfg_s<1, 4, 2, 2>(b, count, mode, nterms, stream);   // 64x256, 64x64 per wave
   if (N % 96 == 0 && N % 64 != 0) return launch_cfg_s<4, 1, 1, 3>(b, count, mode, nterms, stream);              // 128x96 (N = 288)
   if (N % 160 == 0 && N % 64 != 0) return launch_cfg_s<4, 1, 1, 5>(b, count, mode, nterms, stream);             // 128x160
