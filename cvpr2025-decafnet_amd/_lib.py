@@ -21,7 +21,8 @@ vp = ctypes.c_void_p
 class DcfConfig(ctypes.Structure):
     _fields_ = [(n, i32) for n in ('D', 'E', 'TE', 'vid_heads', 'fusion_heads', 'fusion_layers', 'n_embd_convs',
                                    'n_stem', 'n_levels', 'win', 'head_layers', 'sn')] + \
-               [('sratio', f32)] + [(n, i32) for n in ('msf', 'norm', 'use_abs_pe', 'max_batch', 'gemm_mode', 'model_kind', 'second_fusion')]
+               [('sratio', f32)] + [(n, i32) for n in ('msf', 'norm', 'use_abs_pe', 'max_batch', 'gemm_mode', 'model_kind', 'second_fusion',
+                                                      'text_in', 'text_layers', 'text_heads', 'text_abs_pe', 'text_bkgd')]
 
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
@@ -32,6 +33,8 @@ SIGNATURES = {
     'dcf_model_destroy': (None, [vp]),
     'dcf_model_bind': (i32, [vp, ctypes.c_char_p, c_f32p, ctypes.POINTER(i64), i32]),
     'dcf_model_set_pe': (i32, [vp, c_f32p, i64]),
+    'dcf_model_set_text_pe': (i32, [vp, c_f32p, i64]),
+    'dcf_text_encode': (i32, [vp, c_f32p, c_u8p, i32, c_f32p, c_u8p, vp]),
     'dcf_model_finalize': (i32, [vp, vp]),
     'dcf_points_per_query': (i64, [vp, i64]),
     'dcf_forward_eval': (i32, [vp, c_f32p, c_f32p, c_u8p, i64, i32, ctypes.POINTER(vp), ctypes.POINTER(vp),

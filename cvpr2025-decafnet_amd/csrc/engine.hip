@@ -120,6 +120,10 @@ struct DecW {   // one TransformerDecoder of the fusion
   const float *wq, *bq, *wk, *bk, *wv, *bv, *wp, *bp;
   const float *ln_ffn_w, *ln_ffn_b, *fc_w, *fc_b, *pj_w, *pj_b, *ls_ffn;
 };
+struct TextEncW {   // one TransformerEncoder of text_net (stride 0: no depthwise convs, global attention)
+  const float *ln_attn_w, *ln_attn_b, *wq, *bq, *wk, *bk, *wv, *bv, *wp, *bp, *ls_attn;
+  const float *ln_ffn_w, *ln_ffn_b, *fc_w, *fc_b, *pj_w, *pj_b, *ls_ffn;
+};
 struct HeadW {
   std::vector<const float*> conv;            // packed [N][3][Cin]
   std::vector<const float*> ln_w, ln_b;
@@ -159,6 +163,13 @@ struct dcf_model {
   std::vector<float> reg_scales;             // host copy of reg_head.scales.{l}.scale
   const float *tcn_in_w = nullptr, *tcn_in_b = nullptr, *tcn_out_w = nullptr, *tcn_out_b = nullptr;
   std::vector<const float*> tcn_wd, tcn_bd, tcn_wp, tcn_bp, tcn_lnw, tcn_lnb;
+  // text_net (TextTransformer, text_net.py:92-188); empty when cfg.text_layers == 0
+  const float *text_embd_w = nullptr, *text_embd_b = nullptr, *text_bkgd = nullptr;
+  std::vector<TextEncW> text_enc;
+  const float* text_pe = nullptr;            // (text_pe_L, TE) token-major, borrowed
+  int64_t text_pe_L = 0;
+  char* text_ws = nullptr;
+  size_t text_ws_bytes = 0;
 
   // workspace
   char* arena = nullptr;
@@ -212,6 +223,7 @@ static int free_model(dcf_model* m) {
   if (m->arena) (void)hipFree(m->arena);
   if (m->h_meta) (void)hipHostFree(m->h_meta);
   if (m->d_meta) (void)hipFree(m->d_meta);
+  if (m->text_ws) (void)hipFree(m->text_ws);
   for (int i = 0; i < 2; ++i) {
     if (m->ev_fork[i]) (void)hipEventDestroy(m->ev_fork[i]);
     if (m->ev_join[i]) (void)hipEventDestroy(m->ev_join[i]);
@@ -322,6 +334,32 @@ static int finalize(dcf_model* m, hipStream_t st) {
   m->cls1 = HeadW(); m->cls2 = HeadW(); m->reg = HeadW();
   m->tcn_wd.clear(); m->tcn_bd.clear(); m->tcn_wp.clear(); m->tcn_bp.clear(); m->tcn_lnw.clear(); m->tcn_lnb.clear();
   const float* t;
+
+  m->text_enc.clear();
+  m->text_embd_w = m->text_embd_b = m->text_bkgd = nullptr;
+  if (c.text_layers > 0 || c.text_in > 0) {
+    DCF_CHECK(c.text_in > 0 && c.text_layers >= 0 && c.text_heads >= 1 && TE % c.text_heads == 0,
+              "text_net: in_dim=%d layers=%d heads=%d do not fit TE=%d", c.text_in, c.text_layers, c.text_heads, TE);
+    GET("text_net.embd_fc.conv.weight", SH(TE, c.text_in), m->text_embd_w); GET("text_net.embd_fc.conv.bias", SH(TE), m->text_embd_b);
+    if (c.text_bkgd) GET("text_net.bkgd_token", SH(TE), m->text_bkgd);
+    for (int i = 0; i < c.text_layers; ++i) {
+      const std::string p = "text_net.transformer." + std::to_string(i);
+      TextEncW w{};
+      GET(p + ".ln_attn.weight", SH(TE), w.ln_attn_w); GET(p + ".ln_attn.bias", SH(TE), w.ln_attn_b);
+      GET(p + ".attn.attn.query.weight", SH(TE, TE), w.wq); GET(p + ".attn.attn.query.bias", SH(TE), w.bq);
+      GET(p + ".attn.attn.key.weight", SH(TE, TE), w.wk); GET(p + ".attn.attn.key.bias", SH(TE), w.bk);
+      GET(p + ".attn.attn.value.weight", SH(TE, TE), w.wv); GET(p + ".attn.attn.value.bias", SH(TE), w.bv);
+      GET(p + ".attn.attn.proj.weight", SH(TE, TE), w.wp); GET(p + ".attn.attn.proj.bias", SH(TE), w.bp);
+      GET(p + ".drop_path_attn.scale", SH(TE), w.ls_attn);
+      GET(p + ".ln_ffn.weight", SH(TE), w.ln_ffn_w); GET(p + ".ln_ffn.bias", SH(TE), w.ln_ffn_b);
+      GET(p + ".ffn.fc.weight", SH(4 * TE, TE), w.fc_w); GET(p + ".ffn.fc.bias", SH(4 * TE), w.fc_b);
+      GET(p + ".ffn.proj.weight", SH(TE, 4 * TE), w.pj_w); GET(p + ".ffn.proj.bias", SH(TE), w.pj_b);
+      GET(p + ".drop_path_ffn.scale", SH(TE), w.ls_ffn);
+      SPLIT(w.wq, TE, TE); SPLIT(w.wk, TE, TE); SPLIT(w.wv, TE, TE); SPLIT(w.wp, TE, TE);
+      SPLIT(w.fc_w, 4 * TE, TE); SPLIT(w.pj_w, TE, 4 * TE);
+      m->text_enc.push_back(w);
+    }
+  }
 
   if (c.model_kind == 1) {   // PtTransformer: vid_net.embd_fc takes the (2)D-wide gated input itself (model.py:43-48)
     GET("vid_net.embd_fc.conv.weight", SH(E, Din), m->vid_map_w); GET("vid_net.embd_fc.conv.bias", SH(E), m->vid_map_b);
@@ -852,6 +890,58 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
   return 0;
 }
 
+// TextTransformer.forward (text_net.py:158-188) for one query: embd_fc 1x1 on x * mask, + pe * mask, background
+// token, n x TransformerEncoder(stride 0) (blocks.py:578-591 with global MaskedMHA, blocks.py:374-393).
+// tokens (C_t, Lq) channel-major -> text_out (TE, Lk) channel-major (the layout dcf_forward_eval takes), Lk = Lq + bkgd.
+static int text_encode(dcf_model* m, const float* tokens, const uint8_t* token_mask, int Lq, float* text_out, uint8_t* mask_out,
+                       hipStream_t st) {
+  const dcf_config& c = m->cfg;
+  DCF_CHECK(m->finalized, "dcf_text_encode: model not finalized");
+  DCF_CHECK(m->text_embd_w, "dcf_text_encode: the model was created without a text encoder (text_in / text_layers = 0)");
+  DCF_CHECK(Lq >= 1 && tokens && text_out && mask_out, "dcf_text_encode: bad arguments");
+  const int TE = c.TE, Lk = Lq + (c.text_bkgd ? 1 : 0);
+  if (c.text_abs_pe) DCF_CHECK(m->text_pe && m->text_pe_L >= Lq, "text position encoding for %d tokens not set (dcf_model_set_text_pe)", Lq);
+  // workspace: X, X2, R0, Q, K, V [Lk][TE]; HID [Lk][4 TE]
+  const size_t rowB = ((size_t)Lk * TE * sizeof(float) + 255) & ~(size_t)255;
+  const size_t need = 10 * rowB;
+  if (need > m->text_ws_bytes) {
+    DCF_HIP(hipStreamSynchronize(st));
+    if (m->text_ws) DCF_HIP(hipFree(m->text_ws));
+    m->text_ws = nullptr; m->text_ws_bytes = 0;
+    DCF_HIP(hipMalloc(&m->text_ws, need));
+    m->text_ws_bytes = need;
+  }
+  auto buf = [&](int i) { return reinterpret_cast<float*>(m->text_ws + (size_t)i * rowB); };
+  float *X = buf(0), *X2 = buf(1), *R0 = buf(2), *Q = buf(3), *K = buf(4), *V = buf(5), *HID = buf(6);   // HID spans 4 slots
+
+  TextEmbedArgs te{tokens, token_mask, m->text_embd_w, m->text_embd_b, c.text_abs_pe ? m->text_pe : nullptr, m->text_bkgd, X, mask_out,
+                   c.text_in, Lq, TE};
+  TRY(launch_text_embed(te, st));
+  for (const TextEncW& w : m->text_enc) {
+    TRY(launch_mask_rows(X, mask_out, Lk, TE, st));                                   // x = x * mask   (blocks.py:581)
+    LnArgs ln{}; ln.X = X; ln.ldx = TE; ln.Y = R0; ln.ldy = TE; ln.w = w.ln_attn_w; ln.b = w.ln_attn_b; ln.rows = Lk; ln.C = TE;
+    TRY(launch_ln(ln, st));
+    GemmArgs g3[3] = {gemm(R0, TE, w.wq, w.bq, Q, TE, Lk, TE, TE), gemm(R0, TE, w.wk, w.bk, K, TE, Lk, TE, TE),
+                      gemm(R0, TE, w.wv, w.bv, V, TE, Lk, TE, TE)};
+    TRY(run_gemm(m, g3, 3, A_ROWS, st));
+    XAttnArgs xa{Q, K, V, mask_out, R0, 1, Lk, Lk, TE, c.text_heads};                   // softmax over the valid tokens
+    TRY(launch_xattn(xa, st));
+    GemmArgs gp = gemm(R0, TE, w.wp, w.bp, X2, TE, Lk, TE, TE);                        // x = skip * mask + ls * proj(ctx)
+    gp.flags = G_RES; gp.R = X; gp.ldr = TE; gp.ls = w.ls_attn;
+    TRY(run_gemm(m, &gp, 1, A_ROWS, st));
+    LnArgs l2{}; l2.X = X2; l2.ldx = TE; l2.Y = R0; l2.ldy = TE; l2.w = w.ln_ffn_w; l2.b = w.ln_ffn_b; l2.rows = Lk; l2.C = TE;
+    TRY(launch_ln(l2, st));
+    GemmArgs gf = gemm(R0, TE, w.fc_w, w.fc_b, HID, 4 * TE, Lk, 4 * TE, TE);
+    gf.flags = G_GELU;
+    TRY(run_gemm(m, &gf, 1, A_ROWS, st));
+    GemmArgs go = gemm(HID, 4 * TE, w.pj_w, w.pj_b, X, TE, Lk, TE, 4 * TE);             // x += ls * (ffn * mask)
+    go.flags = G_RES | G_OUT_MASK; go.rowmask = mask_out; go.R = X2; go.ldr = TE; go.ls = w.ls_ffn;
+    TRY(run_gemm(m, &go, 1, A_ROWS, st));
+  }
+  TRY(launch_rows_to_chanmajor(X, text_out, Lk, TE, st));
+  return 0;
+}
+
 }  // namespace dcf
 
 // =============================================================================================
@@ -860,7 +950,7 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
 extern "C" {
 
 const char* dcf_last_error(void) { return dcf::g_err.c_str(); }
-int dcf_abi_version(void) { return 1; }
+int dcf_abi_version(void) { return 2; }
 
 int dcf_model_create(const dcf_config* cfg, dcf_model** out) {
   DCF_CHECK(cfg && out, "dcf_model_create: null argument");
@@ -961,6 +1051,19 @@ int dcf_model_set_pe(dcf_model* m, const float* pe_tokens, int64_t T) {
   m->pe = pe_tokens;
   m->pe_T = T;
   return 0;
+}
+
+int dcf_model_set_text_pe(dcf_model* m, const float* pe_tokens, int64_t L) {
+  DCF_CHECK(m, "dcf_model_set_text_pe: null model");
+  m->text_pe = pe_tokens;
+  m->text_pe_L = L;
+  return 0;
+}
+
+int dcf_text_encode(dcf_model* m, const float* tokens, const uint8_t* token_mask, int32_t Lq, float* text_out, uint8_t* mask_out,
+                    void* stream) {
+  DCF_CHECK(m, "dcf_text_encode: null model");
+  return dcf::text_encode(m, tokens, token_mask, Lq, text_out, mask_out, (hipStream_t)stream);
 }
 
 int dcf_model_finalize(dcf_model* m, void* stream) {

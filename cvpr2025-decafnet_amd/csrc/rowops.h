@@ -49,6 +49,21 @@ struct TextMeta {                   // lives in device memory
   int len[DCF_MAX_BATCH];
 };
 
+// text_net front end (text_net.py:158-181): tokens (C_t, Lq) channel-major -> rows [Lk][TE] token-major
+struct TextEmbedArgs {
+  const float* tokens;              // (C_t, Lq)
+  const uint8_t* mask;              // (Lq) or nullptr (= all valid)
+  const float* W; const float* bias;  // embd_fc (TE, C_t), (TE)
+  const float* pe;                  // (>= Lq, TE) token-major or nullptr
+  const float* bkgd;                // (TE) or nullptr
+  float* X;                         // [Lk][TE]
+  uint8_t* mask_out;                // [Lk]
+  int Ct, Lq, TE;
+};
+int launch_text_embed(const TextEmbedArgs& a, hipStream_t st);
+int launch_mask_rows(float* X, const uint8_t* mask, int rows, int C, hipStream_t st);                 // X[r][:] *= mask[r]
+int launch_rows_to_chanmajor(const float* X, float* out, int rows, int C, hipStream_t st);           // out[c][r] = X[r][c]
+
 struct TextLnArgs {
   const TextMeta* meta;
   float* out;                       // [B*Lkmax][TE]

@@ -305,6 +305,47 @@ __global__ __launch_bounds__(64) void k_text_ln(TextLnArgs p) {
   if (lane == 0 && p.kvmask) p.kvmask[b * p.Lkmax + j] = p.meta->text_mask[b] ? p.meta->text_mask[b][j] : 1;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// TextTransformer front end (text_net.py:166-181): MaskedConv1D 1x1 on x * mask (the bias is added at padded
+// tokens too, blocks.py:63-106), + pe * mask, background token prepended, mask = cat(mask[:1], mask).
+// One workgroup per output row; a few hundred KFLOP per query, T independent.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_text_embed(TextEmbedArgs p) {
+  const int j = blockIdx.x;                              // output row
+  const int off = p.bkgd ? 1 : 0;
+  float* out = p.X + (int64_t)j * p.TE;
+  if (j < off) {
+    for (int c = threadIdx.x; c < p.TE; c += 256) out[c] = p.bkgd[c];
+    if (threadIdx.x == 0) p.mask_out[0] = p.mask ? p.mask[0] : 1;
+    return;
+  }
+  const int t = j - off;
+  const float mk = (!p.mask || p.mask[t]) ? 1.f : 0.f;
+  for (int c = threadIdx.x; c < p.TE; c += 256) {
+    const float* w = p.W + (int64_t)c * p.Ct;
+    float acc = 0.f;
+    for (int k = 0; k < p.Ct; ++k) acc += w[k] * (p.tokens[(int64_t)k * p.Lq + t] * mk);
+    acc += p.bias ? p.bias[c] : 0.f;
+    if (p.pe) acc += p.pe[(int64_t)t * p.TE + c] * mk;
+    out[c] = acc;
+  }
+  if (threadIdx.x == 0) p.mask_out[j] = mk != 0.f;
+}
+
+__global__ void k_mask_rows(float* __restrict__ X, const uint8_t* __restrict__ mask, int rows, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * C) return;
+  if (!mask[i / C]) X[i] = 0.f;
+}
+
+__global__ void k_rows_to_chanmajor(const float* __restrict__ X, float* __restrict__ out, int rows, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // index into out: c * rows + r
+  if (i >= rows * C) return;
+  const int c = i / rows, r = i - c * rows;
+  out[i] = X[(int64_t)r * C + c];
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
@@ -397,6 +438,28 @@ int launch_enc_pre(const EncPreArgs& a_, int stride, hipStream_t st) {
     DCF_CHECK(a.Skip, "enc_pre: stride 2 needs a skip buffer");
     DISPATCH_NCH(a.C, hipLaunchKernelGGL((k_enc_pre<NCH, 2>), dim3((strips + 3) / 4), dim3(256), 0, st, a));
   }
+  return 0;
+}
+
+int launch_text_embed(const TextEmbedArgs& a, hipStream_t st) {
+  DCF_CHECK(a.Lq >= 1 && a.Ct >= 1 && a.TE >= 1, "text_embed: empty input");
+  const int Lk = a.Lq + (a.bkgd ? 1 : 0);
+  hipLaunchKernelGGL(k_text_embed, dim3(Lk), dim3(256), 0, st, a);
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_mask_rows(float* X, const uint8_t* mask, int rows, int C, hipStream_t st) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(k_mask_rows, dim3((rows * C + 255) / 256), dim3(256), 0, st, X, mask, rows, C);
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_rows_to_chanmajor(const float* X, float* out, int rows, int C, hipStream_t st) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(k_rows_to_chanmajor, dim3((rows * C + 255) / 256), dim3(256), 0, st, X, out, rows, C);
+  DCF_HIP(hipGetLastError());
   return 0;
 }
 

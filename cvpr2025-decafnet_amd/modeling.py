@@ -233,7 +233,8 @@ class TextTransformer(nn.Module):
 
     def __init__(self, in_dim, embd_dim, n_heads, max_seq_len, n_layers=5, use_abs_pe=True, use_bkgd_token=True, **_):
         super().__init__()
-        self.max_seq_len, self.n_heads = max_seq_len, n_heads
+        self.max_seq_len, self.n_heads, self.in_dim, self.embd_dim = max_seq_len, n_heads, in_dim, embd_dim
+        self.use_abs_pe, self.use_bkgd_token = bool(use_abs_pe), bool(use_bkgd_token)
         self.embd_fc = MaskedConv1D(in_dim, embd_dim, 1)
         if use_abs_pe:
             pe = sinusoid_encoding(max_seq_len, embd_dim // 2) / embd_dim ** 0.5
@@ -250,42 +251,9 @@ class TextTransformer(nn.Module):
             if isinstance(mod, nn.Conv1d) and mod.bias is not None:
                 nn.init.zeros_(mod.bias)
 
-    def _encoder(self, blk: TransformerEncoder, x, mask):
-        mf = mask.to(x.dtype)
-        x = x * mf
-        h = _chan_ln(x, blk.ln_attn)
-        a = blk.attn.attn
-        q, k, v = a.query(h), a.key(h), a.value(h)
-        bs, c, t = q.shape
-        nh = self.n_heads
-        d = c // nh
-        scale = 1.0 / math.sqrt(math.sqrt(d))
-        q = q.view(bs, nh, d, t).transpose(2, 3) * scale
-        k = k.view(bs, nh, d, t) * scale
-        v = v.view(bs, nh, d, t).transpose(2, 3)
-        att = (q @ k).masked_fill(~mask[:, :, None, :], float('-inf'))
-        att = F.softmax(att, dim=-1)
-        h = a.proj((att @ v).transpose(2, 3).reshape(bs, c, t))
-        x = x * mf + blk.drop_path_attn.scale * h
-        h = blk.ffn.proj(F.gelu(blk.ffn.fc(_chan_ln(x, blk.ln_ffn)))) * mf
-        return x + blk.drop_path_ffn.scale * h
-
     def forward(self, x, mask):
-        bs, _, t = x.size()
-        if mask.ndim == 2:
-            mask = mask.unsqueeze(1)
-        x = self.embd_fc.conv(x * mask.to(x.dtype))
-        if self.pe is not None:
-            pe = self.pe.to(x.dtype)
-            if t > self.max_seq_len:
-                pe = F.interpolate(pe[None], size=t, mode='linear', align_corners=True)[0]
-            x = x + pe[..., :t] * mask.to(x.dtype)
-        if self.bkgd_token is not None:
-            x = torch.cat((self.bkgd_token.repeat(bs, 1, 1), x), dim=-1)
-            mask = torch.cat((mask[..., :1], mask), dim=-1)
-        for blk in self.transformer:
-            x = self._encoder(blk, x, mask)
-        return x, mask
+        raise RuntimeError('TextTransformer is a parameter container here: call model.encode_text(tokens, token_masks), '
+                           'which runs the text encoder on the MI355X (dcf_text_encode); there is no CPU path')
 
 
 # ------------------------------------------------------------------------------------------
@@ -301,6 +269,7 @@ class _Engine:
         self.signature = None
         self.keepalive = []
         self.pe_cache = {}
+        self.text_pe_cache = {}
 
     def __del__(self):
         try:
@@ -326,6 +295,46 @@ class _Engine:
         _lib.check(self.lib.dcf_model_finalize(self.handle, _lib.current_stream()), 'dcf_model_finalize')
         self.keepalive = keep
         self.signature = sig
+
+
+def _text_config(c, tn):
+    c.text_in, c.text_layers, c.text_heads = tn.in_dim, len(tn.transformer), tn.n_heads
+    c.text_abs_pe, c.text_bkgd = int(tn.use_abs_pe), int(tn.use_bkgd_token)
+
+
+def _encode_text(model, tokens, token_masks):
+    """TextTransformer.forward through the C ABI, one query at a time (the reference calls it with bs = 1,
+    worker_v2.py:953)."""
+    if not tokens.is_cuda:
+        raise RuntimeError('encode_text runs on the MI355X only: move the tokens to the GPU')
+    if model._engine is None:
+        model._engine = _Engine(model._config())
+    eng = model._engine
+    eng.bind(model._named_engine_tensors())
+    tn = model.text_net
+    bs, ct, lq = tokens.shape
+    assert ct == tn.in_dim, (ct, tn.in_dim)
+    lk = lq + int(tn.use_bkgd_token)
+    te = tn.embd_dim
+    if token_masks is None:
+        token_masks = torch.ones(bs, 1, lq, dtype=torch.bool, device=tokens.device)
+    masks = token_masks.reshape(bs, lq).to(torch.bool).contiguous()
+    if tn.use_abs_pe:
+        key = lq
+        if key not in eng.text_pe_cache:
+            pe = tn.pe.float()
+            if lq > tn.max_seq_len:                                              # text_net.py:172-177
+                pe = F.interpolate(pe[None], size=lq, mode='linear', align_corners=True)[0]
+            eng.text_pe_cache[key] = pe[:, :lq].t().contiguous().to(tokens.device)
+        pe_t = eng.text_pe_cache[key]
+        _lib.check(eng.lib.dcf_model_set_text_pe(eng.handle, _lib.ptr(pe_t), lq), 'dcf_model_set_text_pe')
+    out = torch.empty(bs, te, lk, dtype=torch.float32, device=tokens.device)
+    out_mask = torch.empty(bs, 1, lk, dtype=torch.bool, device=tokens.device)
+    tok = tokens.contiguous().float()
+    for b in range(bs):
+        _lib.check(eng.lib.dcf_text_encode(eng.handle, _lib.ptr(tok[b]), _lib.ptr(masks[b]), lq, _lib.ptr(out[b]),
+                                           _lib.ptr(out_mask[b]), _lib.current_stream()), 'dcf_text_encode')
+    return out, out_mask
 
 
 class PtTransformerEarlyFusionIterative(nn.Module):
@@ -382,8 +391,9 @@ class PtTransformerEarlyFusionIterative(nn.Module):
 
     # -- reference API ---------------------------------------------------------------------
     def encode_text(self, tokens, token_masks):
-        """model.py:434-436: tokens (1, C_t, Lq) f32, token_masks (1, 1, Lq) bool -> ((1, TE, Lq+1), (1, 1, Lq+1))."""
-        return self.text_net(tokens, token_masks)
+        """model.py:434-436: tokens (bs, C_t, Lq) f32, token_masks (bs, 1, Lq) bool -> ((bs, TE, Lk), (bs, 1, Lk)),
+        Lk = Lq + use_bkgd_token.  Runs TextTransformer.forward (text_net.py:158-188) on the GPU (dcf_text_encode)."""
+        return _encode_text(self, tokens, token_masks)
 
     def forward(self, vid, shallow_vid, vid_masks, text, text_cls, text_masks, text_size=None, mv_data=None, eval=False):
         if not eval:
@@ -402,10 +412,11 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         c.use_abs_pe, c.max_batch = int(vn.use_abs_pe), self.max_batch
         c.gemm_mode = self.gemm_mode
         c.model_kind, c.second_fusion = self.MODEL_KIND, int(bool(self.second_fusion))
+        _text_config(c, self.text_net)
         return c
 
     def _named_engine_tensors(self):
-        return [(n, p) for n, p in self.state_dict(keep_vars=True).items() if not n.startswith('text_net.')]
+        return list(self.state_dict(keep_vars=True).items())
 
     def _position_encoding(self, T, device):
         """vid_net.pe for length T, token-major (T, E) (video_net.py:75-78,141-151)."""

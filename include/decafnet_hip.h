@@ -51,6 +51,12 @@ typedef struct dcf_config {
   int32_t model_kind;     /* 0 = PtTransformerEarlyFusionIterative (libs/modeling/model.py:397),
                            * 1 = PtTransformer, late fusion (model.py:30)                            */
   int32_t second_fusion;  /* model_kind 0: also fuse every pyramid level before the heads (model.py:443) */
+  /* text_net = TextTransformer (libs/modeling/text_net.py:92-188); text_in = 0 builds the model without it */
+  int32_t text_in;        /* opt.model.text_net.in_dim (token feature dim C_t)                     */
+  int32_t text_layers;    /* opt.model.text_net.n_layers                                           */
+  int32_t text_heads;     /* opt.model.text_net.n_heads                                            */
+  int32_t text_abs_pe;    /* opt.model.text_net.use_abs_pe                                         */
+  int32_t text_bkgd;      /* opt.model.text_net.use_bkgd_token                                     */
 } dcf_config;
 
 int dcf_model_create(const dcf_config* cfg, dcf_model** out);
@@ -59,7 +65,7 @@ void dcf_model_destroy(dcf_model* m);
 /* Bind one tensor of the reference state_dict by its NAME (the parameter ABI):
  * "vid_map.conv.weight", "fusion.layers.0.xattn.xattn.query.weight", ...  The memory is borrowed
  * (fp32, contiguous, device) and must stay alive until the model is destroyed or re-bound.
- * text_net.* tensors are accepted and ignored (the text encoder is host-side PyTorch).
+ * text_net.* tensors feed dcf_text_encode (ignored when cfg.text_in == 0).
  * Replaces nn.Module.load_state_dict(ckpt['model_ema']) (libs/worker_v2.py:806-812). */
 int dcf_model_bind(dcf_model* m, const char* name, const float* data, const int64_t* shape, int32_t ndim);
 
@@ -67,6 +73,19 @@ int dcf_model_bind(dcf_model* m, const char* name, const float* data, const int6
  * libs/modeling/video_net.py:75-78): token-major (T, E) fp32 already resampled for length T
  * (video_net.py:141-151).  Borrowed.  Needed only when use_abs_pe != 0. */
 int dcf_model_set_pe(dcf_model* m, const float* pe_tokens, int64_t T);
+
+/* Position encoding buffer `text_net.pe` (non-persistent, text_net.py:120-125): token-major (L, TE) fp32,
+ * L >= the longest query (already resampled if longer than max_seq_len, text_net.py:172-177).  Borrowed. */
+int dcf_model_set_text_pe(dcf_model* m, const float* pe_tokens, int64_t L);
+
+/* Text encoder of one query: replaces model.encode_text(tokens, token_masks) = TextTransformer.forward
+ * (libs/modeling/model.py:434-436, text_net.py:158-188; caller libs/worker_v2.py:953).
+ *   tokens     : (C_t, Lq) fp32 channel-major = tensor[0] of the reference's (1, C_t, Lq) input
+ *   token_mask : (Lq) bytes, 1 = valid token; NULL = all valid
+ *   text_out   : (TE, Lk) fp32 channel-major, Lk = Lq + use_bkgd_token  (the layout dcf_forward_eval takes)
+ *   mask_out   : (Lk) bytes = cat(mask[:1], mask) */
+int dcf_text_encode(dcf_model* m, const float* tokens, const uint8_t* token_mask, int32_t Lq, float* text_out,
+                    uint8_t* mask_out, void* stream);
 
 /* Validate that every parameter is bound and repack convolution weights for the kernels. */
 int dcf_model_finalize(dcf_model* m, void* stream);
