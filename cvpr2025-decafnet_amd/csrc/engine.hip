@@ -578,6 +578,11 @@ static int run_gemm(dcf_model* m, GemmArgs* g, int count, GemmAMode mode, hipStr
   return split ? launch_gemm_split(g, count, mode, m->gemm_terms, st) : launch_gemm(g, count, mode, st);
 }
 
+// can this GEMM carry its LayerNorm in the epilogue?  (bf16-split path with planes for W, tile spanning the row)
+static bool can_fuse_ln(dcf_model* m, const float* W, int M, int N, int K, GemmAMode mode) {
+  return m->gemm_terms != 0 && m->wsplit.count(W) && m->wsplit_ldw[W] == K && gemm_can_fuse_ln(M, N, K, mode);
+}
+
 // TransformerEncoder (vid_net) at one level.  Xin: [B*T_in][ldx]; output rows [B*T_out] at Xout (ld ldo).
 static int run_encoder(dcf_model* m, const EncW& w, Buffers& b, const float* Xin, int64_t ldx, const uint8_t* mask_in,
                        const uint8_t* mask_out, int B, int T_in, int stride, float* Xout, int64_t ldo, hipStream_t st) {
@@ -599,9 +604,14 @@ static int run_encoder(dcf_model* m, const EncW& w, Buffers& b, const float* Xin
   GemmArgs gp = gemm(b.R[0], E, w.wp, w.bp, b.R[1], E, rows, E, E);
   gp.flags = G_RES | G_RES_MASK; gp.rowmask = mask_out; gp.ls = w.ls_attn;
   if (stride == 2) { gp.R = b.R[3]; gp.ldr = E; } else { gp.R = Xin; gp.ldr = ldx; }
-  TRY(run_gemm(m, &gp, 1, A_ROWS, st));
-  LnArgs ln{}; ln.X = b.R[1]; ln.ldx = E; ln.Y = b.R[2]; ln.ldy = E; ln.w = w.ln_ffn_w; ln.b = w.ln_ffn_b; ln.rows = rows; ln.C = E;
-  TRY(launch_ln(ln, st));
+  if (can_fuse_ln(m, w.wp, rows, E, E, A_ROWS)) {                 // ln_ffn(x') rides in the epilogue
+    gp.ln_w = w.ln_ffn_w; gp.ln_b = w.ln_ffn_b; gp.Y = b.R[2]; gp.ldy = E;
+    TRY(run_gemm(m, &gp, 1, A_ROWS, st));
+  } else {
+    TRY(run_gemm(m, &gp, 1, A_ROWS, st));
+    LnArgs ln{}; ln.X = b.R[1]; ln.ldx = E; ln.Y = b.R[2]; ln.ldy = E; ln.w = w.ln_ffn_w; ln.b = w.ln_ffn_b; ln.rows = rows; ln.C = E;
+    TRY(launch_ln(ln, st));
+  }
   GemmArgs gf = gemm(b.R[2], E, w.fc_w, w.fc_b, b.HID, 4 * E, rows, 4 * E, E);
   gf.flags = G_GELU;
   TRY(run_gemm(m, &gf, 1, A_ROWS, st));
@@ -626,11 +636,18 @@ static int run_head(dcf_model* m, const HeadW& h, Buffers& b, const Plan& pl, in
   for (size_t i = 0; i < h.conv.size(); ++i) {
     GemmArgs g = gemm(in, ldin, h.conv[i], nullptr, HA, Cin, rowsAll, Cin, 3 * Cin);
     g.cin = Cin; g.nbr = nbr;
-    TRY(run_gemm(m, &g, 1, A_ROWS_TAP3, st));
-    LnArgs ln{}; ln.X = HA; ln.ldx = Cin; ln.Y = HB; ln.ldy = Cin; ln.w = h.ln_w[i]; ln.b = h.ln_b[i];
-    ln.rows = rowsAll; ln.C = Cin; ln.relu = 1;
-    TRY(launch_ln(ln, st));
-    in = HB; ldin = Cin;
+    float* outp = (in == HB) ? HA : HB;                          // ping-pong between the two trunk buffers
+    if (can_fuse_ln(m, h.conv[i], rowsAll, Cin, 3 * Cin, A_ROWS_TAP3)) {
+      g.C = nullptr; g.ln_w = h.ln_w[i]; g.ln_b = h.ln_b[i]; g.Y = outp; g.ldy = Cin; g.ln_relu = 1;
+      TRY(run_gemm(m, &g, 1, A_ROWS_TAP3, st));
+    } else {
+      g.C = outp;                                                // raw conv output, normalised in place
+      TRY(run_gemm(m, &g, 1, A_ROWS_TAP3, st));
+      LnArgs ln{}; ln.X = outp; ln.ldx = Cin; ln.Y = outp; ln.ldy = Cin; ln.w = h.ln_w[i]; ln.b = h.ln_b[i];
+      ln.rows = rowsAll; ln.C = Cin; ln.relu = 1;
+      TRY(launch_ln(ln, st));
+    }
+    in = outp; ldin = Cin;
   }
   ConvOutArgs co{};
   co.X = in; co.ldx = ldin; co.nbr = nbr; co.W = h.out_w; co.bias = h.out_b; co.lt = pl.d_lt;
@@ -677,6 +694,12 @@ static int run_fusion(dcf_model* m, Buffers& b, float* X, int64_t ldx, int B, in
     TRY(run_gemm(m, &gf, 1, A_ROWS, st));
     GemmArgs go = gemm(b.HID, 4 * E, w.pj_w, w.pj_b, X, ldx, rows, E, 4 * E);
     go.flags = G_RES | G_OUT_MASK; go.rowmask = mask; go.ls = w.ls_ffn; go.R = b.R[2]; go.ldr = E;
+    if (li + 1 == m->dec.size() && can_fuse_ln(m, w.pj_w, rows, E, 4 * E, A_ROWS)) {
+      // last layer: only ln_out(x) is consumed afterwards (fusion.py:64-66), the raw stream is not written
+      go.C = nullptr; go.ln_w = m->fus_out_w; go.ln_b = m->fus_out_b; go.Y = out; go.ldy = ld_out;
+      TRY(run_gemm(m, &go, 1, A_ROWS, st));
+      return 0;
+    }
     TRY(run_gemm(m, &go, 1, A_ROWS, st));
   }
   LnArgs ln{}; ln.X = X; ln.ldx = ldx; ln.Y = out; ln.ldy = ld_out; ln.w = m->fus_out_w; ln.b = m->fus_out_b; ln.rows = rows; ln.C = E;
@@ -815,11 +838,21 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
       for (int i = 0; i < c.n_embd_convs; ++i) {
         GemmArgs g = gemm(b.X, E, m->embd_conv[i], nullptr, b.R[0], E, rows0, E, 3 * E);
         g.cin = E; g.nbr = b.nbr_all;
-        TRY(run_gemm(m, &g, 1, A_ROWS_TAP3, st));
-        LnArgs ln{}; ln.X = b.R[0]; ln.ldx = E; ln.Y = b.X; ln.ldy = E; ln.w = m->embd_ln_w[i]; ln.b = m->embd_ln_b[i];
-        ln.rows = rows0; ln.C = E; ln.relu = 1;
-        if (c.use_abs_pe && i == c.n_embd_convs - 1) { ln.pe = m->pe; ln.mask = mask0; ln.T = T0; }
-        TRY(launch_ln(ln, st));
+        const bool with_pe = c.use_abs_pe && i == c.n_embd_convs - 1;
+        if (can_fuse_ln(m, m->embd_conv[i], rows0, E, 3 * E, A_ROWS_TAP3)) {
+          // conv -> LN -> ReLU (+ pe * mask) in one kernel; the result goes to R[3] (same size as X) because the k3
+          // taps of other workgroups still read X, then X and R[3] swap roles
+          g.C = nullptr; g.ln_w = m->embd_ln_w[i]; g.ln_b = m->embd_ln_b[i]; g.Y = b.R[3]; g.ldy = E; g.ln_relu = 1;
+          if (with_pe) { g.ln_pe = m->pe; g.ln_mask = mask0; g.ln_T = T0; }
+          TRY(run_gemm(m, &g, 1, A_ROWS_TAP3, st));
+          std::swap(b.X, b.R[3]);
+        } else {
+          TRY(run_gemm(m, &g, 1, A_ROWS_TAP3, st));
+          LnArgs ln{}; ln.X = b.R[0]; ln.ldx = E; ln.Y = b.X; ln.ldy = E; ln.w = m->embd_ln_w[i]; ln.b = m->embd_ln_b[i];
+          ln.rows = rows0; ln.C = E; ln.relu = 1;
+          if (with_pe) { ln.pe = m->pe; ln.mask = mask0; ln.T = T0; }
+          TRY(launch_ln(ln, st));
+        }
       }
       if (c.use_abs_pe && c.n_embd_convs == 0) {
         LnArgs ln{}; ln.X = b.X; ln.ldx = E; ln.Y = b.X; ln.ldy = E; ln.rows = rows0; ln.C = E; ln.skip_ln = 1;

@@ -37,6 +37,17 @@ struct GemmArgs {
   int64_t ldr;
   const float* ls;         // [N] layer scale (G_RES); nullptr = 1
   int flags;
+  // Optional fused channel LayerNorm of the output row (bf16-split kernel only, tile must span all N columns, see
+  // gemm_can_fuse_ln): Y = LN(v) * ln_w + ln_b [ReLU] [+ ln_pe[row % ln_T] * rowmask[row]], v = the epilogue value
+  // that goes to C.  C may be nullptr when only the normalised rows are needed.
+  const float* ln_w;       // [N] or nullptr = no fused LayerNorm
+  const float* ln_b;       // [N]
+  float* Y;                // [M][ldy]
+  int64_t ldy;
+  int ln_relu;
+  const float* ln_pe;      // optional (ln_T, N) position encoding added where ln_mask != 0
+  const uint8_t* ln_mask;  // [M] (with ln_pe)
+  int ln_T;
 };
 
 // Launch up to 3 independent GEMMs of identical (M, N, K, mode) in one grid (blockIdx.z).
@@ -45,5 +56,8 @@ int launch_gemm(const GemmArgs* g, int count, GemmAMode mode, hipStream_t stream
 // fp32-accurate GEMM on the bf16 matrix cores by operand splitting (gemm_bf16s.hip); nterms = 6 or 3
 int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, hipStream_t stream);
 int launch_split_planes(const float* W, unsigned short* out, int N, int K, int64_t ldw, hipStream_t st);
+// true if launch_gemm_split can run g with its LayerNorm fused (one tile spans all N columns and the grid still
+// fills the chip); otherwise the caller launches the LayerNorm kernel itself
+bool gemm_can_fuse_ln(int M, int N, int K, GemmAMode mode);
 
 }  // namespace dcf

@@ -75,7 +75,9 @@ int launch_split_planes(const float* W, unsigned short* out, int N, int K, int64
 }
 
 // 3 waves per SIMD (<= 168 registers): measured 3.16 -> 3.00 ms per step over the compiler's default of 2
-template <int WM, int WN, int TM, int TN, int AMODE, int NTERMS>
+// LN = true: the variant with the fused LayerNorm epilogue (its own kernel so that the extra scalars and the
+// statistics registers do not cost the plain kernel its third wave per SIMD)
+template <int WM, int WN, int TM, int TN, int AMODE, int NTERMS, bool LN = false>
 __global__ __launch_bounds__(WM * WN * 64, (TM * TN >= 5 ? 2 : 3)) void gemm_bf16s_kernel(GemmBatch batch) {
   constexpr int NT = WM * WN * 64;                    // 4 or 8 wavefronts
   constexpr int BM = WM * TM * 32;
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(WM * WN * 64, (TM * TN >= 5 ? 2 : 3)) void gemm_bf1
   extern __shared__ unsigned char smem_b[];
   unsigned char* As = smem_b;                          // [NPL][BM][ROWB]: the only LDS tile (A is shared by the N-waves)
 
-  const GemmArgs p = blockIdx.z == 0 ? batch.g[0] : (blockIdx.z == 1 ? batch.g[1] : batch.g[2]);
+  const GemmArgs p = LN ? batch.g[0] : (blockIdx.z == 0 ? batch.g[0] : (blockIdx.z == 1 ? batch.g[1] : batch.g[2]));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
@@ -242,7 +244,12 @@ __global__ __launch_bounds__(WM * WN * 64, (TM * TN >= 5 ? 2 : 3)) void gemm_bf1
       }
     }
   }
-  gemm_epilogue<WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, r, h);
+  if constexpr (LN) {                                   // tile spans the whole output row (n0 = 0)
+    __syncthreads();                                    // the A tile is dead: its LDS becomes the row-statistics scratch
+    gemm_epilogue_ln<WN, TM, TN>(p, acc, m0, wn, lane, reinterpret_cast<float*>(smem_b));
+  } else {
+    gemm_epilogue<WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, r, h);
+  }
 }
 
 // ---- k-sliced variant for grids that cannot fill the chip --------------------------------------------------
@@ -399,8 +406,23 @@ static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterm
   ProfScope prof(name, stream, 2.0 * mnk,
                  4.0 * count * ((double)p.M * p.K / (mode == A_ROWS_TAP3 ? 3 : 1) + 1.5 * (double)p.N * p.K + (double)p.M * p.N * ((p.flags & G_RES) ? 2 : 1)));
   const int npl = nterms == 6 ? 3 : 2;
-  const size_t lds = (size_t)npl * BM * ROWB;
+  size_t lds = (size_t)npl * BM * ROWB;
+  if (p.ln_w) {
+    DCF_CHECK(WM == 1 && TM == 2 && TN >= 2 && BN == p.N, "launch_gemm_split: fused LayerNorm needs a tile spanning all %d columns", p.N);
+    const size_t need = ((size_t)WN * BM * LN_PITCH + BM) * sizeof(float);
+    if (need > lds) lds = need;
+  }
 #define LS(MODE_, NT_) hipLaunchKernelGGL((gemm_bf16s_kernel<WM, WN, TM, TN, MODE_, NT_>), grid, dim3(WM * WN * 64), lds, stream, b)
+#define LSN(MODE_, NT_) hipLaunchKernelGGL((gemm_bf16s_kernel<WM, WN, TM, TN, MODE_, NT_, true>), grid, dim3(WM * WN * 64), lds, stream, b)
+  if (p.ln_w) {
+    if constexpr (WM == 1 && TM == 2 && TN >= 2) {
+      DCF_CHECK(mode != A_CHANMAJOR && count == 1, "launch_gemm_split: fused LayerNorm: unsupported mode");
+      if (mode == A_ROWS) { if (nterms == 6) LSN(A_ROWS, 6); else LSN(A_ROWS, 3); }
+      else { if (nterms == 6) LSN(A_ROWS_TAP3, 6); else LSN(A_ROWS_TAP3, 3); }
+    } else {
+      DCF_CHECK(false, "launch_gemm_split: fused LayerNorm is not built for this tile");
+    }
+  } else
   if (mode == A_ROWS) { if (nterms == 6) LS(A_ROWS, 6); else LS(A_ROWS, 3); }
   else if (mode == A_ROWS_TAP3) { if (nterms == 6) LS(A_ROWS_TAP3, 6); else LS(A_ROWS_TAP3, 3); }
   else {
@@ -409,6 +431,7 @@ static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterm
     else DCF_CHECK(false, "launch_gemm_split: channel-major A needs a 64-row tile");
   }
 #undef LS
+#undef LSN
   DCF_HIP(hipGetLastError());
   return 0;
 }
@@ -428,6 +451,15 @@ static int launch_kslice(const GemmBatch& b, int count, int nterms, hipStream_t 
   return 0;
 }
 
+bool gemm_can_fuse_ln(int M, int N, int K, GemmAMode mode) {
+  static const bool off = getenv("DCF_NO_LN_FUSE") != nullptr;
+  // The fused kernel needs a 64 x N tile, i.e. M / 64 workgroups.  Measured at T = 16384 (rocprofv3): with 256
+  // workgroups (M = 16384, one per CU) conv + LN fused 64 us vs 40 + 8 us as two kernels on 64x128 tiles; with 510
+  // (M = 32640, the heads) 79 vs 74 + 12.5 us.  So: only where the grid still gives two workgroups per CU.
+  static const long min_tiles = getenv("DCF_LN_FUSE_MIN_TILES") ? atol(getenv("DCF_LN_FUSE_MIN_TILES")) : 448;
+  return !off && mode != A_CHANMAJOR && N == 256 && K % SBK == 0 && (M + 63) / 64 >= min_tiles;
+}
+
 // same contract as launch_gemm; every g[i].Ws must hold the pre-tiled bf16 planes of g[i].W (launch_split_planes)
 int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, hipStream_t stream) {
   DCF_CHECK(count >= 1 && count <= 3, "launch_gemm_split: count %d out of range", count);
@@ -437,7 +469,7 @@ int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, 
   const GemmArgs& p = g[0];
   for (int i = 0; i < count; ++i) {
     DCF_CHECK(g[i].M == p.M && g[i].N == p.N && g[i].K == p.K, "launch_gemm_split: grouped shapes differ");
-    DCF_CHECK(g[i].A && g[i].Ws && g[i].C, "launch_gemm_split: null operand");
+    DCF_CHECK(g[i].A && g[i].Ws && (g[i].C || (g[i].ln_w && g[i].Y)), "launch_gemm_split: null operand");
     DCF_CHECK(g[i].lda % 4 == 0, "launch_gemm_split: lda %% 4 != 0");
     if (mode == A_CHANMAJOR) DCF_CHECK(g[i].M % 4 == 0 && !(g[i].flags & G_AMASK), "launch_gemm_split: channel-major A needs M %% 4 == 0, no row mask");
     if (mode == A_ROWS_TAP3) DCF_CHECK(g[i].nbr && g[i].cin % 32 == 0 && g[i].K == 3 * g[i].cin, "launch_gemm_split: bad tap3 args");
@@ -460,6 +492,11 @@ int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, 
       if (bm == 64 && bn == 64) return launch_cfg_s<2, 2, 1, 1>(b, count, mode, nterms, stream);
       if (bm == 128 && bn == 128) return launch_cfg_s<2, 2, 2, 2>(b, count, mode, nterms, stream);
     }
+  }
+  if (p.ln_w) {                                          // fused LayerNorm: the tile must span the row
+    DCF_CHECK(count == 1 && p.Y && p.ln_b && gemm_can_fuse_ln(p.M, N, p.K, mode), "launch_gemm_split: LayerNorm cannot be fused for %dx%dx%d", p.M, N, p.K);
+    if (p.ln_pe) DCF_CHECK(p.ln_mask && p.ln_T >= 64, "launch_gemm_split: fused position encoding needs a mask and T >= 64");
+    return launch_cfg_s<1, 4, 2, 2>(b, count, mode, nterms, stream);
   }
   // small grids: split K over the waves instead of the tile (see gemm_bf16s_kslice_kernel)
   static const long kslice_max = getenv("DCF_KSLICE_MAX") ? atol(getenv("DCF_KSLICE_MAX")) : 512;

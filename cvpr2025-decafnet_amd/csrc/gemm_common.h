@@ -117,4 +117,154 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
   else gemm_epilogue_flags<false, WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, r, h);
 }
 
+// ---- epilogue with a fused channel LayerNorm (blocks.py:125-131) ---------------------------------------------
+// The workgroup tile spans all N = WN * TN * 32 output channels of its BM = TM * 32 rows (WM = 1).  Row statistics
+// are taken in two passes like the reference (mean, then the mean of squared deviations): every lane adds its TN
+// column tiles, the 32 lanes x WN waves of a row are summed through LDS (`red`: [WN][BM][36] floats, `stat`: [BM]).
+constexpr int LN_PITCH = 36;      // floats per (wave, row) line: 16-byte reads of 4 lanes of a quad hit distinct banks
+
+template <int WN, int TM, int TN>
+__device__ __forceinline__ void ln_row_reduce(float (&ps)[TM][16], float scale, bool rsqrt_eps, float* red, float* stat, int wn,
+                                              int lane) {   // in: per-lane partial sums; out (in place): the row statistic
+  constexpr int BM = TM * 32, NT = WN * 64;
+  const int r = lane & 31, h = lane >> 5, tid = wn * 64 + lane;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[(wn * BM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LN_PITCH + r] = ps[i][e];
+  __syncthreads();
+  for (int row = tid >> 2; row < BM; row += NT / 4) {            // four lanes per row, 8 of the 32 columns each
+    const int part = tid & 3;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < WN; ++w) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(red + (w * BM + row) * LN_PITCH + part * 8);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(red + (w * BM + row) * LN_PITCH + part * 8 + 4);
+      s += ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
+    }
+    s += dpp_zero<DPP_XOR1>(s);
+    s += dpp_zero<DPP_XOR2>(s);
+    if (part == 0) stat[row] = rsqrt_eps ? 1.0f / sqrtf(s * scale + 1e-5f) : s * scale;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int e4 = 0; e4 < 4; ++e4) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(stat + i * 32 + 8 * e4 + 4 * h);   // rows (e & 3) = 0..3
+      ps[i][4 * e4 + 0] = t.x; ps[i][4 * e4 + 1] = t.y; ps[i][4 * e4 + 2] = t.z; ps[i][4 * e4 + 3] = t.w;
+    }
+}
+
+template <int WN, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_ln(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0_, int wn, int lane, float* lds) {
+  constexpr int BM = TM * 32, N = WN * TN * 32;
+  float* red = lds;
+  float* stat = lds + WN * BM * LN_PITCH;
+  const int r = lane & 31, h = lane >> 5;
+  const int flags = p.flags;
+  const int m0 = __builtin_amdgcn_readfirstlane(m0_);
+  const int rows_left = p.M - m0;
+  const bool full = rows_left >= BM;
+  const unsigned ldc = (unsigned)p.ldc, ldr = (unsigned)p.ldr, ldy = (unsigned)p.ldy;
+  float* __restrict__ Cb = p.C ? p.C + (int64_t)m0 * p.ldc : nullptr;
+  const float* __restrict__ Rb = (flags & G_RES) ? p.R + (int64_t)m0 * p.ldr : nullptr;
+  const uint8_t* __restrict__ Mb = ((flags & G_RES) && (flags & (G_RES_MASK | G_OUT_MASK))) ? p.rowmask + m0 : nullptr;
+  // 1. the ordinary epilogue value, kept in acc (and written to C if asked for)
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const unsigned row0 = (unsigned)(i * 32 + 4 * h);
+    float mk[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mk[e] = 1.f;
+    if (Mb) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const unsigned row = row0 + (e & 3) + 8 * (e >> 2);
+        if (full || (int)row < rows_left) mk[e] = Mb[row] ? 1.f : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const unsigned col = (unsigned)((wn * TN + j) * 32 + r);
+      const float bias = p.bias ? p.bias[col] : 0.f;
+      const float ls = (Rb && p.ls) ? p.ls[col] : 1.f;
+      float res[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) res[e] = 0.f;
+      if (Rb) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const unsigned row = row0 + (e & 3) + 8 * (e >> 2);
+          if (full || (int)row < rows_left) res[e] = Rb[row * ldr + col];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const unsigned row = row0 + (e & 3) + 8 * (e >> 2);
+        float v = acc[i][j][e] + bias;
+        if (flags & G_GELU) v = gelu_erf(v);
+        if (flags & G_RELU) v = fmaxf(v, 0.f);
+        if (Rb) {
+          if (flags & G_OUT_MASK) v *= mk[e];
+          float r_ = res[e];
+          if (flags & G_RES_MASK) r_ *= mk[e];
+          v = r_ + ls * v;
+        }
+        acc[i][j][e] = v;
+        if (Cb && (full || (int)row < rows_left)) Cb[row * ldc + col] = v;
+      }
+    }
+  }
+  // 2. mean (acc becomes the deviation from it), 3. 1 / sqrt(var + eps); one 32-float array is reused throughout
+  float ps[TM][16];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) s += acc[i][j][e];
+      ps[i][e] = s;
+    }
+  ln_row_reduce<WN, TM, TN>(ps, 1.0f / N, false, red, stat, wn, lane);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float mean = ps[i][e];
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) { const float d = acc[i][j][e] - mean; acc[i][j][e] = d; s += d * d; }
+      ps[i][e] = s;
+    }
+  ln_row_reduce<WN, TM, TN>(ps, 1.0f / N, true, red, stat, wn, lane);
+  // 4. affine (+ ReLU, + pe * mask) and store
+  float* __restrict__ Yb = p.Y + (int64_t)m0 * p.ldy;
+  const int t0 = p.ln_pe ? m0 % p.ln_T : 0;            // BM <= ln_T (checked by the launcher)
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const unsigned row0 = (unsigned)(i * 32 + 4 * h);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const unsigned col = (unsigned)((wn * TN + j) * 32 + r);
+      const float w = p.ln_w[col], b = p.ln_b[col];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const unsigned row = row0 + (e & 3) + 8 * (e >> 2);
+        if (full || (int)row < rows_left) {
+          float y = acc[i][j][e] * ps[i][e] * w + b;
+          if (p.ln_relu) y = fmaxf(y, 0.f);
+          if (p.ln_pe && p.ln_mask[m0 + row]) {
+            int t = t0 + (int)row;                     // (m0 + row) % ln_T with one scalar modulo per tile
+            if (t >= p.ln_T) t -= p.ln_T;
+            y += p.ln_pe[(int64_t)t * N + col];
+          }
+          Yb[row * ldy + col] = y;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace dcf
