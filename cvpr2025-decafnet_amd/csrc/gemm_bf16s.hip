@@ -83,9 +83,11 @@ __global__ __launch_bounds__(WM * WN * 64, (TM * TN >= 5 ? 2 : 3)) void gemm_bf1
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
   constexpr int NPL = NTERMS == 6 ? 3 : 2;            // planes used: hi, mid (, lo)
-  constexpr int ACH = BM * 4 / NT;                    // 8-float chunks of the A tile per thread
+  constexpr int ACH = (BM * 4 + NT - 1) / NT;         // 8-float chunks of the A tile per thread (the last may be partial)
+  constexpr bool APART = (BM * 4) % NT != 0;          // 3-wave workgroups: chunk ids >= BM * 4 do not exist
   constexpr int BLK = 2 * 3 * 64 * 8;                 // bf16 elements of one weight block (6 KiB)
-  static_assert((WM * WN == 4 || WM * WN == 8) && (BM * 4) % NT == 0, "tile/threads mismatch");
+  static_assert(WM * WN == 2 || WM * WN == 3 || WM * WN == 4 || WM * WN == 8, "2, 3, 4 or 8 wavefronts");
+  static_assert(!(APART && AMODE == A_CHANMAJOR), "channel-major A needs a whole number of chunks per thread");
   static_assert(AMODE == A_ROWS || AMODE == A_ROWS_TAP3 || AMODE == A_CHANMAJOR, "unknown A mode");
 
   extern __shared__ unsigned char smem_b[];
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(WM * WN * 64, (TM * TN >= 5 ? 2 : 3)) void gemm_bf1
       const int row = id >> 2, c8 = id & 3;
       const int m = m0 + row;
       unsigned f = 0;
-      if (m < M) {
+      if (m < M && (!APART || id < BM * 4)) {
         if constexpr (AMODE == A_ROWS) f = (p.flags & G_AMASK) ? (p.rowmask[m] ? 1u : 0u) : 1u;
         else f = p.nbr[m];
       }
@@ -171,6 +173,7 @@ __global__ __launch_bounds__(WM * WN * 64, (TM * TN >= 5 ? 2 : 3)) void gemm_bf1
           if constexpr (NPL == 3) *reinterpret_cast<unsigned*>(As + (2 * BM + row) * ROWB + pk * 4) = lo;
         }
       } else {
+        if (APART && id >= BM * 4) continue;
         const int row = id >> 2, c8 = id & 3;
         unsigned h0, h1, h2, h3, m0_, m1, m2, m3, l0, l1, l2, l3;
         split2(araw[i][0].x, araw[i][0].y, h0, m0_, l0);
@@ -507,7 +510,10 @@ int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, 
     return launch_cfg_s<1, 4, 2, 1>(b, count, mode, nterms, stream);
   }
   if (N % 256 == 0 && wgs(64, 256) >= WANT) return launch_cfg_s<1, 4, 2, 2>(b, count, mode, nterms, stream);   // 64x256, 64x64 per wave
-  if (N % 96 == 0 && N % 64 != 0) return launch_cfg_s<4, 1, 1, 3>(b, count, mode, nterms, stream);              // 128x96 (N = 288)
+  // N = 288 (heads on E + 32 channels).  Also measured for M = 32640, K = 864: 64x288 tiles of three 64x96 waves
+  // with the LayerNorm fused (each weight fragment fetched once, but 252 registers = 2 waves/SIMD) 122 us, 64x96
+  // tiles of two 32x96 waves 107 us, against 100 + 16 us (LayerNorm kernel) for the four-wave 128x96 tile below.
+  if (N % 96 == 0 && N % 64 != 0) return launch_cfg_s<4, 1, 1, 3>(b, count, mode, nterms, stream);              // 128x96
   if (N % 160 == 0 && N % 64 != 0) return launch_cfg_s<4, 1, 1, 5>(b, count, mode, nterms, stream);             // 128x160
   if (N % 128 == 0 && wgs(64, 128) >= WANT) return launch_cfg_s<1, 4, 2, 1>(b, count, mode, nterms, stream);   // 64x128
   if (N % 64 == 0) return launch_cfg_s<2, 2, 1, 1>(b, count, mode, nterms, stream);                             // 64x64
