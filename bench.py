@@ -170,6 +170,18 @@ def main():
             'note': 'HIP events around every launch of this kernel, same K steps re-run right after the timed region; '
                     'achieved = algorithmic 2*M*N*K flops / event time',
         }
+        # HBM-side bytes per launch of this kernel family: rocprofv3 PMC passes cannot run inside this process, so the
+        # figure comes from the committed summary of tools/pmc_traffic.sh (same command, same build); null if absent
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r01_pmc_gemm_traffic.json')) as fh:
+                pmc = json.load(fh).get('gemm_bf16s' if terms else 'gemm_f32')
+            if pmc:
+                result['roofline']['traffic'] = pmc['hbm_bytes_per_launch']
+                result['roofline']['traffic_note'] = ('bytes per launch, FETCH_SIZE x2 + WRITE_SIZE from two rocprofv3 --pmc passes '
+                                                      '(profiles/r01_pmc_gemm_traffic.json, tools/pmc_traffic.sh); algorithmic '
+                                                      'operand bytes per launch: %.3e' % (d['bytes'] / d['count']))
+        except (OSError, ValueError, KeyError):
+            pass
         result['config']['gemm_mode'] = {6: 'bf16x6 split MFMA (fp32 accurate)', 3: 'bf16x3 split MFMA', 0: 'native fp32 MFMA'}[terms]
         xa = prof.get('xattn_core')
         if xa:
@@ -182,6 +194,9 @@ def main():
         if not args.no_post:
             sys.path.insert(0, os.path.join(ROOT, 'tools'))
             import xattn_bench
+            # run twice, keep the second: the first call works on ~800 MB of freshly hipMalloc'ed buffers and is 20 % slower
+            # for all of its 140 launches (73 vs 61 us; same for a plain copy kernel), the second reuses the cached blocks
+            xattn_bench.run(4096, 1024, 16, Lk=33, B=8, reps=100)
             x = xattn_bench.run(4096, 1024, 16, Lk=33, B=8, reps=100)
             result['xattn_config2'] = {'bound': 'hbm', 'achieved': x['cold']['GBps'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                        'frac': x['cold']['GBps'] / PEAK_HBM_GBS, 'warm_GBps': x['warm']['GBps'],

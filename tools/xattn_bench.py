@@ -22,8 +22,8 @@ def run(T, E, heads, Lk=33, B=1, reps=100):
     m = torch.ones(B * Lk, dtype=torch.bool, device='cuda')
     out = {}
     for mode in ('cold', 'warm'):
-        for _ in range(5):
-            lib.dcf_op_xattn(P(qs[0]), P(k), P(v), P(m), P(os_[0]), B, T, Lk, E, heads, st)
+        for i in range(40):                      # long enough for the clocks to settle (the first ~20 launches run slow)
+            lib.dcf_op_xattn(P(qs[i % nsets]), P(k), P(v), P(m), P(os_[i % nsets]), B, T, Lk, E, heads, st)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
