@@ -195,7 +195,7 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, 'tools'))
             import xattn_bench
             # run twice, keep the second: the first call works on ~800 MB of freshly hipMalloc'ed buffers and is 20 % slower
-            # for all of its 140 launches (73 vs 61 us; same for a plain copy kernel), the second reuses the cached blocks
+            # for all of its 140 launches (73 vs 61 us, tools/xattn_bench.py run back to back), the second reuses the cached blocks
             xattn_bench.run(4096, 1024, 16, Lk=33, B=8, reps=100)
             x = xattn_bench.run(4096, 1024, 16, Lk=33, B=8, reps=100)
             result['xattn_config2'] = {'bound': 'hbm', 'achieved': x['cold']['GBps'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
