@@ -18,6 +18,7 @@ enum GemmFlags {
   G_RES_MASK = 8,
   G_OUT_MASK = 16,
   G_AMASK = 32,     // A_ROWS: multiply A rows by rowmask on load (MaskedConv1D's x * mask)
+  G_NARROW = 64,    // force the dword-store epilogue (experiments: DCF_NARROW_EPILOGUE=1)
 };
 
 struct GemmArgs {

@@ -251,7 +251,12 @@ __global__ __launch_bounds__(WM * WN * 64, (TM * TN >= 5 ? 2 : 3)) void gemm_bf1
     __syncthreads();                                    // the A tile is dead: its LDS becomes the row-statistics scratch
     gemm_epilogue_ln<WN, TM, TN>(p, acc, m0, wn, lane, reinterpret_cast<float*>(smem_b));
   } else {
-    gemm_epilogue<WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, r, h);
+    if (gemm_wide_ok(p)) {                              // uniform
+      __syncthreads();                                  // the A tile is dead: every wave takes a private transpose tile in it
+      gemm_epilogue_wide<WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, lane, reinterpret_cast<float*>(smem_b) + wave * EPI_WAVE_FLOATS);
+    } else {
+      gemm_epilogue<WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, r, h);
+    }
   }
 }
 
@@ -410,6 +415,7 @@ static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterm
                  4.0 * count * ((double)p.M * p.K / (mode == A_ROWS_TAP3 ? 3 : 1) + 1.5 * (double)p.N * p.K + (double)p.M * p.N * ((p.flags & G_RES) ? 2 : 1)));
   const int npl = nterms == 6 ? 3 : 2;
   size_t lds = (size_t)npl * BM * ROWB;
+  if (lds < (size_t)WM * WN * EPI_WAVE_FLOATS * sizeof(float)) lds = (size_t)WM * WN * EPI_WAVE_FLOATS * sizeof(float);
   if (p.ln_w) {
     DCF_CHECK(WM == 1 && TM == 2 && TN >= 2 && BN == p.N, "launch_gemm_split: fused LayerNorm needs a tile spanning all %d columns", p.N);
     const size_t need = ((size_t)WN * BM * LN_PITCH + BM) * sizeof(float);
@@ -469,6 +475,8 @@ int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, 
   DCF_CHECK(nterms == 3 || nterms == 6, "launch_gemm_split: nterms must be 3 or 6");
   GemmBatch b;
   for (int i = 0; i < 3; ++i) b.g[i] = g[i < count ? i : 0];
+  static const bool narrow = getenv("DCF_NARROW_EPILOGUE") != nullptr;
+  if (narrow) for (int i = 0; i < 3; ++i) b.g[i].flags |= G_NARROW;
   const GemmArgs& p = g[0];
   for (int i = 0; i < count; ++i) {
     DCF_CHECK(g[i].M == p.M && g[i].N == p.N && g[i].K == p.K, "launch_gemm_split: grouped shapes differ");

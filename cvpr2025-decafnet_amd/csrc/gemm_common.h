@@ -117,6 +117,105 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
   else gemm_epilogue_flags<false, WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, r, h);
 }
 
+// ---- epilogue with 16-byte stores --------------------------------------------------------------------------------
+// The MFMA D fragment gives a lane ONE column of 16 rows: 16 dword stores (and 16 dword residual loads) per 32x32
+// fragment, 64 store instructions per 64x64 wave tile, and the store tail of a kernel is issue bound, not bandwidth
+// bound.  Here every fragment goes through a wave-private LDS tile [32][36] (conflict-free dword writes in D layout,
+// 16-byte reads) and comes back as 4 consecutive columns of one row per lane: 4 stores and 4 residual loads of 16
+// bytes per fragment.  Needs 16-byte aligned C / R rows (ldc, ldr multiples of 4, checked by the caller).
+constexpr int EPI_PITCH = 36;
+constexpr int EPI_WAVE_FLOATS = 32 * EPI_PITCH;
+
+template <bool FULL, int ACT, bool RES, int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_wide_body(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0_, int n0_, int wm, int wn,
+                                                        int lane, float* tile /* wave private, EPI_WAVE_FLOATS */) {
+  const int flags = p.flags;
+  const int m0 = __builtin_amdgcn_readfirstlane(m0_), n0 = __builtin_amdgcn_readfirstlane(n0_);
+  const int rows_left = p.M - m0;
+  float* __restrict__ Cb = p.C + (int64_t)m0 * p.ldc + n0;
+  const float* __restrict__ Rb = RES ? p.R + (int64_t)m0 * p.ldr + n0 : nullptr;
+  const uint8_t* __restrict__ Mb = (RES && (flags & (G_RES_MASK | G_OUT_MASK))) ? p.rowmask + m0 : nullptr;
+  const unsigned ldc = (unsigned)p.ldc, ldr = (unsigned)p.ldr;
+  const int r = lane & 31, h = lane >> 5;
+  const int rr = lane >> 3, c4 = (lane & 7) * 4;                       // read-back role: row rr + 8 p, columns c4 .. c4+3
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    float mk[4] = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (RES) {
+      if (Mb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = (wm * TM + i) * 32 + rr + 8 * q;
+          if (FULL || row < rows_left) mk[q] = Mb[row] ? 1.f : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const unsigned colb = (unsigned)((wn * TN + j) * 32 + c4);
+      f32x4 bias = {0.f, 0.f, 0.f, 0.f}, ls = {1.f, 1.f, 1.f, 1.f};
+      if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + n0 + colb);
+      f32x4 res[4];
+      if constexpr (RES) {
+        if (p.ls) ls = *reinterpret_cast<const f32x4*>(p.ls + n0 + colb);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned row = (unsigned)((wm * TM + i) * 32 + rr + 8 * q);
+          res[q] = (FULL || (int)row < rows_left) ? *reinterpret_cast<const f32x4*>(Rb + row * ldr + colb) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      // D layout -> LDS: element e of lane (r, h) is row (e & 3) + 8 (e >> 2) + 4 h, column r
+#pragma unroll
+      for (int e = 0; e < 16; ++e) tile[((e & 3) + 8 * (e >> 2) + 4 * h) * EPI_PITCH + r] = acc[i][j][e];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned row = (unsigned)((wm * TM + i) * 32 + rr + 8 * q);
+        f32x4 v = *reinterpret_cast<const f32x4*>(tile + (rr + 8 * q) * EPI_PITCH + c4) + bias;
+        if constexpr (ACT == 1) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+        if constexpr (ACT == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if constexpr (RES) {
+          if (flags & G_OUT_MASK) v *= mk[q];
+          f32x4 r_ = res[q];
+          if (flags & G_RES_MASK) r_ *= mk[q];
+          v = r_ + ls * v;
+        }
+        if (FULL || (int)row < rows_left) *reinterpret_cast<f32x4*>(Cb + row * ldc + colb) = v;
+      }
+    }
+  }
+}
+
+template <bool FULL, int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_wide_flags(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
+                                                         int lane, float* tile) {
+  const int act = (p.flags & G_GELU) ? 1 : ((p.flags & G_RELU) ? 2 : 0);
+  if (p.flags & G_RES) {
+    if (act == 0) gemm_epilogue_wide_body<FULL, 0, true, WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, lane, tile);
+    else if (act == 1) gemm_epilogue_wide_body<FULL, 1, true, WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, lane, tile);
+    else gemm_epilogue_wide_body<FULL, 2, true, WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, lane, tile);
+  } else {
+    if (act == 0) gemm_epilogue_wide_body<FULL, 0, false, WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, lane, tile);
+    else if (act == 1) gemm_epilogue_wide_body<FULL, 1, false, WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, lane, tile);
+    else gemm_epilogue_wide_body<FULL, 2, false, WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, lane, tile);
+  }
+}
+
+// true if the 16-byte epilogue applies to this operand set (row pitches and base pointers 16-byte aligned)
+__device__ __forceinline__ bool gemm_wide_ok(const GemmArgs& p) {
+  bool ok = !(p.flags & G_NARROW) && (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
+  if (p.flags & G_RES) ok = ok && (p.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(p.R) & 15) == 0;
+  if (p.bias) ok = ok && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
+  if ((p.flags & G_RES) && p.ls) ok = ok && (reinterpret_cast<uintptr_t>(p.ls) & 15) == 0;
+  return ok;
+}
+
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
+                                                   int lane, float* tile) {
+  if (m0 + WM * TM * 32 <= p.M) gemm_epilogue_wide_flags<true, WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, lane, tile);
+  else gemm_epilogue_wide_flags<false, WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, lane, tile);
+}
+
 // ---- epilogue with a fused channel LayerNorm (blocks.py:125-131) ---------------------------------------------
 // The workgroup tile spans all N = WN * TN * 32 output channels of its BM = TM * 32 rows (WM = 1).  Row statistics
 // are taken in two passes like the reference (mean, then the mean of squared deviations): every lane adds its TN
