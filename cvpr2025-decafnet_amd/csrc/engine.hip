@@ -175,11 +175,6 @@ struct dcf_model {
   char* arena = nullptr;
   size_t arena_bytes = 0;
   std::vector<Plan> plans;
-  static constexpr int META_SLOTS = 64;      // ring of pinned/device TextMeta slots (one per forward chunk)
-  TextMeta* h_meta = nullptr;                // pinned host [META_SLOTS]
-  TextMeta* d_meta = nullptr;                // device      [META_SLOTS]
-  int meta_next = GRAPH_META_SLOTS;
-  static constexpr int GRAPH_META_SLOTS = 8; // slots [0, 8) belong to the captured graph (one per forward chunk)
   // HIP graph of the last repeated forward (same pointers and sizes): one graph launch replaces ~135 kernel launches,
   // so a busy host cannot starve the GPU.  Captured on the second identical call, dropped whenever anything it bakes
   // in changes (weights, position encoding, workspace).
@@ -187,7 +182,6 @@ struct dcf_model {
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   bool capturing = false;
-  int capture_chunk = 0;
   // second stream for the two independent branches of the forward (fork_side / join_side)
   hipStream_t side = nullptr;
   hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
@@ -221,8 +215,6 @@ static int free_model(dcf_model* m) {
   for (auto& pl : m->plans) if (pl.d_lt) (void)hipFree(pl.d_lt);
   m->plans.clear();
   if (m->arena) (void)hipFree(m->arena);
-  if (m->h_meta) (void)hipHostFree(m->h_meta);
-  if (m->d_meta) (void)hipFree(m->d_meta);
   if (m->text_ws) (void)hipFree(m->text_ws);
   for (int i = 0; i < 2; ++i) {
     if (m->ev_fork[i]) (void)hipEventDestroy(m->ev_fork[i]);
@@ -662,7 +654,7 @@ static int run_head(dcf_model* m, const HeadW& h, Buffers& b, const Plan& pl, in
 // of T rows (lt == nullptr) or the whole pyramid (lt != nullptr: rows ordered [level][b][t], neighbour flags `nbr`
 // delimit the sequences for the depthwise conv, the attention core is launched per level).
 static int run_fusion(dcf_model* m, Buffers& b, float* X, int64_t ldx, int B, int T, const LevelTable* lt, const uint8_t* mask,
-                      const uint8_t* nbr, TextMeta* dm, int Lk, float* out, int64_t ld_out, hipStream_t st) {
+                      const uint8_t* nbr, const TextMeta* dm, int Lk, float* out, int64_t ld_out, hipStream_t st) {
   const dcf_config& c = m->cfg;
   const int E = c.E;
   const int rows = lt ? lt->start[lt->n_levels] : B * T;
@@ -673,7 +665,7 @@ static int run_fusion(dcf_model* m, Buffers& b, float* X, int64_t ldx, int B, in
     TRY(launch_dec_pre(dp, st));
     GemmArgs gq = gemm(b.R[0], E, w.wq, w.bq, b.R[2], E, rows, E, E);
     TRY(run_gemm(m, &gq, 1, A_ROWS, st));
-    TextLnArgs tl{dm, b.kvn, b.kvmask, w.ln_kv_w, w.ln_kv_b, Lk, c.TE};
+    TextLnArgs tl{*dm, b.kvn, b.kvmask, w.ln_kv_w, w.ln_kv_b, Lk, c.TE};
     TRY(launch_text_ln(tl, B, st));
     GemmArgs gkv[2] = {gemm(b.kvn, c.TE, w.wk, w.bk, b.Kt, E, B * Lk, E, c.TE), gemm(b.kvn, c.TE, w.wv, w.bv, b.Vt, E, B * Lk, E, c.TE)};
     TRY(run_gemm(m, gkv, 2, A_ROWS, st));
@@ -746,11 +738,6 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
     Arena real{m->arena, 0, m->arena_bytes, false};
     carve(real, c, T0, Bmax, nq, S, Lk, b);
   }
-  if (!m->h_meta) {
-    DCF_HIP(hipHostMalloc(&m->h_meta, sizeof(TextMeta) * dcf_model::META_SLOTS));
-    DCF_HIP(hipMalloc(&m->d_meta, sizeof(TextMeta) * dcf_model::META_SLOTS));
-  }
-
   // ---- per video: sidekick scores and the query-independent halves of vid_map
   bool forked = false;
   if (!gate_override) {
@@ -799,27 +786,15 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
     if (m->keep_debug && m->dbg_vidmap) DCF_HIP(hipMemcpyAsync(m->dbg_vidmap, b.X, (size_t)rows0 * E * 4, hipMemcpyDeviceToDevice, st));
 
     // ---- text side: pointers of this chunk
-    TextMeta *hm, *dm;
-    if (m->capturing) {                              // the graph owns fixed slots: replays re-read the same pinned memory
-      DCF_CHECK(m->capture_chunk < dcf_model::GRAPH_META_SLOTS, "internal: too many chunks for a captured forward");
-      hm = m->h_meta + m->capture_chunk;
-      dm = m->d_meta + m->capture_chunk;
-      m->capture_chunk++;
-    } else {
-      if (m->meta_next == dcf_model::META_SLOTS) {   // ring wrapped: make sure the old slots were consumed
-        DCF_HIP(hipStreamSynchronize(st));
-        m->meta_next = dcf_model::GRAPH_META_SLOTS;
-      }
-      hm = m->h_meta + m->meta_next;
-      dm = m->d_meta + m->meta_next;
-      m->meta_next++;
-    }
+    // the kernels take the pointers by value (kernel argument): a captured graph bakes them in, which is what its key
+    // (every text pointer and length) promises
+    TextMeta tm{};
     for (int i = 0; i < B; ++i) {
-      hm->text[i] = text[q0 + i];
-      hm->text_mask[i] = text_mask ? text_mask[q0 + i] : nullptr;
-      hm->len[i] = text_len[q0 + i];
+      tm.text[i] = text[q0 + i];
+      tm.text_mask[i] = text_mask ? text_mask[q0 + i] : nullptr;
+      tm.len[i] = text_len[q0 + i];
     }
-    DCF_HIP(hipMemcpyAsync(dm, hm, sizeof(TextMeta), hipMemcpyHostToDevice, st));
+    const TextMeta* dm = &tm;
 
     // ---- early fusion: XAttNFusion on the level-0 sequence (fusion.py:56-66)
     if (c.model_kind == 0) {
@@ -1027,7 +1002,7 @@ static int forward_maybe_graph(dcf_model* m, const float* vid, const float* shal
                                const float* text_cls, const float* gate, float* lo, float* oo, uint8_t* mo, hipStream_t st) {
   static const bool no_graph = getenv("DCF_NO_GRAPH") != nullptr;
   const int Bmax = std::min(nq, m->cfg.max_batch > 0 ? m->cfg.max_batch : 8);
-  const bool eligible = !no_graph && !g_prof_on && !m->keep_debug && nq > 0 && (nq + Bmax - 1) / Bmax <= dcf_model::GRAPH_META_SLOTS;
+  const bool eligible = !no_graph && !g_prof_on && !m->keep_debug && nq > 0;
   if (!eligible) return forward(m, vid, shallow, vid_mask, T0, nq, text, text_mask, text_len, text_cls, gate, lo, oo, mo, st);
   std::vector<uint64_t> key = {(uint64_t)vid, (uint64_t)shallow, (uint64_t)vid_mask, (uint64_t)T0, (uint64_t)nq, (uint64_t)text_cls,
                                (uint64_t)gate, (uint64_t)lo, (uint64_t)oo, (uint64_t)mo, (uint64_t)st, (uint64_t)m->pe, (uint64_t)m->pe_T};
@@ -1052,7 +1027,6 @@ static int forward_maybe_graph(dcf_model* m, const float* vid, const float* shal
     return forward(m, vid, shallow, vid_mask, T0, nq, text, text_mask, text_len, text_cls, gate, lo, oo, mo, st);
   }
   m->capturing = true;
-  m->capture_chunk = 0;
   const int rc = forward(m, vid, shallow, vid_mask, T0, nq, text, text_mask, text_len, text_cls, gate, lo, oo, mo, st);
   m->capturing = false;
   hipGraph_t g = nullptr;

@@ -43,7 +43,7 @@ struct EncPreArgs {
   int strip;                        // output rows per wavefront (filled in by the launcher)
 };
 
-struct TextMeta {                   // lives in device memory
+struct TextMeta {                   // passed BY VALUE inside TextLnArgs (kernel argument, 208 bytes at 8 queries)
   const float* text[DCF_MAX_BATCH];        // (TE, len) channel-major per query
   const uint8_t* text_mask[DCF_MAX_BATCH]; // (len) or nullptr
   int len[DCF_MAX_BATCH];
@@ -65,7 +65,7 @@ int launch_mask_rows(float* X, const uint8_t* mask, int rows, int C, hipStream_t
 int launch_rows_to_chanmajor(const float* X, float* out, int rows, int C, hipStream_t st);           // out[c][r] = X[r][c]
 
 struct TextLnArgs {
-  const TextMeta* meta;
+  TextMeta meta;
   float* out;                       // [B*Lkmax][TE]
   uint8_t* kvmask;                  // [B*Lkmax] or nullptr
   const float* w; const float* b;   // ln_xattn_kv affine (TE)

@@ -287,14 +287,14 @@ __global__ __launch_bounds__(256) void k_enc_pre(EncPreArgs p) {
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_text_ln(TextLnArgs p) {
   const int j = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
-  const int len = p.meta->len[b];
+  const int len = p.meta.len[b];
   float* out = p.out + ((int64_t)b * p.Lkmax + j) * p.TE;
   if (j >= len) {
     for (int c = lane; c < p.TE; c += 64) out[c] = 0.f;
     if (lane == 0 && p.kvmask) p.kvmask[b * p.Lkmax + j] = 0;
     return;
   }
-  const float* src = p.meta->text[b];
+  const float* src = p.meta.text[b];
   float s = 0.f;
   for (int c = lane; c < p.TE; c += 64) s += src[(int64_t)c * len + j];
   const float mean = wave_sum(s) / (float)p.TE;
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(64) void k_text_ln(TextLnArgs p) {
   for (int c = lane; c < p.TE; c += 64) { float d = src[(int64_t)c * len + j] - mean; sq += d * d; }
   const float rs = 1.0f / sqrtf(wave_sum(sq) / (float)p.TE + 1e-5f);
   for (int c = lane; c < p.TE; c += 64) out[c] = (src[(int64_t)c * len + j] - mean) * rs * p.w[c] + p.b[c];
-  if (lane == 0 && p.kvmask) p.kvmask[b * p.Lkmax + j] = p.meta->text_mask[b] ? p.meta->text_mask[b][j] : 1;
+  if (lane == 0 && p.kvmask) p.kvmask[b * p.Lkmax + j] = p.meta.text_mask[b] ? p.meta.text_mask[b][j] : 1;
 }
 
 
