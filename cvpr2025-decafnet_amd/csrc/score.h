@@ -5,7 +5,7 @@
 
 namespace dcf {
 
-constexpr int SCORE_SLICES = 16;   // channel slices of the partial-sum pass
+constexpr int SCORE_SLICES = 32;   // channel slices of the partial-sum pass
 constexpr int SCORE_MAXQ = 8;      // queries per scoring launch
 
 struct ScoreArgs {

@@ -42,7 +42,23 @@ __global__ __launch_bounds__(64) void k_sidekick_partial(ScoreArgs p, int q0) {
 #pragma unroll
   for (int q = 0; q < NQ; ++q) dot[q] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (t < p.T) {
-    for (int c = c0; c < c1; ++c) {
+    int c = c0;
+    if (vec) {
+      // eight channel rows requested before the first is used: with one wave per SIMD (1024-2048 waves in all) a
+      // load per iteration left the loop waiting for one round trip per channel (35 us for 64 MiB)
+      for (; c + 8 <= c1; c += 8) {
+        f32x4 x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const f32x4*>(p.shallow + (size_t)(c + u) * p.T + t);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          ss += x[u] * x[u];
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) dot[q] += x[u] * p.tn[(size_t)(q0 + q) * p.D + c + u];
+        }
+      }
+    }
+    for (; c < c1; ++c) {
       const float* src = p.shallow + (size_t)c * p.T + t;
       f32x4 x = {0.f, 0.f, 0.f, 0.f};
       if (vec) x = *reinterpret_cast<const f32x4*>(src);
