@@ -283,6 +283,62 @@ __global__ __launch_bounds__(256) void k_refine_pool(float* __restrict__ F, int6
   *reinterpret_cast<f32x4*>(F + (out_row0 + r) * ldf + E + cq * 4) = best;
 }
 
+// All levels of that pooling chain in one launch: one workgroup per row i of the coarsest level.  It loads the
+// 2W - 1 level-0 rows [iW - (W - 1), iW + W) (W = 2^(L-1)) into LDS and walks down the pyramid there; level l keeps
+// W_l - 1 halo rows to the left of its W_l = W >> l owned rows (the window only reaches one row to the left), which
+// neighbours recompute.  Replaces L - 1 dependent launches of k_refine_pool (7 x 4.8 us at L = 8).
+__global__ __launch_bounds__(256) void k_refine_pool_all(float* __restrict__ F, int64_t ldf, int E,
+                                                          const uint8_t* __restrict__ mask_all, const LevelTable* __restrict__ lt) {
+  extern __shared__ float s_pool[];                    // two buffers of (2W - 1) rows x 32 channels
+  const int L = lt->n_levels, B = lt->B;
+  const int W = 1 << (L - 1);
+  const int TL = lt->T[L - 1];
+  const int b = blockIdx.x / TL, i = blockIdx.x - b * TL;
+  (void)B;
+  float* cur = s_pool;
+  float* nxt = s_pool + (2 * W - 1) * TCN_HID;
+  const int tid = threadIdx.x;
+  {   // level 0 window
+    const int t_lo = i * W - (W - 1);
+    for (int idx = tid; idx < (2 * W - 1) * 8; idx += 256) {
+      const int j = idx >> 3, cq = idx & 7;
+      const int t = t_lo + j;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (t >= 0) v = *reinterpret_cast<const f32x4*>(F + ((int64_t)lt->start[0] + (int64_t)b * lt->T[0] + t) * ldf + E + cq * 4);
+      *reinterpret_cast<f32x4*>(cur + j * TCN_HID + cq * 4) = v;
+    }
+  }
+  __syncthreads();
+  for (int l = 1; l < L; ++l) {
+    const int Wl = W >> l, hl = Wl - 1, Wp = W >> (l - 1), hp = Wp - 1;
+    const int k_lo = i * Wl - hl;                        // first row of this level's window
+    const int p_lo = i * Wp - hp;                        // first row of the previous level's window
+    const uint8_t* mask_in = mask_all + lt->start[l - 1] + (int64_t)b * lt->T[l - 1];
+    for (int idx = tid; idx < (2 * Wl - 1) * 8; idx += 256) {
+      const int j = idx >> 3, cq = idx & 7;
+      const int k = k_lo + j;
+      f32x4 best = {0.f, 0.f, 0.f, 0.f};
+      if (k >= 0) {
+        bool any = false;
+#pragma unroll
+        for (int d = -1; d <= 1; ++d) {
+          const int t = 2 * k + d;
+          if (t < 0 || t >= lt->T[l - 1] || !mask_in[t]) continue;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(cur + (t - p_lo) * TCN_HID + cq * 4);
+          if (!any) best = v;
+          else { best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y); best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w); }
+          any = true;
+        }
+        if (j >= hl)                                     // owned row: goes to the pyramid buffer
+          *reinterpret_cast<f32x4*>(F + ((int64_t)lt->start[l] + (int64_t)b * lt->T[l] + k) * ldf + E + cq * 4) = best;
+      }
+      *reinterpret_cast<f32x4*>(nxt + j * TCN_HID + cq * 4) = best;
+    }
+    __syncthreads();
+    float* t_ = cur; cur = nxt; nxt = t_;
+  }
+}
+
 int launch_refine(const RefineArgs& a, const LevelTable& lt, hipStream_t st) {
   const int rows0 = a.B * a.T0;
   if (rows0 <= 0) return 0;
@@ -299,11 +355,19 @@ int launch_refine(const RefineArgs& a, const LevelTable& lt, hipStream_t st) {
     float* t = cur; cur = nxt; nxt = t;
   }
   hipLaunchKernelGGL(k_refine_out, g64, b64, 0, st, (const float*)cur, a.w_out, a.b_out, a.mask_all, a.F, a.ldf, a.E, rows0);
-  for (int l = 1; l < a.n_levels; ++l) {
-    const int Tin = lt.T[l - 1];
-    const int n = a.B * (Tin / 2) * 8;
-    hipLaunchKernelGGL(k_refine_pool, dim3((n + 255) / 256), dim3(256), 0, st, a.F, a.ldf, a.E,
-                       a.mask_all + lt.start[l - 1], (int64_t)lt.start[l - 1], (int64_t)lt.start[l], a.B, Tin);
+  if (a.n_levels > 1) {
+    const int W = 1 << (a.n_levels - 1);
+    const size_t lds = (size_t)2 * (2 * W - 1) * TCN_HID * sizeof(float);
+    if (lds <= 64 * 1024 && lt.T[0] == lt.T[a.n_levels - 1] * W) {
+      hipLaunchKernelGGL(k_refine_pool_all, dim3(a.B * lt.T[a.n_levels - 1]), dim3(256), lds, st, a.F, a.ldf, a.E, a.mask_all, a.lt);
+    } else {                                             // very deep pyramids: level by level
+      for (int l = 1; l < a.n_levels; ++l) {
+        const int Tin = lt.T[l - 1];
+        const int n = a.B * (Tin / 2) * 8;
+        hipLaunchKernelGGL(k_refine_pool, dim3((n + 255) / 256), dim3(256), 0, st, a.F, a.ldf, a.E,
+                           a.mask_all + lt.start[l - 1], (int64_t)lt.start[l - 1], (int64_t)lt.start[l], a.B, Tin);
+      }
+    }
   }
   DCF_HIP(hipGetLastError());
   return 0;
