@@ -86,7 +86,7 @@ __global__ __launch_bounds__(WM * WN * 64, (TM * TN >= 5 ? 2 : 3)) void gemm_bf1
   constexpr int ACH = (BM * 4 + NT - 1) / NT;         // 8-float chunks of the A tile per thread (the last may be partial)
   constexpr bool APART = (BM * 4) % NT != 0;          // 3-wave workgroups: chunk ids >= BM * 4 do not exist
   constexpr int BLK = 2 * 3 * 64 * 8;                 // bf16 elements of one weight block (6 KiB)
-  static_assert(WM * WN == 2 || WM * WN == 3 || WM * WN == 4 || WM * WN == 8, "2, 3, 4 or 8 wavefronts");
+  static_assert(WM * WN == 2 || WM * WN == 3 || WM * WN == 4 || WM * WN == 6 || WM * WN == 8, "2, 3, 4, 6 or 8 wavefronts");
   static_assert(!(APART && AMODE == A_CHANMAJOR), "channel-major A needs a whole number of chunks per thread");
   static_assert(AMODE == A_ROWS || AMODE == A_ROWS_TAP3 || AMODE == A_CHANMAJOR, "unknown A mode");
 
@@ -520,7 +520,8 @@ int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, 
   if (N % 256 == 0 && wgs(64, 256) >= WANT) return launch_cfg_s<1, 4, 2, 2>(b, count, mode, nterms, stream);   // 64x256, 64x64 per wave
   // N = 288 (heads on E + 32 channels).  Also measured for M = 32640, K = 864: 64x288 tiles of three 64x96 waves
   // with the LayerNorm fused (each weight fragment fetched once, but 252 registers = 2 waves/SIMD) 122 us, 64x96
-  // tiles of two 32x96 waves 107 us, against 100 + 16 us (LayerNorm kernel) for the four-wave 128x96 tile below.
+  // tiles of two 32x96 waves 107 us, 128x96 tiles of six 64x32 waves 117 us, against 100 + 16 us (LayerNorm kernel) for the
+  // four-wave 128x96 tile below.
   if (N % 96 == 0 && N % 64 != 0) return launch_cfg_s<4, 1, 1, 3>(b, count, mode, nterms, stream);              // 128x96
   if (N % 160 == 0 && N % 64 != 0) return launch_cfg_s<4, 1, 1, 5>(b, count, mode, nterms, stream);             // 128x160
   if (N % 128 == 0 && wgs(64, 128) >= WANT) return launch_cfg_s<1, 4, 2, 1>(b, count, mode, nterms, stream);   // 64x128
