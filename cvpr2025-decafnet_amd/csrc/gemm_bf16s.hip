@@ -269,25 +269,27 @@ __global__ __launch_bounds__(WM * WN * 64, (TM * TN >= 5 ? 2 : 3)) void gemm_bf1
 // fragments from the weight image, so four independent load streams with 48 MFMAs per tile are in flight per
 // workgroup and the K loop is 4x shorter.  The partial tiles are summed through LDS in a fixed order (wave 0, 1,
 // 2, 3 -- deterministic), wave q finishing quadrant q with the common epilogue.
-template <int NTERMS>
+// TM = 2: 64x64 tile; TM = 1: 32x64 tile (twice the workgroups, half the MFMAs per wave: the very small levels)
+template <int NTERMS, int TM>
 __global__ __launch_bounds__(256) void gemm_bf16s_kslice_kernel(GemmBatch batch) {
   constexpr int NPL = NTERMS == 6 ? 3 : 2;
   constexpr int BLK = 2 * 3 * 64 * 8;
-  __shared__ f32x4 red[4][3][4][64];                   // [owner quadrant][source slot][quarter][lane], 48 KiB
+  constexpr int NF = TM * 2;                           // 32x32 fragments of the tile = owner waves
+  __shared__ f32x4 red[NF][3][4][64];                  // [owner fragment][source slot][quarter][lane], 48 / 24 KiB
 
   const GemmArgs p = blockIdx.z == 0 ? batch.g[0] : (blockIdx.z == 1 ? batch.g[1] : batch.g[2]);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   int m0, n0;
-  if (!tile_origin<64, 64>(p, m0, n0)) return;
+  if (!tile_origin<TM * 32, 64>(p, m0, n0)) return;
   const int M = p.M;
   const int KT = p.K / SBK;
   const int kb = KT * wave / 4, ke = KT * (wave + 1) / 4;
 
-  const float* a_ptr[2];
-  bool a_ok[2];
+  const float* a_ptr[TM];
+  bool a_ok[TM];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < TM; ++i) {
     const int m = m0 + i * 32 + r;
     a_ok[i] = m < M && (!(p.flags & G_AMASK) || p.rowmask[m]);
     a_ptr[i] = p.A + (int64_t)(m < M ? m : 0) * p.lda + h * 8;
@@ -296,11 +298,11 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kslice_kernel(GemmBatch batch)
 #pragma unroll
   for (int j = 0; j < 2; ++j) w_ptr[j] = reinterpret_cast<const bf16x8*>(p.Ws + ((int64_t)(n0 / 32 + j) * KT) * BLK) + lane;
 
-  f32x4 araw[2][2][2];                                  // [row tile][chunk][half]
+  f32x4 araw[TM][2][2];                                 // [row tile][chunk][half]
   bf16x8 bfr[2][2][NPL];                                // [chunk][col tile][plane]
   auto load = [&](int kt) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
@@ -319,9 +321,9 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kslice_kernel(GemmBatch batch)
         for (int pl = 0; pl < NPL; ++pl) bfr[c][j][pl] = w_ptr[j][(int64_t)kt * (BLK / 8) + (c * 3 + pl) * 64];
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -329,9 +331,9 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kslice_kernel(GemmBatch batch)
 
   if (kb < ke) load(kb);
   for (int kt = kb; kt < ke; ++kt) {
-    bf16x8 a[2][2][NPL];                                // [row tile][chunk][plane]
+    bf16x8 a[TM][2][NPL];                               // [row tile][chunk][plane]
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         unsigned h0, h1, h2, h3, m0_, m1, m2, m3, l0, l1, l2, l3;
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kslice_kernel(GemmBatch batch)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TM; ++i) {
           if constexpr (NTERMS == 6) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][c][1], bc[c][j][1], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][c][0], bc[c][j][2], acc[i][j], 0, 0, 0);
@@ -368,9 +370,9 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kslice_kernel(GemmBatch batch)
         }
   }
 
-  // hand the three quadrants this wave does not finish to their owners
+  // hand the fragments this wave does not finish to their owners (waves 0 .. NF-1)
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < NF; ++q) {
     if (q == wave) continue;
     const int slot = wave < q ? wave : wave - 1;
 #pragma unroll
@@ -380,7 +382,10 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kslice_kernel(GemmBatch batch)
     }
   }
   __syncthreads();
-  f32x16 own = wave == 0 ? acc[0][0] : (wave == 1 ? acc[0][1] : (wave == 2 ? acc[1][0] : acc[1][1]));
+  if (wave >= NF) return;
+  f32x16 own;
+  if constexpr (TM == 2) own = wave == 0 ? acc[0][0] : (wave == 1 ? acc[0][1] : (wave == 2 ? acc[1][0] : acc[1][1]));
+  else own = wave == 0 ? acc[0][0] : acc[0][1];
   f32x16 fin[1][1];
 #pragma unroll
   for (int e = 0; e < 16; ++e) fin[0][0][e] = 0.f;
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kslice_kernel(GemmBatch batch)
       }
     }
   }
-  gemm_epilogue<2, 2, 1, 1>(p, fin, m0, n0, wave >> 1, wave & 1, r, h);
+  gemm_epilogue<TM, 2, 1, 1>(p, fin, m0, n0, wave >> 1, wave & 1, r, h);
 }
 
 template <int WM, int WN, int TM, int TN>
@@ -447,15 +452,24 @@ static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterm
 
 static int launch_kslice(const GemmBatch& b, int count, int nterms, hipStream_t stream) {
   const GemmArgs& p = b.g[0];
-  dim3 grid(tile_grid<64, 64>(p), 1, count);
+  // 32-row tiles while 64-row tiles would leave most CUs without a workgroup
+  static const long small_max = getenv("DCF_KSLICE_SMALL") ? atol(getenv("DCF_KSLICE_SMALL")) : 128;
+  const long tiles64 = (long)((p.M + 63) / 64) * (p.N / 64) * count;
+  const bool small = tiles64 <= small_max;
+  dim3 grid(small ? tile_grid<32, 64>(p) : tile_grid<64, 64>(p), 1, count);
   char name[96];
   static const bool shapes = getenv("DCF_PROF_SHAPES") != nullptr;
-  if (shapes) snprintf(name, sizeof(name), "gemm_bf16x%d<64x64,kslice>[%dx%dx%dx%d]", nterms, count, p.M, p.N, p.K);
+  if (shapes) snprintf(name, sizeof(name), "gemm_bf16x%d<%dx64,kslice>[%dx%dx%dx%d]", nterms, small ? 32 : 64, count, p.M, p.N, p.K);
   else snprintf(name, sizeof(name), "gemm_bf16x%d<64x64,kslice>", nterms);
   const double mnk = (double)count * p.M * (double)p.N * p.K;
   ProfScope prof(name, stream, 2.0 * mnk, 4.0 * count * ((double)p.M * p.K + 1.5 * (double)p.N * p.K + (double)p.M * p.N * ((p.flags & G_RES) ? 2 : 1)));
-  if (nterms == 6) hipLaunchKernelGGL((gemm_bf16s_kslice_kernel<6>), grid, dim3(256), 0, stream, b);
-  else hipLaunchKernelGGL((gemm_bf16s_kslice_kernel<3>), grid, dim3(256), 0, stream, b);
+  if (small) {
+    if (nterms == 6) hipLaunchKernelGGL((gemm_bf16s_kslice_kernel<6, 1>), grid, dim3(256), 0, stream, b);
+    else hipLaunchKernelGGL((gemm_bf16s_kslice_kernel<3, 1>), grid, dim3(256), 0, stream, b);
+  } else {
+    if (nterms == 6) hipLaunchKernelGGL((gemm_bf16s_kslice_kernel<6, 2>), grid, dim3(256), 0, stream, b);
+    else hipLaunchKernelGGL((gemm_bf16s_kslice_kernel<3, 2>), grid, dim3(256), 0, stream, b);
+  }
   DCF_HIP(hipGetLastError());
   return 0;
 }
