@@ -464,7 +464,7 @@ struct Arena {
 struct Buffers {
   float *P1, *P2, *tn, *partial, *correl, *gate;
   uint8_t *mask_all, *nbr_all, *kvmask;
-  float *X, *R[7], *H2, *HID, *F, *HA, *HB, *logits1, *tcnA, *tcnB, *kvn, *Kt, *Vt;
+  float *X, *R[7], *H2, *HID, *F, *HA, *HB, *HC, *HD, *logits1, *tcnA, *tcnB, *kvn, *Kt, *Vt;
 };
 
 static void carve(Arena& a, const dcf_config& c, int T0, int B, int nq, int S, int Lk, Buffers& b) {
@@ -487,6 +487,8 @@ static void carve(Arena& a, const dcf_config& c, int T0, int B, int nq, int S, i
   b.F = a.take<float>(rowsAll * EH);
   b.HA = a.take<float>(rowsAll * EH);
   b.HB = a.take<float>(rowsAll * EH);
+  b.HC = a.take<float>(rowsAll * EH);      // second trunk pair: two heads of equal shape run in lockstep (run_head_pair)
+  b.HD = a.take<float>(rowsAll * EH);
   b.logits1 = a.take<float>(rowsAll);
   b.tcnA = a.take<float>(rows0 * TCN_HID);
   b.tcnB = a.take<float>(rows0 * TCN_HID);
@@ -646,6 +648,52 @@ static int run_head(dcf_model* m, const HeadW& h, Buffers& b, const Plan& pl, in
   co.out = query_major ? out : out + row0;
   co.rows = rowsAll; co.C = Cin; co.NO = NO; co.row0 = row0; co.mode = mode; co.query_major = query_major;
   TRY(launch_conv_out(co, st));
+  return 0;
+}
+
+// Two head trunks of the same shape on the same pyramid (cls_head2 and reg_head): each pair of k3 convolutions is one
+// grid of twice the workgroups (blockIdx.z picks the operand set), so the kernel runs two rounds of workgroups whose
+// prologues and epilogues overlap instead of two single-round launches.
+static int run_head_pair(dcf_model* m, const HeadW& h1, const HeadW& h2, Buffers& b, const Plan& pl, int Cin, int NO1, int mode1,
+                         float* out1, int NO2, int mode2, float* out2, hipStream_t st) {
+  const int rowsAll = pl.B * pl.lt.S;
+  static const bool off = getenv("DCF_NO_HEAD_PAIR") != nullptr;
+  bool pair = !off && h1.conv.size() == h2.conv.size() && !h1.conv.empty() && m->gemm_terms != 0;
+  for (size_t i = 0; pair && i < h1.conv.size(); ++i)
+    pair = !can_fuse_ln(m, h1.conv[i], rowsAll, Cin, 3 * Cin, A_ROWS_TAP3) && m->wsplit.count(h1.conv[i]) && m->wsplit.count(h2.conv[i]);
+  if (!pair) {
+    TRY(run_head(m, h1, b, pl, Cin, NO1, mode1, 1, out1, st));
+    return run_head(m, h2, b, pl, Cin, NO2, mode2, 1, out2, st);
+  }
+  const int ldf = m->cfg.E + TCN_HID;
+  const float* in[2] = {b.F, b.F};
+  int64_t ldin = ldf;
+  float* buf[2][2] = {{b.HA, b.HB}, {b.HC, b.HD}};
+  const HeadW* hs[2] = {&h1, &h2};
+  for (size_t i = 0; i < h1.conv.size(); ++i) {
+    float* outp[2] = {buf[0][i & 1], buf[1][i & 1]};
+    GemmArgs g[2];
+    for (int k = 0; k < 2; ++k) {
+      g[k] = gemm(in[k], ldin, hs[k]->conv[i], nullptr, outp[k], Cin, rowsAll, Cin, 3 * Cin);
+      g[k].cin = Cin; g[k].nbr = b.nbr_all;
+    }
+    TRY(run_gemm(m, g, 2, A_ROWS_TAP3, st));
+    for (int k = 0; k < 2; ++k) {
+      LnArgs ln{}; ln.X = outp[k]; ln.ldx = Cin; ln.Y = outp[k]; ln.ldy = Cin; ln.w = hs[k]->ln_w[i]; ln.b = hs[k]->ln_b[i];
+      ln.rows = rowsAll; ln.C = Cin; ln.relu = 1;
+      TRY(launch_ln(ln, st));
+      in[k] = outp[k];
+    }
+    ldin = Cin;
+  }
+  const int NOs[2] = {NO1, NO2}, modes[2] = {mode1, mode2};
+  float* outs[2] = {out1, out2};
+  for (int k = 0; k < 2; ++k) {
+    ConvOutArgs co{};
+    co.X = in[k]; co.ldx = ldin; co.nbr = b.nbr_all; co.W = hs[k]->out_w; co.bias = hs[k]->out_b; co.lt = pl.d_lt;
+    co.out = outs[k]; co.rows = rowsAll; co.C = Cin; co.NO = NOs[k]; co.row0 = 0; co.mode = modes[k]; co.query_major = 1;
+    TRY(launch_conv_out(co, st));
+  }
   return 0;
 }
 
@@ -865,8 +913,7 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
 
     if (c.model_kind == 1) {
       // ---- PtTransformer.fuse_and_predict (model.py:65-69): cls_head / reg_head on the fused pyramid
-      TRY(run_head(m, m->cls1, b, *pl, E, 1, 0, 1, logits_out + (int64_t)q0 * S, st));
-      TRY(run_head(m, m->reg, b, *pl, E, 2, 1, 1, offsets_out + (int64_t)q0 * S * 2, st));
+      TRY(run_head_pair(m, m->cls1, m->reg, b, *pl, E, 1, 0, logits_out + (int64_t)q0 * S, 2, 1, offsets_out + (int64_t)q0 * S * 2, st));
     } else {
     // ---- heads: fuse_and_predict (model.py:442-471).  (Running cls_head level by level on a side stream was
     // measured slower, 40 small launches instead of 5 big ones; the split above is one extra set of 5 launches.)
@@ -885,8 +932,8 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
       ra.B = B; ra.T0 = T0; ra.n_levels = L; ra.n_layers = L;
       TRY(launch_refine(ra, lt, st));
     }
-    TRY(run_head(m, m->cls2, b, *pl, E + TCN_HID, 1, 0, 1, logits_out + (int64_t)q0 * S, st));
-    TRY(run_head(m, m->reg, b, *pl, E + TCN_HID, 2, 1, 1, offsets_out + (int64_t)q0 * S * 2, st));
+    TRY(run_head_pair(m, m->cls2, m->reg, b, *pl, E + TCN_HID, 1, 0, logits_out + (int64_t)q0 * S, 2, 1,
+                      offsets_out + (int64_t)q0 * S * 2, st));
     }
     hipLaunchKernelGGL(k_masks_out, dim3((rowsAll + 255) / 256), dim3(256), 0, st, (const uint8_t*)b.mask_all,
                        masks_out + (int64_t)q0 * S, (const LevelTable*)pl->d_lt);
