@@ -508,7 +508,7 @@ int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, 
   // and the 64-row A tile in LDS is shared by all of them.
   const int N = p.N;
   auto wgs = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * (N / bn) * count; };
-  constexpr long WANT = 512;            // >= 2 workgroups per CU
+  constexpr long WANT = 448;            // ~2 workgroups per CU (32640x256x768: 64x256 tiles, 510 workgroups, 70.8 us vs 76.9 with 64x128)
   static const char* forced = getenv("DCF_GEMM_CFG");      // experiments: tools/gemm_sweep.py
   if (forced) {
     int bm = 0, bn = 0;
@@ -526,7 +526,9 @@ int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, 
   }
   // small grids: split K over the waves instead of the tile (see gemm_bf16s_kslice_kernel)
   static const long kslice_max = getenv("DCF_KSLICE_MAX") ? atol(getenv("DCF_KSLICE_MAX")) : 512;
-  if (mode == A_ROWS && N % 64 == 0 && p.K >= 4 * SBK && wgs(64, 64) <= kslice_max) return launch_kslice(b, count, nterms, stream);
+  // (8192x256x256, 512 tiles: tile kernel 14.9 us vs 18.0 k-sliced; 8192x256x1024: 40 vs 38 -> short K switches at 256 tiles)
+  if (mode == A_ROWS && N % 64 == 0 && p.K >= 4 * SBK && wgs(64, 64) <= (p.K >= 16 * SBK ? kslice_max : kslice_max / 2))
+    return launch_kslice(b, count, nterms, stream);
   if (mode == A_CHANMAJOR) {
     DCF_CHECK(N % 128 == 0, "launch_gemm_split: channel-major A needs N %% 128 == 0");
     if (N % 256 == 0 && wgs(64, 256) >= WANT) return launch_cfg_s<1, 4, 2, 2>(b, count, mode, nterms, stream);
