@@ -72,7 +72,8 @@ def test_linear(L, M, N, K, act):
 
 @pytest.mark.parametrize('nterms,tol', [(6, 2e-5), (3, 3e-4)])
 @pytest.mark.parametrize('M,N,K,act', [(64, 256, 256, 0), (1000, 256, 1024, 1), (333, 1024, 256, 0), (77, 288, 864, 2),
-                                         (50, 160, 128, 0), (200, 96, 64, 0), (129, 64, 32, 0), (65, 32, 32, 0), (4096, 512, 256, 0)])
+                                         (50, 160, 128, 0), (200, 96, 64, 0), (129, 64, 32, 0), (65, 32, 32, 0), (4096, 512, 256, 0),
+                                         (65600, 256, 256, 1), (32704, 288, 96, 0), (20000, 256, 128, 2)])   # 128x256 / 128x96 / 64x256 tiles
 def test_linear_bf16_split(L, M, N, K, act, nterms, tol):
     """fp32-accurate GEMM on the bf16 matrix cores (operand splitting, gemm_bf16s.hip) vs fp64"""
     pkg, lib = L
