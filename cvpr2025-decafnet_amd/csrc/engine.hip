@@ -1289,6 +1289,21 @@ int dcf_op_linear_cm(const float* A_cm, const float* W, const float* bias, float
   return dcf::launch_gemm(&g, 1, dcf::A_CHANMAJOR, (hipStream_t)stream);
 }
 
+int dcf_op_linear_cm_split(const float* A_cm, const float* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K,
+                           int32_t nterms, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  unsigned short* planes = nullptr;
+  DCF_HIP(hipMallocAsync((void**)&planes, (size_t)3 * N * K * sizeof(unsigned short), st));
+  int rc = dcf::launch_split_planes(W, planes, N, K, K, st);
+  if (rc == 0) {
+    dcf::GemmArgs g = dcf::gemm(A_cm, M, W, bias, C, N, M, N, K);
+    g.Ws = planes;
+    rc = dcf::launch_gemm_split(&g, 1, dcf::A_CHANMAJOR, nterms, st);
+  }
+  DCF_HIP(hipFreeAsync(planes, st));
+  return rc;
+}
+
 int dcf_op_conv3(const float* X, const uint8_t* mask, const float* W_ock, float* Y, int32_t B, int32_t T, int32_t Cin,
                  int32_t N, void* stream) {
   hipStream_t st = (hipStream_t)stream;

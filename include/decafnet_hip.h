@@ -170,6 +170,9 @@ int dcf_op_linear_split(const float* A, const float* W, const float* bias, float
 /* same with A given channel-major (K, M) -- the reference's (C, T) layout */
 int dcf_op_linear_cm(const float* A_cm, const float* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K,
                      void* stream);
+/* same product on the bf16-split matrix-core path (how vid_map runs); needs M % 4 == 0, N % 128 == 0, K % 32 == 0 */
+int dcf_op_linear_cm_split(const float* A_cm, const float* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K,
+                           int32_t nterms, void* stream);
 /* MaskedConv1D(k=3, pad=1, no bias) on token-major (B*T, Cin) rows; W is the PyTorch (N, Cin, 3) weight. */
 int dcf_op_conv3(const float* X, const uint8_t* mask, const float* W_ock, float* Y, int32_t B, int32_t T, int32_t Cin,
                  int32_t N, void* stream);

@@ -97,6 +97,21 @@ def test_linear_bf16_split(L, M, N, K, act, nterms, tol):
         assert e6 <= 2.0 * e32 + 1e-7, (float(e6), float(e32))
 
 
+@pytest.mark.parametrize('nterms,tol', [(6, 2e-5), (3, 3e-4)])
+@pytest.mark.parametrize('M,N,K', [(256, 256, 512), (1000, 128, 64), (4096, 256, 1024), (16384, 256, 96), (20, 128, 32)])
+def test_linear_channel_major_split(L, M, N, K, nterms, tol):
+    """channel-major A on the bf16-split path (vid_map): transposed LDS staging of packed (k, k+1) pairs"""
+    pkg, lib = L
+    g = torch.Generator().manual_seed(M + N + K + nterms)
+    X = torch.randn(K, M, generator=g) * 2          # the reference's (C, T) layout
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    ref = X.double().t() @ W.double().t() + b.double()
+    C = torch.empty(M, N, device='cuda')
+    pkg._lib.check(lib.dcf_op_linear_cm_split(P(X.cuda()), P(W.cuda()), P(b.cuda()), P(C), M, N, K, nterms, st()))
+    torch.testing.assert_close(C.cpu().double(), ref, rtol=tol, atol=tol)
+
+
 @pytest.mark.parametrize('M,N,K', [(256, 256, 512), (1000, 128, 64), (4096, 256, 1024), (250, 64, 32)])
 def test_linear_channel_major(L, M, N, K):
     pkg, lib = L
