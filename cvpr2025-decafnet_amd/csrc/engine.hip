@@ -1289,6 +1289,23 @@ int dcf_op_linear_cm(const float* A_cm, const float* W, const float* bias, float
   return dcf::launch_gemm(&g, 1, dcf::A_CHANMAJOR, (hipStream_t)stream);
 }
 
+int dcf_op_linear_ln(const float* A, const float* W, const float* bias, const float* ln_w, const float* ln_b, float* C, float* Y,
+                     int32_t M, int32_t N, int32_t K, int32_t relu, int32_t nterms, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DCF_CHECK(dcf::gemm_can_fuse_ln(M, N, K, dcf::A_ROWS), "dcf_op_linear_ln: %dx%dx%d cannot carry a fused LayerNorm (N = 256, M >= 28672)", M, N, K);
+  unsigned short* planes = nullptr;
+  DCF_HIP(hipMallocAsync((void**)&planes, (size_t)3 * N * K * sizeof(unsigned short), st));
+  int rc = dcf::launch_split_planes(W, planes, N, K, K, st);
+  if (rc == 0) {
+    dcf::GemmArgs g = dcf::gemm(A, K, W, bias, C, N, M, N, K);
+    g.Ws = planes;
+    g.ln_w = ln_w; g.ln_b = ln_b; g.Y = Y; g.ldy = N; g.ln_relu = relu;
+    rc = dcf::launch_gemm_split(&g, 1, dcf::A_ROWS, nterms, st);
+  }
+  DCF_HIP(hipFreeAsync(planes, st));
+  return rc;
+}
+
 int dcf_op_linear_cm_split(const float* A_cm, const float* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K,
                            int32_t nterms, void* stream) {
   hipStream_t st = (hipStream_t)stream;

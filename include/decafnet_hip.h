@@ -170,6 +170,12 @@ int dcf_op_linear_split(const float* A, const float* W, const float* bias, float
 /* same with A given channel-major (K, M) -- the reference's (C, T) layout */
 int dcf_op_linear_cm(const float* A_cm, const float* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K,
                      void* stream);
+/* Y = LayerNorm_channels(A W^T + bias) * ln_w + ln_b [ReLU], the normalisation fused into the GEMM epilogue (how the
+ * head trunks run: MaskedConv1D -> LayerNorm -> ReLU, libs/modeling/head.py:53-64); C (optional, may be NULL) receives
+ * the raw product.  Only shapes the engine fuses: N = 256, M >= 28672, K % 32 == 0. */
+int dcf_op_linear_ln(const float* A, const float* W, const float* bias, const float* ln_w, const float* ln_b, float* C, float* Y,
+                     int32_t M, int32_t N, int32_t K, int32_t relu, int32_t nterms, void* stream);
+
 /* same product on the bf16-split matrix-core path (how vid_map runs); needs M % 4 == 0, N % 128 == 0, K % 32 == 0 */
 int dcf_op_linear_cm_split(const float* A_cm, const float* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K,
                            int32_t nterms, void* stream);

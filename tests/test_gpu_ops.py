@@ -97,6 +97,29 @@ def test_linear_bf16_split(L, M, N, K, act, nterms, tol):
         assert e6 <= 2.0 * e32 + 1e-7, (float(e6), float(e32))
 
 
+@pytest.mark.parametrize('M,K,relu,raw', [(28700, 96, 1, False), (32768, 256, 0, True)])
+def test_linear_with_fused_layernorm(L, M, K, relu, raw):
+    """GEMM with the channel LayerNorm (+ReLU) of the output row in its epilogue vs fp64 (last row tile partial)"""
+    pkg, lib = L
+    N = 256
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=g) * 2
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b, lw, lb = torch.randn(N, generator=g), torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+    v = A.double() @ W.double().t() + b.double()
+    mu = v.mean(1, keepdim=True)
+    ref = (v - mu) / torch.sqrt(((v - mu) ** 2).mean(1, keepdim=True) + 1e-5) * lw.double() + lb.double()
+    if relu:
+        ref = F.relu(ref)
+    C = torch.empty(M, N, device='cuda') if raw else None
+    Y = torch.empty(M, N, device='cuda')
+    pkg._lib.check(lib.dcf_op_linear_ln(P(A.cuda()), P(W.cuda()), P(b.cuda()), P(lw.cuda()), P(lb.cuda()),
+                                        P(C) if raw else None, P(Y), M, N, K, relu, 6, st()))
+    torch.testing.assert_close(Y.cpu().double(), ref, rtol=5e-5, atol=5e-5)
+    if raw:
+        torch.testing.assert_close(C.cpu().double(), v, rtol=2e-5, atol=2e-5)
+
+
 @pytest.mark.parametrize('nterms,tol', [(6, 2e-5), (3, 3e-4)])
 @pytest.mark.parametrize('M,N,K', [(256, 256, 512), (1000, 128, 64), (4096, 256, 1024), (16384, 256, 96), (20, 128, 32)])
 def test_linear_channel_major_split(L, M, N, K, nterms, tol):
