@@ -268,7 +268,9 @@ __global__ __launch_bounds__(256) void k_xattn_mfma(XAttnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// sliding-window self attention
+// sliding-window self attention.  One wave per query row, 8 waves per SIMD.  Measured alternatives (level 0, 26 us):
+// all K/V rows of the window requested up front (4 waves/SIMD) 0.107 -> 0.120 ms per step; next key prefetched in the
+// loop 0.113; K/V of a 16-row strip staged once through LDS (3 workgroups per CU) 0.157.
 // ------------------------------------------------------------------------------------------
 template <int NCH, int LPH>
 __global__ __launch_bounds__(256) void k_local_attn(LocalAttnArgs p) {
@@ -301,8 +303,8 @@ __global__ __launch_bounds__(256) void k_local_attn(LocalAttnArgs p) {
     for (int j = 0; j < NCH; ++j) {
       float s = head_sum<LPH>(dot4(q.v[j], k.v[j] * scale)) + pen;
       float mn = fmaxf(m[j], s);
-      float corr = expf(m[j] - mn);
-      float e = expf(s - mn);
+      float corr = fast_exp(m[j] - mn);                // exp(-inf) = 0 on the first key; v_exp_f32 instead of ~12-instruction expf
+      float e = fast_exp(s - mn);
       acc[j] = acc[j] * corr + e * v.v[j];
       l[j] = l[j] * corr + e;
       m[j] = mn;
