@@ -1,5 +1,7 @@
+"""Copy-kernel ceiling beside the cross-attention core on the same rotating buffers (torch copy: ~5.3 TB/s on MI355X)."""
 import torch, json, sys, os
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tools')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tools'))
 import xattn_bench
 def copy(rows, E, reps=100):
     per_set = 2*rows*E*4
