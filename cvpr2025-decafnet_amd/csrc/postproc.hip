@@ -223,16 +223,80 @@ __global__ __launch_bounds__(NT) void k_nms(NmsArgs p) {
     alive[a] = 1;
   }
   __syncthreads();
-  for (int a = 0; a < n; ++a) {
-    if (!alive[a]) continue;                         // uniform: written before the last barrier
-    const float ix1 = x1[a], ix2 = x2[a], ia = ar[a];
-    for (int b = a + 1 + tid; b < n; b += NT) {
-      if (!alive[b]) continue;
-      const float xx1 = fmaxf(ix1, x1[b]);
-      const float xx2 = fminf(ix2, x2[b]);
-      const float inter = fmaxf(0.f, xx2 - xx1);
-      const float ovr = inter / (ia + ar[b] - inter);
-      if (ovr >= p.iou_thresh) alive[b] = 0;
+  // Greedy suppression in blocks of 64 candidates (sorted order).  The kept set of a greedy NMS does not depend on the
+  // order in which suppressions are applied, only on "i kept => every later j with IoU(i, j) >= thr dies":
+  //   1. all threads build the 64 x 64 suppression bit matrix of the block (four IoUs each), wave 0 resolves the block
+  //      with a scalar scan over readlane'd rows (no barrier per candidate: the one-candidate-per-barrier loop this
+  //      replaces took 0.87 ms at n = 2000);
+  //   2. every thread tests the later candidates against the (<= 64) kept members of the block.
+  // Four barriers per 64 candidates.  IoU arithmetic as nms_cpu.cpp:38-56 (same fp32 expressions).
+  __shared__ int s_kept[64];
+  __shared__ int s_nkept;
+  __shared__ unsigned s_row[64][2];
+  const bool nonpos_thr = !(p.iou_thresh > 0.f);       // then 0 >= thr holds and disjoint pairs suppress too
+  for (int a0 = 0; a0 < n; a0 += 64) {
+    // 1a. the 64 x 64 bit matrix with all threads: thread -> (row i, four columns j)
+    if (tid < 128) s_row[tid >> 1][tid & 1] = 0u;
+    __syncthreads();
+    {
+      const int i = tid >> 4, j0 = (tid & 15) * 4;
+      const int gi = a0 + i;
+      if (gi < n) {
+        const float ix1 = x1[gi], ix2 = x2[gi], ia = ar[gi];
+        unsigned bits = 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int j = j0 + q, gj = a0 + j;
+          if (j > i && gj < n) {
+            const float xx1 = fmaxf(ix1, x1[gj]);
+            const float xx2 = fminf(ix2, x2[gj]);
+            const float inter = fmaxf(0.f, xx2 - xx1);
+            if (inter > 0.f || nonpos_thr) {             // disjoint pairs: ovr = 0 < thr, no division needed
+              const float ovr = inter / (ia + ar[gj] - inter);
+              if (ovr >= p.iou_thresh) bits |= 1u << (j & 31);
+            }
+          }
+        }
+        if (bits) atomicOr(&s_row[i][j0 >> 5], bits);
+      }
+    }
+    __syncthreads();
+    // 1b. wave 0 resolves the block
+    if (tid < 64) {
+      const int i = a0 + tid;
+      const bool valid = i < n;
+      const bool al = valid && alive[i];
+      const unsigned rlo = s_row[tid][0], rhi = s_row[tid][1];
+      const unsigned long long alive_mask = __ballot(al);
+      unsigned long long removed = ~alive_mask, keepmask = 0ull;
+#pragma unroll
+      for (int k = 0; k < 64; ++k) {                   // scalar scan: rows come from lane k
+        const unsigned long long rk = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)rhi, k) << 32) |
+                                      (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)rlo, k);   // readlane returns int: no sign extension
+        if (!((removed >> k) & 1ull)) { keepmask |= 1ull << k; removed |= rk; }
+      }
+      const bool kept = (keepmask >> tid) & 1ull;
+      if (valid) alive[i] = kept ? 1 : 0;
+      if (kept) s_kept[__popcll(keepmask & ((1ull << tid) - 1ull))] = i;
+      if (tid == 0) s_nkept = __popcll(keepmask);
+    }
+    __syncthreads();
+    const int nk = s_nkept;
+    if (nk > 0) {
+      for (int b = a0 + 64 + tid; b < n; b += NT) {
+        if (!alive[b]) continue;
+        const float bx1 = x1[b], bx2 = x2[b], ba = ar[b];
+        for (int k = 0; k < nk; ++k) {
+          const int a = s_kept[k];
+          const float xx1 = fmaxf(x1[a], bx1);
+          const float xx2 = fminf(x2[a], bx2);
+          const float inter = fmaxf(0.f, xx2 - xx1);
+          if (inter > 0.f || nonpos_thr) {
+            const float ovr = inter / (ar[a] + ba - inter);
+            if (ovr >= p.iou_thresh) { alive[b] = 0; break; }
+          }
+        }
+      }
     }
     __syncthreads();
   }
