@@ -113,9 +113,7 @@ def main():
     # stream shares a hardware queue on some runs, so three is the default).
     others = []
     for k in range(1, max(1, args.videos)):
-        mk = pkg.modeling.create_model(opt)
-        mk.load_state_dict(sd)
-        mk = mk.to(dev).eval().requires_grad_(False)
+        mk = model.replica()                        # same parameters, own engine / workspace / graph
         mk.reuse_output_buffers = True
         ik = pkg.synth.make_inputs(kw['D'], T, vid_len, args.nq, kw['text_in'], 32, 2025 + 3 + rank + 1000 * k)
         tk, mkk = zip(*[mk.encode_text(tok[None].to(dev), torch.ones(1, 1, tok.size(-1), dtype=torch.bool, device=dev))

@@ -400,6 +400,16 @@ class PtTransformerEarlyFusionIterative(nn.Module):
             raise NotImplementedError('only the eval forward (eval=True) is implemented; training is out of scope')
         return self._drop_forward_eval(vid, shallow_vid, vid_masks, text, text_cls, text_masks, text_size, mv_data, eval)
 
+    def replica(self):
+        """A second handle on the SAME parameters with its own engine (workspace, repacked weights, HIP graph): run it on
+        another HIP stream to keep several videos in flight (throughput mode, see bench.py).  Parameters are shared by
+        reference; call after ``.cuda().eval()``."""
+        other = copy.copy(self)                     # shallow: _parameters / _modules / _buffers are the same objects
+        other._engine = None
+        other._out_cache = {}
+        other._last_inputs = other._last_flat = None
+        return other
+
     # -- HIP path ----------------------------------------------------------------------------
     def _config(self) -> _lib.DcfConfig:
         c = _lib.DcfConfig()
