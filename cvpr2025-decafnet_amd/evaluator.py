@@ -115,17 +115,19 @@ class GroundingEvaluator:
         self.time_dict = defaultdict(list)
 
     @torch.no_grad()
-    def forward(self, data):
+    def forward(self, data, model=None):
         """data: vid (D,T), shallow_vid (D,T), text: tuple of (C_t, Lq) token tensors, text_cls (NQ,D).
-        Returns the flat device outputs (logits (NQ,S), offsets (NQ,S,2), masks (NQ,S)) and T_padded."""
-        dev = next(self.model.parameters()).device
+        Returns the flat device outputs (logits (NQ,S), offsets (NQ,S,2), masks (NQ,S)) and T_padded.
+        ``model``: a ``self.model.replica()`` when several videos are kept in flight (``run(n_streams > 1)``)."""
+        model_ = model or self.model
+        dev = next(model_.parameters()).device
         t0 = time.perf_counter()
         tokens = data['text'] if isinstance(data['text'], (tuple, list)) else (data['text'],)
         texts, tmasks = [], []
         for tok in tokens:
             tok = tok[None].to(dev, non_blocking=True)
             m = torch.ones(1, 1, tok.size(-1), dtype=torch.bool, device=dev)
-            t, m = self.model.encode_text(tok, m)
+            t, m = model_.encode_text(tok, m)
             texts.append(t)
             tmasks.append(m)
         vid, shallow = data['vid'], data['shallow_vid']
@@ -137,10 +139,10 @@ class GroundingEvaluator:
         text_cls = data['text_cls'].to(dev, non_blocking=True)
         self.time_dict['prepare'].append(time.perf_counter() - t0)
         t0 = time.perf_counter()
-        out = self.model(window, shallow_window, mask, tuple(texts), text_cls, tuple(tmasks), eval=True)
+        out = model_(window, shallow_window, mask, tuple(texts), text_cls, tuple(tmasks), eval=True)
         self.time_dict['forward'].append(time.perf_counter() - t0)
         self.outputs = out
-        return self.model._last_flat, T
+        return model_._last_flat, T
 
     @torch.no_grad()
     def generate_proposals(self, flat, T, data=None):
@@ -168,10 +170,34 @@ class GroundingEvaluator:
         flat, T = self.forward(data)
         return self.generate_proposals(flat, T, data)
 
-    def run(self, dataset, counter: RecallCounter = None):
+    def run(self, dataset, counter: RecallCounter = None, n_streams: int = 1):
         """Evaluator.run (worker_v2.py:815-910) over an iterable of per-video dicts (keys as in
         libs/data/dataset.py:977-994: vid, shallow_vid, text, text_cls, segment, fps, clip_stride, clip_size, duration)."""
         counter = counter or RecallCounter(self.opt['eval'].get('ranks', (1, 5)), self.opt['eval'].get('iou_threshs', (0.3, 0.5)))
+        if n_streams <= 1:
+            for data in dataset:
+                counter.update(self.predict(data), data['segment'])
+            return counter
+        # throughput mode: n_streams videos in flight, one model replica (shared parameters, own workspace) and one HIP
+        # stream each; the decode / NMS of a video (host syncs on its own stream only) overlaps the forwards of the others
+        lanes = [(self.model if i == 0 else self.model.replica(), torch.cuda.Stream()) for i in range(n_streams)]
+        group = []
+
+        def finish():
+            for stream, flat, T, data in group:
+                with torch.cuda.stream(stream):
+                    res = self.generate_proposals(flat, T, data)
+                counter.update(res, data['segment'])
+            group.clear()
+
         for data in dataset:
-            counter.update(self.predict(data), data['segment'])
+            mdl, stream = lanes[len(group)]
+            stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(stream):
+                flat, T = self.forward(data, mdl)
+            group.append((stream, flat, T, data))
+            if len(group) == n_streams:
+                finish()
+        finish()
+        torch.cuda.synchronize()
         return counter
