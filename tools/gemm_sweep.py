@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 SHAPES = [(16384, 256, 256), (16384, 1024, 256), (16384, 256, 1024), (16384, 512, 256), (8192, 256, 256), (8192, 1024, 256),
           (8192, 256, 1024), (32640, 256, 768), (131072, 256, 256), (131072, 256, 1024), (131072, 1024, 256)]
-TILES = ['x6:auto', 'x6:64x256', 'x6:64x128', 'x6:64x64', 'x6:128x128']
+TILES = ['x6:auto', 'x6:64x256', 'x6:64x128']
 
 def child():
     import torch
