@@ -22,7 +22,8 @@ class DcfConfig(ctypes.Structure):
     _fields_ = [(n, i32) for n in ('D', 'E', 'TE', 'vid_heads', 'fusion_heads', 'fusion_layers', 'n_embd_convs',
                                    'n_stem', 'n_levels', 'win', 'head_layers', 'sn')] + \
                [('sratio', f32)] + [(n, i32) for n in ('msf', 'norm', 'use_abs_pe', 'max_batch', 'gemm_mode', 'model_kind', 'second_fusion',
-                                                      'text_in', 'text_layers', 'text_heads', 'text_abs_pe', 'text_bkgd')]
+                                                      'text_in', 'text_layers', 'text_heads', 'text_abs_pe', 'text_bkgd',
+                                                      'scat', 'sfonly')]
 
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header

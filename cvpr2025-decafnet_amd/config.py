@@ -40,13 +40,13 @@ def to_attr(d):
 def make_opt(D=1024, E=256, TE=256, text_in=300, n_levels=8, win=9, n_heads=4, sn=60, sratio=0.3,
              msf=True, scat=False, norm=True, max_seq_len=2304, text_layers=5, fusion_layers=2,
              text_max_len=48, n_embd_convs=2, n_stem=0, head_layers=2, use_abs_pe=True,
-             text_use_abs_pe=False, max_vid_len=None):
+             text_use_abs_pe=False, max_vid_len=None, sfonly=False):
     """Build an ``opt`` tree with the keys the hot path reads.  Defaults are
     the survey's probe configuration: D=1024, E=TE=256, L=8, w=9,
     4 heads, 2 fusion layers, sn=60, sratio=0.3, msf, norm."""
     opt = dict(
         model=dict(
-            name='iter', sn=sn, sratio=sratio, msf=msf, scat=scat, sfonly=False, norm=norm,
+            name='iter', sn=sn, sratio=sratio, msf=msf, scat=scat, sfonly=sfonly, norm=norm,
             max_vid_len=max_vid_len or max_seq_len, vid_stride=1,
             num_fpn_levels=n_levels, mha_win_size=win,
             text_net=dict(name='transformer', in_dim=text_in, embd_dim=TE, max_seq_len=text_max_len,

@@ -154,6 +154,9 @@ struct dcf_model {
 
   // resolved weights
   const float *vid_map_w = nullptr, *vid_map_b = nullptr;
+  // column blocks of the (E, Din) vid_map weight: expert half, sidekick half, the scat column (model.py:543-551)
+  const float *vid_w1 = nullptr, *vid_w2 = nullptr, *vid_w3 = nullptr;
+  int64_t vid_ldw = 0;
   std::vector<DecW> dec;
   const float *fus_out_w = nullptr, *fus_out_b = nullptr;
   const float *embd_fc_w = nullptr, *embd_fc_b = nullptr;
@@ -308,10 +311,18 @@ static int resolve_head(dcf_model* m, const std::string& p, const std::string& o
   return 0;
 }
 
+// model.py:411-414 / :543-551: what vid_map (PtTransformer: vid_net.embd_fc) sees.  sfonly only exists in the iterative
+// model and only on the msf branch (`elif`, model.py:546); its input is then the sidekick features alone.
+static inline bool vidmap_sfonly(const dcf_config& c) { return c.model_kind == 0 && c.msf && c.sfonly; }
+static inline int vidmap_in_dim(const dcf_config& c) {
+  return ((c.msf && !vidmap_sfonly(c)) ? 2 * c.D : c.D) + (c.scat ? 1 : 0);
+}
+
 static int finalize(dcf_model* m, hipStream_t st) {
   const dcf_config& c = m->cfg;
   const int E = c.E, D = c.D, TE = c.TE, L = c.n_levels;
-  const int Din = c.msf ? 2 * D : D;
+  const bool sfonly = vidmap_sfonly(c);
+  const int Din = vidmap_in_dim(c);
   for (float* p : m->owned) (void)hipFree(p);
   m->owned.clear();
   m->wsplit.clear();
@@ -358,10 +369,28 @@ static int finalize(dcf_model* m, hipStream_t st) {
   } else {
     GET("vid_map.conv.weight", SH(E, Din), m->vid_map_w); GET("vid_map.conv.bias", SH(E), m->vid_map_b);
   }
-  // the deep / shallow column halves of the (E, [2]D) weight are separate GEMM operands with row pitch Din
+  // the deep / shallow column halves of the (E, [2]D[+1]) weight are separate GEMM operands with row pitch Din
+  m->vid_w1 = (c.msf && sfonly) ? nullptr : m->vid_map_w;
+  m->vid_w2 = c.msf ? (sfonly ? m->vid_map_w : m->vid_map_w + D) : nullptr;
+  m->vid_w3 = nullptr;
+  m->vid_ldw = Din;
+  if (c.scat) {
+    // the extra score column makes the row pitch odd: keep aligned copies of the column blocks (pitch D) and of the column
+    float* blk[3] = {nullptr, nullptr, nullptr};
+    const float* src[3] = {m->vid_w1, m->vid_w2, m->vid_map_w + (Din - 1)};
+    const int wid[3] = {D, D, 1};
+    for (int i = 0; i < 3; ++i) {
+      if (!src[i]) continue;
+      DCF_HIP(hipMalloc(&blk[i], (size_t)E * wid[i] * sizeof(float)));
+      m->owned.push_back(blk[i]);
+      DCF_HIP(hipMemcpy2DAsync(blk[i], (size_t)wid[i] * 4, src[i], (size_t)Din * 4, (size_t)wid[i] * 4, E, hipMemcpyDeviceToDevice, st));
+    }
+    m->vid_w1 = blk[0]; m->vid_w2 = blk[1]; m->vid_w3 = blk[2];
+    m->vid_ldw = D;
+  }
   if (D % 32 == 0 && E % 32 == 0) {
-    if (split_weight(m, m->vid_map_w, E, D, st, Din)) return -1;
-    if (c.msf && split_weight(m, m->vid_map_w + D, E, D, st, Din)) return -1;
+    if (m->vid_w1 && split_weight(m, m->vid_w1, E, D, st, m->vid_ldw)) return -1;
+    if (m->vid_w2 && split_weight(m, m->vid_w2, E, D, st, m->vid_ldw)) return -1;
   }
   for (int i = 0; i < c.fusion_layers; ++i) {
     const std::string p = "fusion.layers." + std::to_string(i);
@@ -788,6 +817,7 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
   }
   // ---- per video: sidekick scores and the query-independent halves of vid_map
   bool forked = false;
+  DCF_CHECK(!(gate_override && c.scat), "opt.model.scat needs the sidekick scores: the externally gated (T-sharded) forward does not take them");
   if (!gate_override) {
     // HBM-bound scoring of the shallow features next to the MFMA-bound vid_map GEMMs
     ScoreArgs sa{shallow, text_cls, b.tn, b.partial, b.correl, D, T0, nq, c.norm};
@@ -799,13 +829,14 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
       TRY(launch_sidekick(sa, st));
     }
   }
-  const int Din = c.msf ? 2 * D : D;
   {
     // deep and shallow halves of vid_map share one grid (same shape, blockIdx.z selects the operand set)
-    GemmArgs g[2] = {gemm(vid, T0, m->vid_map_w, nullptr, b.P1, E, T0, E, D),
-                     gemm(shallow, T0, m->vid_map_w + D, nullptr, b.P2, E, T0, E, D)};
-    g[0].ldw = g[1].ldw = Din;
-    TRY(run_gemm(m, g, c.msf ? 2 : 1, A_CHANMAJOR, st));
+    GemmArgs g[2];
+    int ng = 0;
+    if (m->vid_w1) g[ng++] = gemm(vid, T0, m->vid_w1, nullptr, b.P1, E, T0, E, D);
+    if (m->vid_w2) g[ng++] = gemm(shallow, T0, m->vid_w2, nullptr, b.P2, E, T0, E, D);
+    for (int i = 0; i < ng; ++i) g[i].ldw = m->vid_ldw;
+    TRY(run_gemm(m, g, ng, A_CHANMAJOR, st));
     if (forked) TRY(join_side(m, 0, st));
   }
 
@@ -830,7 +861,8 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
     const uint8_t* mask0 = b.mask_all;
 
     // ---- vid_map (model.py:543-555)
-    TRY(launch_vidmap_combine(b.P1, c.msf ? b.P2 : nullptr, m->vid_map_b, b.gate, mask0, b.X, T0, rows0, E, st));
+    TRY(launch_vidmap_combine(m->vid_w1 ? b.P1 : nullptr, m->vid_w2 ? b.P2 : nullptr, m->vid_map_b, b.gate, mask0,
+                              m->vid_w3, m->vid_w3 ? b.correl + (int64_t)q0 * T0 : nullptr, b.X, T0, rows0, E, st));
     if (m->keep_debug && m->dbg_vidmap) DCF_HIP(hipMemcpyAsync(m->dbg_vidmap, b.X, (size_t)rows0 * E * 4, hipMemcpyDeviceToDevice, st));
 
     // ---- text side: pointers of this chunk
@@ -1005,7 +1037,7 @@ static int text_encode(dcf_model* m, const float* tokens, const uint8_t* token_m
 extern "C" {
 
 const char* dcf_last_error(void) { return dcf::g_err.c_str(); }
-int dcf_abi_version(void) { return 2; }
+int dcf_abi_version(void) { return 3; }
 
 int dcf_model_create(const dcf_config* cfg, dcf_model** out) {
   DCF_CHECK(cfg && out, "dcf_model_create: null argument");

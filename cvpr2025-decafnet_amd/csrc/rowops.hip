@@ -61,29 +61,34 @@ __global__ void k_mask_down(const uint8_t* __restrict__ in, uint8_t* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
-// vid_map epilogue: X0[b,t,:] = m * (g * P1[t,:] + P2[t,:]) + bias     (model.py:543-555)
-// P1 = W[:, :D] . vid, P2 = W[:, D:] . shallow are query independent and computed once.
+// vid_map epilogue: X0[b,t,:] = m * (g * P1[t,:] + P2[t,:] + correl[b,t] * w3) + bias     (model.py:543-555)
+// P1 = W[:, :D] . vid, P2 = W[:, D:2D] . shallow are query independent and computed once; w3 = W[:, 2D] is the
+// column of the raw-score channel (opt.model.scat).  P1 is null for sfonly, P2 without msf, w3 without scat.
 // ------------------------------------------------------------------------------------------
 template <int NCH>
 __global__ __launch_bounds__(256) void k_vidmap_combine(const float* __restrict__ P1, const float* __restrict__ P2,
                                                          const float* __restrict__ bias, const float* __restrict__ gate,
-                                                         const uint8_t* __restrict__ mask, float* __restrict__ X,
-                                                         int T, int rows, int E) {
+                                                         const uint8_t* __restrict__ mask,
+                                                         const float* __restrict__ w3, const float* __restrict__ correl,
+                                                         float* __restrict__ X, int T, int rows, int E) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
   const int t = r % T;
   const float m = mask[r] ? 1.f : 0.f;
   const float g = gate[r];
+  const float s = w3 ? correl[r] : 0.f;     // scat: the clip's raw sidekick score is one more input channel
   Row<NCH> a, b;
-  a.load(P1 + (int64_t)t * E, E, lane);
+  if (P1) a.load(P1 + (int64_t)t * E, E, lane); else a.zero();
   if (P2) b.load(P2 + (int64_t)t * E, E, lane); else b.zero();
 #pragma unroll
   for (int j = 0; j < NCH; ++j) {
     int c = 256 * j + 4 * lane;
     if (c < E) {
       f32x4 bb = *reinterpret_cast<const f32x4*>(bias + c);
-      a.v[j] = m * (g * a.v[j] + b.v[j]) + bb;
+      f32x4 v = g * a.v[j] + b.v[j];
+      if (w3) v += s * *reinterpret_cast<const f32x4*>(w3 + c);
+      a.v[j] = m * v + bb;
     }
   }
   a.store(X + (int64_t)r * E, E, lane);
@@ -386,11 +391,11 @@ int launch_mask_down(const uint8_t* in, uint8_t* out, int rows_out, hipStream_t 
 }
 
 int launch_vidmap_combine(const float* P1, const float* P2, const float* bias, const float* gate, const uint8_t* mask,
-                          float* X, int T, int rows, int E, hipStream_t st) {
+                          const float* w3, const float* correl, float* X, int T, int rows, int E, hipStream_t st) {
   if (rows <= 0) return 0;
   ProfScope prof("vidmap_combine", st, 3.0 * rows * E, 4.0 * 3.0 * rows * E);
   DISPATCH_NCH(E, hipLaunchKernelGGL((k_vidmap_combine<NCH>), dim3((rows + 3) / 4), dim3(256), 0, st, P1, P2, bias, gate,
-                                     mask, X, T, rows, E));
+                                     mask, w3, correl, X, T, rows, E));
   return 0;
 }
 

@@ -351,19 +351,22 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         mo = opt['model'] if isinstance(opt, dict) else opt.model
         mo = copy.deepcopy(mo)
         self.opt = opt
-        if mo.get('scat', False) or mo.get('sfonly', False):
-            raise NotImplementedError('opt.model.scat / sfonly are not supported by the HIP path')
         vn, tn, fu = dict(mo['vid_net']), dict(mo['text_net']), dict(mo['fusion'])
         if vn.get('name', 'transformer') != 'transformer' or tn.get('name', 'transformer') != 'transformer':
             raise NotImplementedError('only the transformer video / text backbones are supported')
         self.sn, self.sratio = int(mo['sn']), float(mo['sratio'])
         self.msf, self.norm = bool(mo['msf']), bool(mo['norm'])
-        D, E = int(vn['in_dim']), int(vn['embd_dim'])
+        self.scat, self.sfonly = bool(mo.get('scat', False)), bool(mo.get('sfonly', False))
+        in_dim, E = int(vn['in_dim']), int(vn['embd_dim'])
+        # model.py:409-416: vid_map takes in_dim (x2 with msf) (+1 with scat) channels.  With msf and sfonly its input is
+        # the sidekick features alone (model.py:546-547), so the feature files are 2*in_dim wide in that configuration.
+        map_in = (2 * in_dim if self.msf else in_dim)
+        D = map_in if (self.msf and self.sfonly) else in_dim
         self.D, self.E = D, E
 
         tn.pop('name', None)
         self.text_net = TextTransformer(**tn)
-        self.vid_map = MaskedConv1D(2 * D if self.msf else D, E, 1)
+        self.vid_map = MaskedConv1D(map_in + int(self.scat), E, 1)
         vn.pop('name', None)
         vn['in_dim'] = E
         self.vid_net = VideoTransformer(**vn)
@@ -419,6 +422,7 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         c.n_embd_convs, c.n_stem, c.n_levels = vn.arch
         c.win, c.head_layers = vn.mha_win_size, self.head_layers
         c.sn, c.sratio, c.msf, c.norm = self.sn, self.sratio, int(self.msf), int(self.norm)
+        c.scat, c.sfonly = int(self.scat), int(self.sfonly and self.MODEL_KIND == 0)
         c.use_abs_pe, c.max_batch = int(vn.use_abs_pe), self.max_batch
         c.gemm_mode = self.gemm_mode
         c.model_kind, c.second_fusion = self.MODEL_KIND, int(bool(self.second_fusion))
@@ -530,17 +534,16 @@ class PtTransformer(PtTransformerEarlyFusionIterative):
         nn.Module.__init__(self)
         mo = copy.deepcopy(opt['model'] if isinstance(opt, dict) else opt.model)
         self.opt = opt
-        if mo.get('scat', False) or mo.get('sfonly', False):
-            raise NotImplementedError('opt.model.scat / sfonly are not supported by the HIP path')
         vn, tn, fu = dict(mo['vid_net']), dict(mo['text_net']), dict(mo['fusion'])
         self.sn, self.sratio = int(mo['sn']), float(mo['sratio'])
         self.msf, self.norm = bool(mo['msf']), bool(mo['norm'])
+        self.scat, self.sfonly = bool(mo.get('scat', False)), False     # model.py:30-161 never reads opt.model.sfonly
         D, E = int(vn['in_dim']), int(vn['embd_dim'])
         self.D, self.E = D, E
         tn.pop('name', None)
         self.text_net = TextTransformer(**tn)
         vn.pop('name', None)
-        vn['in_dim'] = 2 * D if self.msf else D
+        vn['in_dim'] = (2 * D if self.msf else D) + int(self.scat)      # model.py:43-48
         self.vid_net = VideoTransformer(**vn)
         fu.pop('name', None)
         self.fusion = XAttNFusion(**fu)

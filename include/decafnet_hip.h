@@ -57,6 +57,11 @@ typedef struct dcf_config {
   int32_t text_heads;     /* opt.model.text_net.n_heads                                            */
   int32_t text_abs_pe;    /* opt.model.text_net.use_abs_pe                                         */
   int32_t text_bkgd;      /* opt.model.text_net.use_bkgd_token                                     */
+  /* ABI version 3 */
+  int32_t scat;           /* opt.model.scat: the clip's raw sidekick score is one more vid_map input channel
+                           * (model.py:413-414,550-551; PtTransformer model.py:46-47,128-129)      */
+  int32_t sfonly;         /* opt.model.sfonly: with msf, vid_map sees the sidekick features only (model.py:546-547);
+                           * D is then the sidekick feature dim = 2 * opt.model.vid_net.in_dim; ignored by model_kind 1 */
 } dcf_config;
 
 int dcf_model_create(const dcf_config* cfg, dcf_model** out);

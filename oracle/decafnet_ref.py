@@ -419,8 +419,9 @@ def encode_text(sd: SD, cfg, tokens: Tensor, token_masks: Tensor):
     return text_transformer(sd, cfg['text_net'], tokens, token_masks)
 
 
-def gated_video_input(cfg, vid, shallow_vid, vid_masks, correl, b):
-    """model.py:527-551 for query ``b``: returns (x (1, C_in, T), mask (1, T))."""
+def gated_video_input(cfg, vid, shallow_vid, vid_masks, correl, b, allow_sfonly=True):
+    """model.py:527-551 for query ``b``: returns (x (1, C_in, T), mask (1, T)).  PtTransformer (model.py:123-129) has
+    the same lines without the sfonly branch (``allow_sfonly=False``)."""
     vid = vid.clone()
     masks = vid_masks.clone()
     vid_len = int(masks.sum())
@@ -430,7 +431,7 @@ def gated_video_input(cfg, vid, shallow_vid, vid_masks, correl, b):
     vid = vid * all_weight.unsqueeze(1)
     if not cfg['msf']:
         masks = torch.logical_and(all_weight.bool(), masks)
-    elif cfg.get('sfonly', False):
+    elif allow_sfonly and cfg.get('sfonly', False):
         vid = shallow_vid
     else:
         vid = torch.cat([vid, shallow_vid], dim=1)
@@ -478,7 +479,7 @@ def forward_eval_late_fusion(sd: SD, cfg, vid: Tensor, shallow_vid: Tensor, vid_
     vn = dict(cfg['vid_net'])
     logits_list, offsets_list, masks_list = [], [], []
     for b, (txt, txt_mask) in enumerate(zip(text, text_masks)):
-        x, masks = gated_video_input(cfg, vid, shallow_vid, vid_masks, correl, b)
+        x, masks = gated_video_input(cfg, vid, shallow_vid, vid_masks, correl, b, allow_sfonly=False)
         fpn, fpn_masks = video_transformer(sd, vn, x, masks)
         fpn, fpn_masks = xattn_fusion_pyramid(sd, cfg['fusion'], fpn, fpn_masks, txt, txt_mask)
         lg, _ = cls_head(sd, 'cls_head', fpn, fpn_masks, cfg['cls_head'].get('n_layers', 2))

@@ -229,7 +229,17 @@ E2E_CASES = {
     'nomsf': dict(opt=dict(D=64, E=64, TE=32, text_in=32, n_levels=3, win=5, n_heads=2, sn=8, sratio=0.5,
                            msf=False, norm=False, max_seq_len=128, text_layers=1, text_max_len=24),
                   T=128, vid_len=100, nq=2, lq=5, wseed=41, iseed=42),
+    # opt.model.scat: the raw sidekick score row is one more vid_map input channel (model.py:413-414,550-551)
+    'scat': dict(opt=dict(D=64, E=64, TE=32, text_in=32, n_levels=3, win=5, n_heads=2, sn=8, sratio=0.4,
+                          msf=True, scat=True, norm=True, max_seq_len=128, text_layers=1, text_max_len=24),
+                 T=128, vid_len=115, nq=2, lq=6, wseed=71, iseed=72),
+    # opt.model.sfonly (+ scat): vid_map sees the sidekick features alone (model.py:546-547); vid_net.in_dim * 2 must then
+    # equal the feature width, so the features are 64 wide with in_dim = 32
+    'sfonly': dict(opt=dict(D=32, E=64, TE=32, text_in=32, n_levels=3, win=5, n_heads=2, sn=8, sratio=0.4,
+                            msf=True, scat=True, sfonly=True, norm=True, max_seq_len=128, text_layers=1, text_max_len=24),
+                   feat_dim=64, T=128, vid_len=120, nq=2, lq=4, wseed=81, iseed=82),
 }
+ONLY = set(filter(None, os.environ.get('ONLY', '').split(',')))
 
 
 # secondary compositions of the same blocks: late fusion (PtTransformer) and second_fusion=True
@@ -240,6 +250,10 @@ E2E_VARIANTS = {
     'second': dict(cls='iter2', opt=dict(D=64, E=64, TE=32, text_in=32, n_levels=4, win=5, n_heads=4, sn=16, sratio=0.3,
                                          msf=True, norm=True, max_seq_len=256, text_layers=1, text_max_len=24),
                    T=256, vid_len=256, nq=2, lq=5, wseed=61, iseed=62),
+    # PtTransformer without msf and with scat (model.py:43-48,124-129): embd_fc is (E, D+1, 1), the gate goes into the mask
+    'late_scat': dict(cls='PtTransformer', opt=dict(D=64, E=64, TE=32, text_in=32, n_levels=3, win=5, n_heads=4, sn=8, sratio=0.5,
+                                                    msf=False, scat=True, norm=True, max_seq_len=128, text_layers=1, text_max_len=24),
+                      T=128, vid_len=101, nq=2, lq=5, wseed=91, iseed=92),
 }
 
 
@@ -247,6 +261,8 @@ E2E_VARIANTS = {
 def gen_e2e_variants():
     from libs.modeling.model import PtTransformerEarlyFusionIterative, PtTransformer
     for name, c in E2E_VARIANTS.items():
+        if ONLY and name not in ONLY:
+            continue
         opt = make_opt(**c['opt'])
         if c['cls'] == 'PtTransformer':
             model = PtTransformer(opt.clone()).eval()
@@ -276,12 +292,14 @@ def gen_e2e_variants():
 def gen_e2e():
     from libs.modeling.model import PtTransformerEarlyFusionIterative, PtGenerator
     for name, c in E2E_CASES.items():
+        if ONLY and name not in ONLY:
+            continue
         opt = make_opt(**c['opt'])
         model = PtTransformerEarlyFusionIterative(opt.clone(), second_fusion=False).eval()
         shapes = {k: list(v.shape) for k, v in model.state_dict().items()}
         sd = synth.make_state_dict(shapes, c['wseed'])
         model.load_state_dict(sd)
-        inp = synth.make_inputs(c['opt']['D'], c['T'], c['vid_len'], c['nq'], c['opt']['text_in'], c['lq'], c['iseed'])
+        inp = synth.make_inputs(c.get('feat_dim', c['opt']['D']), c['T'], c['vid_len'], c['nq'], c['opt']['text_in'], c['lq'], c['iseed'])
         texts, tmasks = [], []
         for tok in inp['tokens']:
             t, m = model.encode_text(tok[None], torch.ones(1, 1, tok.size(-1), dtype=torch.bool))
@@ -293,7 +311,7 @@ def gen_e2e():
         logits, offsets, masks = model(inp['vid'], inp['shallow_vid'], inp['vid_masks'], tuple(texts),
                                        inp['text_cls'], tuple(tmasks), eval=True)
         out = dict(opt_kwargs=c['opt'], meta=dict(T=c['T'], vid_len=c['vid_len'], nq=c['nq'], lq=c['lq'],
-                                                  wseed=c['wseed'], iseed=c['iseed']),
+                                                  wseed=c['wseed'], iseed=c['iseed'], feat_dim=c.get('feat_dim', c['opt']['D'])),
                    shapes=shapes,
                    weight_checksum=torch.stack([sum(v.double().sum() for v in sd.values()),
                                                 sum(v.double().abs().sum() for v in sd.values())]))

@@ -49,12 +49,12 @@ def test_config_struct_layout():
     assert fields == [f[0] for f in pkg._lib.DcfConfig._fields_]
 
 
-@pytest.mark.parametrize('name', ['c1', 'pe', 'nomsf', 'late', 'second'])
+@pytest.mark.parametrize('name', ['c1', 'pe', 'nomsf', 'scat', 'sfonly', 'late', 'second', 'late_scat'])
 def test_parameter_abi_matches_reference(name):
     """state_dict keys and shapes == the reference model's (captured in the fixture)"""
     pkg = load_pkg()
     g = Golden(f'e2e_{name}.npz')
-    if name == 'late':
+    if name.startswith('late'):
         model = pkg.modeling.PtTransformer(pkg.config.make_opt(**g.js('opt_kwargs')))
     else:
         model = pkg.modeling.create_model(pkg.config.make_opt(**g.js('opt_kwargs')))
@@ -88,10 +88,6 @@ def test_points_match_reference_and_text_encoder_has_no_cpu_path():
 def test_unsupported_switches_fail_loudly():
     pkg = load_pkg()
     kw = Golden('e2e_nomsf.npz').js('opt_kwargs')
-    opt = pkg.config.make_opt(**kw)
-    opt.model['scat'] = True
-    with pytest.raises(NotImplementedError):
-        pkg.modeling.create_model(opt)
     opt = pkg.config.make_opt(**kw)
     opt.model['name'] = 'default'
     with pytest.raises(NotImplementedError):

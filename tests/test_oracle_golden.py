@@ -116,7 +116,7 @@ def test_gate_cases():
 
 
 # ------------------------------------------------------------------ G3
-@pytest.mark.parametrize('name', ['c1', 'pe', 'nomsf'])
+@pytest.mark.parametrize('name', ['c1', 'pe', 'nomsf', 'scat', 'sfonly'])
 def test_end_to_end(name):
     g = Golden(f'e2e_{name}.npz')
     pkg = load_pkg()
@@ -126,7 +126,7 @@ def test_end_to_end(name):
     sd = pkg.synth.make_state_dict(shapes, meta['wseed'])
     chk = torch.stack([sum(v.double().sum() for v in sd.values()), sum(v.double().abs().sum() for v in sd.values())])
     torch.testing.assert_close(chk, g.t('weight_checksum'), rtol=1e-12, atol=0)
-    inp = pkg.synth.make_inputs(kw['D'], meta['T'], meta['vid_len'], meta['nq'], kw['text_in'], meta['lq'], meta['iseed'])
+    inp = pkg.synth.make_inputs(meta.get('feat_dim', kw['D']), meta['T'], meta['vid_len'], meta['nq'], kw['text_in'], meta['lq'], meta['iseed'])
     texts, tmasks = [], []
     for q, tok in enumerate(inp['tokens']):
         t, m = R.encode_text(sd, opt.model, tok[None], torch.ones(1, 1, tok.size(-1), dtype=torch.bool))
@@ -212,7 +212,7 @@ def test_nms_vs_compiled_reference_random():
             assert torch.equal(d1[:len(i1)], d2[:len(i2)])
 
 
-@pytest.mark.parametrize('name', ['late', 'second'])
+@pytest.mark.parametrize('name', ['late', 'second', 'late_scat'])
 def test_secondary_compositions(name):
     """PtTransformer (late fusion, model.py:30-161) and second_fusion=True (model.py:443-444) restatements"""
     g = Golden(f'e2e_{name}.npz')
@@ -220,7 +220,7 @@ def test_secondary_compositions(name):
     meta, kw = g.js('meta'), g.js('opt_kwargs')
     opt = pkg.config.make_opt(**kw)
     sd = pkg.synth.make_state_dict(g.js('shapes'), meta['wseed'])
-    inp = pkg.synth.make_inputs(kw['D'], meta['T'], meta['vid_len'], meta['nq'], kw['text_in'], meta['lq'], meta['iseed'])
+    inp = pkg.synth.make_inputs(meta.get('feat_dim', kw['D']), meta['T'], meta['vid_len'], meta['nq'], kw['text_in'], meta['lq'], meta['iseed'])
     texts, tmasks = zip(*[R.encode_text(sd, opt.model, t[None], torch.ones(1, 1, t.size(-1), dtype=torch.bool)) for t in inp['tokens']])
     if meta['cls'] == 'PtTransformer':
         out = R.forward_eval_late_fusion(sd, opt.model, inp['vid'], inp['shallow_vid'], inp['vid_masks'], list(texts), inp['text_cls'], list(tmasks))
