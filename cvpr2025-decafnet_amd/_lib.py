@@ -46,6 +46,7 @@ SIGNATURES = {
     'dcf_profile_enable': (i32, [i32]),
     'dcf_profile_report': (i64, [ctypes.c_char_p, i64]),
     'dcf_collect_segments': (i32, [c_f32p, c_f32p, c_u8p, i32, i64, i32, f32, i32, f32, c_f32p, c_f32p, c_i32p, vp]),
+    'dcf_collect_segments_ext': (i32, [c_f32p, c_f32p, c_u8p, c_f32p, i32, i64, i32, f32, i32, f32, c_f32p, c_f32p, c_i32p, vp]),
     'dcf_nms_1d': (i32, [c_f32p, c_f32p, c_i32p, i32, i32, i32, f32, c_i64p, c_i32p, vp]),
     'dcf_softnms_1d': (i32, [c_f32p, c_f32p, c_i32p, i32, i32, i32, f32, f32, f32, i32, i32, c_f32p, c_i64p, c_i32p, vp]),
     'dcf_segment_voting': (i32, [c_f32p, i32, c_i32p, i32, i32, c_f32p, c_f32p, c_i32p, i32, i32, f32, i32, c_f32p, vp]),

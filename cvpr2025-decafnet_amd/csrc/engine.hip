@@ -1247,10 +1247,18 @@ int64_t dcf_profile_report(char* buf, int64_t cap) {
 int dcf_collect_segments(const float* logits, const float* offsets, const uint8_t* masks, int32_t nq, int64_t T,
                          int32_t n_levels, float pre_nms_thresh, int32_t pre_nms_topk, float seg_len_thresh,
                          float* segs_out, float* scores_out, int32_t* counts_out, void* stream) {
+  return dcf_collect_segments_ext(logits, offsets, masks, nullptr, nq, T, n_levels, pre_nms_thresh, pre_nms_topk, seg_len_thresh,
+                                  segs_out, scores_out, counts_out, stream);
+}
+
+int dcf_collect_segments_ext(const float* logits, const float* offsets, const uint8_t* masks, const float* ext_scores,
+                             int32_t nq, int64_t T, int32_t n_levels, float pre_nms_thresh, int32_t pre_nms_topk,
+                             float seg_len_thresh, float* segs_out, float* scores_out, int32_t* counts_out, void* stream) {
   DCF_CHECK(logits && offsets && masks && segs_out && scores_out && counts_out, "dcf_collect_segments: null argument");
   DCF_CHECK(n_levels >= 1 && n_levels <= 16, "dcf_collect_segments: n_levels out of range");
   dcf::CollectArgs a{};
   a.logits = logits; a.offsets = offsets; a.masks = masks;
+  a.ext = ext_scores; a.T = (int)T;
   int acc = 0;
   for (int l = 0; l < n_levels; ++l) { a.off[l] = acc; acc += (int)(T >> l); }
   a.off[n_levels] = acc;

@@ -11,6 +11,8 @@ struct CollectArgs {
   const float* offsets;     // [nq][S][2]
   const uint8_t* masks;     // [nq][S]
   uint32_t* keys;           // [nq][S] scratch
+  const float* ext;         // [nq][T] external per-clip scores (worker_v2.py:1150-1156) or nullptr
+  int T;                    // level-0 length (row pitch of ext)
   int S, n_levels;
   int off[17];              // off[l] = first point of level l inside a query (off[n_levels] = S)
   float pre_nms_thresh, seg_len_thresh;

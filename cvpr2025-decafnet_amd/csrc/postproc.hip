@@ -90,10 +90,24 @@ __global__ __launch_bounds__(NT) void k_collect(CollectArgs p) {
   const uint8_t* mask = p.masks + (size_t)q * S;
   uint32_t* skey = p.keys + (size_t)q * S;
 
-  // (1) score = sigmoid(logit) * mask, keep > thresh
+  // (1) score = sigmoid(logit) [* ext] * mask, keep > thresh
+  // ext_scores are max-pooled (k3, s2, p1, -inf padding) once per level (worker_v2.py:1150-1156); a maximum of maxima is
+  // the maximum over the union of the windows, which for point j of level l is the level-0 range
+  // [j 2^l - (2^l - 1), j 2^l + (2^l - 1)] clipped to the video: read straight from the level-0 row, no pyramid buffer.
+  const float* ext = p.ext ? p.ext + (size_t)q * p.T : nullptr;
   int cnt = 0;
   for (int i = tid; i < S; i += NT) {
-    float s = sigmoidf_(logits[i]) * (mask[i] ? 1.f : 0.f);
+    float s = sigmoidf_(logits[i]);
+    if (ext) {
+      int l = 0;
+      while (l + 1 < p.n_levels && i >= p.off[l + 1]) ++l;
+      const int c = (i - p.off[l]) << l, h = (1 << l) - 1;
+      const int lo = max(c - h, 0), hi = min(c + h, p.T - 1);
+      float e = ext[lo];
+      for (int t = lo + 1; t <= hi; ++t) e = fmaxf(e, ext[t]);
+      s *= e;
+    }
+    s *= (mask[i] ? 1.f : 0.f);
     uint32_t k = (s > p.pre_nms_thresh) ? __float_as_uint(s) : 0u;   // positive floats order as uints
     skey[i] = k;
     cnt += k != 0;

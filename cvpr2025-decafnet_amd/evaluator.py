@@ -137,6 +137,9 @@ class GroundingEvaluator:
         shallow_window = F.pad(shallow, (0, T - vid_len))[None].to(dev, non_blocking=True)
         mask = (torch.arange(T, device=dev).view(1, -1) < vid_len)
         text_cls = data['text_cls'].to(dev, non_blocking=True)
+        # external per-clip scores (NQ, vid_len), zero-padded like the features (worker_v2.py:964-967,992-994)
+        ext = data.get('ext_scores') if isinstance(data, dict) else None
+        self._window_ext = None if ext is None else F.pad(ext.float(), (0, T - vid_len)).to(dev, non_blocking=True)
         self.time_dict['prepare'].append(time.perf_counter() - t0)
         t0 = time.perf_counter()
         out = model_(window, shallow_window, mask, tuple(texts), text_cls, tuple(tmasks), eval=True)
@@ -145,12 +148,13 @@ class GroundingEvaluator:
         return model_._last_flat, T
 
     @torch.no_grad()
-    def generate_proposals(self, flat, T, data=None):
-        """_collect_segments + batched_nms + seconds for every query; results as in worker_v2.py:1124."""
+    def generate_proposals(self, flat, T, data=None, window_ext=None):
+        """_collect_segments + batched_nms + seconds for every query; results as in worker_v2.py:1124.
+        ``window_ext``: padded external scores (NQ, T) on the device (worker_v2.py:1078-1081) or None."""
         logits, offsets, masks = flat
         t0 = time.perf_counter()
         segs, scores, counts = _nms.collect_segments(logits, offsets, masks, T, self.num_fpn_levels, self.pre_nms_thresh,
-                                                     self.pre_nms_topk, self.seg_len_thresh)
+                                                     self.pre_nms_topk, self.seg_len_thresh, ext_scores=window_ext)
         counts_h = counts.cpu()
         self.time_dict['post_process'].append(time.perf_counter() - t0)
         t0 = time.perf_counter()
@@ -168,7 +172,7 @@ class GroundingEvaluator:
 
     def predict(self, data):
         flat, T = self.forward(data)
-        return self.generate_proposals(flat, T, data)
+        return self.generate_proposals(flat, T, data, self._window_ext)
 
     def run(self, dataset, counter: RecallCounter = None, n_streams: int = 1):
         """Evaluator.run (worker_v2.py:815-910) over an iterable of per-video dicts (keys as in
@@ -184,9 +188,9 @@ class GroundingEvaluator:
         group = []
 
         def finish():
-            for stream, flat, T, data in group:
+            for stream, flat, T, data, ext in group:
                 with torch.cuda.stream(stream):
-                    res = self.generate_proposals(flat, T, data)
+                    res = self.generate_proposals(flat, T, data, ext)
                 counter.update(res, data['segment'])
             group.clear()
 
@@ -195,7 +199,7 @@ class GroundingEvaluator:
             stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(stream):
                 flat, T = self.forward(data, mdl)
-            group.append((stream, flat, T, data))
+            group.append((stream, flat, T, data, self._window_ext))
             if len(group) == n_streams:
                 finish()
         finish()

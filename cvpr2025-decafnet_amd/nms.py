@@ -176,17 +176,25 @@ def batched_nms(segs, scores, iou_thresh, min_score, max_num_segs, mode='soft_nm
     return nms_segs[idx[:k]].to(in_dev), nms_scores[idx[:k]].to(in_dev)
 
 
-def collect_segments(logits, offsets, masks, T, n_levels, pre_nms_thresh=0.001, pre_nms_topk=2000, seg_len_thresh=0.1):
+def collect_segments(logits, offsets, masks, T, n_levels, pre_nms_thresh=0.001, pre_nms_topk=2000, seg_len_thresh=0.1,
+                     ext_scores=None):
     """Evaluator._collect_segments for all queries: logits (nq,S), offsets (nq,S,2), masks (nq,S) on the GPU ->
-    segs (nq, topk, 2), scores (nq, topk), counts (nq) int32 (device; rows beyond counts[q] are undefined)."""
+    segs (nq, topk, 2), scores (nq, topk), counts (nq) int32 (device; rows beyond counts[q] are undefined).
+    ``ext_scores`` (nq, T) or (T,) are the optional external per-clip scores of worker_v2.py:964-967,1150-1156."""
     lib = _lib.lib()
     nq = logits.shape[0]
     dev = logits.device
+    ext = None
+    if ext_scores is not None:
+        ext = ext_scores.to(device=dev, dtype=torch.float32)
+        ext = (ext[None].expand(nq, -1) if ext.dim() == 1 else ext).contiguous()
+        assert ext.shape == (nq, T), (ext.shape, nq, T)
     segs = torch.empty(nq, pre_nms_topk, 2, dtype=torch.float32, device=dev)
     scores = torch.empty(nq, pre_nms_topk, dtype=torch.float32, device=dev)
     counts = torch.empty(nq, dtype=torch.int32, device=dev)
-    _lib.check(lib.dcf_collect_segments(_lib.ptr(logits.contiguous()), _lib.ptr(offsets.contiguous()),
-                                        _lib.ptr(masks.contiguous()), nq, T, n_levels, float(pre_nms_thresh),
-                                        int(pre_nms_topk), float(seg_len_thresh), _lib.ptr(segs), _lib.ptr(scores),
-                                        _lib.ptr(counts), _lib.current_stream()), 'dcf_collect_segments')
+    _lib.check(lib.dcf_collect_segments_ext(_lib.ptr(logits.contiguous()), _lib.ptr(offsets.contiguous()),
+                                            _lib.ptr(masks.contiguous()), _lib.ptr(ext) if ext is not None else None,
+                                            nq, T, n_levels, float(pre_nms_thresh),
+                                            int(pre_nms_topk), float(seg_len_thresh), _lib.ptr(segs), _lib.ptr(scores),
+                                            _lib.ptr(counts), _lib.current_stream()), 'dcf_collect_segments_ext')
     return segs, scores, counts

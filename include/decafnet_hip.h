@@ -134,6 +134,13 @@ int dcf_collect_segments(const float* logits, const float* offsets, const uint8_
                          int32_t n_levels, float pre_nms_thresh, int32_t pre_nms_topk, float seg_len_thresh,
                          float* segs_out, float* scores_out, int32_t* counts_out, void* stream);
 
+/* The same with the optional external per-clip scores of _collect_segments (worker_v2.py:1137,1150-1156):
+ * ext_scores (nq, T) fp32 device or NULL; they multiply sigmoid(logits) level by level after a k3/s2/p1 max-pool
+ * per level.  ABI version 3. */
+int dcf_collect_segments_ext(const float* logits, const float* offsets, const uint8_t* masks, const float* ext_scores,
+                             int32_t nq, int64_t T, int32_t n_levels, float pre_nms_thresh, int32_t pre_nms_topk,
+                             float seg_len_thresh, float* segs_out, float* scores_out, int32_t* counts_out, void* stream);
+
 /* --------------------------------------------------------------------------------------------
  * NMS: replaces the extension module nms_1d_cpu_vg (libs/nms/src/nms_cpu.cpp:184-194).
  * Batched over nq independent problems laid out with a fixed `stride` (entries) per problem;

@@ -559,14 +559,18 @@ def padded_length(vid_len: int, max_vid_len: int, num_fpn_levels: int, mha_win_s
 
 
 def collect_segments(fpn_points, fpn_logits, fpn_offsets, fpn_masks, pre_nms_thresh: float = 0.001,
-                     pre_nms_topk: int = 2000, seg_len_thresh: float = 0.1, stable: bool = True):
-    """Evaluator._collect_segments worker_v2.py:1131-1187 (ext_scores=None).
+                     pre_nms_topk: int = 2000, seg_len_thresh: float = 0.1, stable: bool = True, ext_scores=None):
+    """Evaluator._collect_segments worker_v2.py:1131-1187; ``ext_scores`` (T,) as worker_v2.py:1150-1156.
     ``stable=True`` pins the (reference-unspecified) argsort tie order to lowest index
     first, which is what the HIP path implements."""
     pts_l, sc_l, off_l = [], [], []
     for points, logits, offsets, masks in zip(fpn_points, fpn_logits, fpn_offsets, fpn_masks):
         logits, offsets, masks = logits[0], offsets[0], masks[0]
-        scores = torch.sigmoid(logits) * masks.float()
+        scores = torch.sigmoid(logits)
+        if ext_scores is not None:
+            scores = scores * ext_scores
+            ext_scores = F.max_pool1d(ext_scores[None, None], kernel_size=3, stride=2, padding=1)[0, 0]
+        scores = scores * masks.float()
         keep = scores > pre_nms_thresh
         pts_l.append(points[keep])
         sc_l.append(scores[keep])

@@ -398,6 +398,35 @@ def gen_postproc():
     save('postproc.npz', out)
 
 
+@torch.no_grad()
+def gen_postproc_ext():
+    """Evaluator._collect_segments with ext_scores (worker_v2.py:1150-1156): the external per-clip scores multiply the
+    level scores and are max-pooled (k3, s2, p1) down the pyramid."""
+    from libs.worker_v2 import Evaluator
+    from libs.modeling.model import PtGenerator
+    g = torch.Generator().manual_seed(177)
+    T0, L = 1024, 5
+    ev = Evaluator.__new__(Evaluator)
+    ev.pre_nms_topk, ev.pre_nms_thresh, ev.seg_len_thresh = 500, 0.001, 0.1
+    ev.vid_stride = 1
+    pts = PtGenerator(max_seq_len=T0, num_fpn_levels=L, regression_range=4, sigma=0.5)([T0 >> l for l in range(L)])
+    vid_len = 1000
+    logits, offsets, masks = [], [], []
+    for l in range(L):
+        n = T0 >> l
+        logits.append(torch.randn(1, n, generator=g) * 2.0 - 1.0)
+        offsets.append(torch.rand(1, n, 2, generator=g) * 6.0)
+        valid = (vid_len + (1 << l) - 1) >> l
+        masks.append((torch.arange(n) < valid).view(1, n))
+    ext = torch.rand(T0, generator=g)
+    ext[::5] = 0.0
+    segs, scores = ev._collect_segments(pts, [x.clone() for x in logits], offsets, masks, ext.clone())
+    out = dict(meta=dict(T0=T0, L=L, vid_len=vid_len, pre_nms_topk=500), ext=ext, segs=segs, scores=scores)
+    for l in range(L):
+        out[f'l{l}/logits'], out[f'l{l}/offsets'], out[f'l{l}/mask'] = logits[l], offsets[l], masks[l]
+    save('postproc_ext.npz', out)
+
+
 # ------------------------------------------------------------------ G5: NMS known answers
 @torch.no_grad()
 def gen_nms(ext):
@@ -465,5 +494,7 @@ if __name__ == '__main__':
         gen_e2e_variants()
     if 'postproc' in which:
         gen_postproc()
+    if 'postproc_ext' in which or 'postproc' in which:
+        gen_postproc_ext()
     if 'nms' in which:
         gen_nms(ext)

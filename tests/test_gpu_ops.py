@@ -353,3 +353,40 @@ def test_collect_multi_query_vs_oracle(L):
         assert n == len(wc)
         torch.testing.assert_close(scores[q, :n].cpu(), wc, rtol=1e-6, atol=1e-7)
         torch.testing.assert_close(segs[q, :n].cpu(), ws, rtol=1e-6, atol=1e-4)
+
+
+def test_collect_with_ext_scores(L):
+    """external per-clip scores, max-pooled down the pyramid (worker_v2.py:1150-1156): reference fixture at nq = 1 and the
+    oracle at nq = 3 with per-query rows"""
+    pkg, lib = L
+    g = Golden('postproc_ext.npz')
+    meta = g.js('meta')
+    Lv, T0 = meta['L'], meta['T0']
+    logits = torch.cat([g.t(f'l{l}/logits')[0] for l in range(Lv)])[None].cuda()
+    offsets = torch.cat([g.t(f'l{l}/offsets')[0] for l in range(Lv)])[None].cuda()
+    masks = torch.cat([g.t(f'l{l}/mask')[0] for l in range(Lv)])[None].cuda()
+    segs, scores, counts = pkg.nms.collect_segments(logits, offsets, masks, T0, Lv, pre_nms_topk=meta['pre_nms_topk'],
+                                                    ext_scores=g.t('ext').cuda())
+    n = int(counts[0])
+    assert n == len(g.t('scores'))
+    torch.testing.assert_close(scores[0, :n].cpu(), g.t('scores'), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(segs[0, :n].cpu(), g.t('segs'), rtol=1e-6, atol=1e-5)
+
+    gen = torch.Generator().manual_seed(19)
+    T0, Lv, nq = 2048, 7, 3
+    S = sum(T0 >> l for l in range(Lv))
+    logits = torch.randn(nq, S, generator=gen) * 2 - 1
+    offsets = torch.rand(nq, S, 2, generator=gen) * 5
+    masks = torch.ones(nq, S, dtype=torch.bool)
+    ext = torch.rand(nq, T0, generator=gen)
+    ext[:, ::3] = 0
+    pts = R.generate_points(T0, Lv, 4, 0.5)
+    sizes = [T0 >> l for l in range(Lv)]
+    segs, scores, counts = pkg.nms.collect_segments(logits.cuda(), offsets.cuda(), masks.cuda(), T0, Lv, ext_scores=ext.cuda())
+    for q in range(nq):
+        ws, wc = R.collect_segments(pts, [x[None] for x in logits[q].split(sizes)], [x[None] for x in offsets[q].split(sizes)],
+                                    [x[None] for x in masks[q].split(sizes)], ext_scores=ext[q])
+        n = int(counts[q])
+        assert n == len(wc)
+        torch.testing.assert_close(scores[q, :n].cpu(), wc, rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(segs[q, :n].cpu(), ws, rtol=1e-6, atol=1e-4)

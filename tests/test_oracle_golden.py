@@ -169,6 +169,18 @@ def test_postproc():
         close(sec, g.t(f'{k}/seconds'), atol=1e-4)
 
 
+def test_postproc_ext_scores():
+    """_collect_segments with external per-clip scores (worker_v2.py:1150-1156)"""
+    g = Golden('postproc_ext.npz')
+    meta = g.js('meta')
+    L, T0 = meta['L'], meta['T0']
+    pts = R.generate_points(T0, L, 4, 0.5)
+    segs, scores = R.collect_segments(pts, [g.t(f'l{l}/logits') for l in range(L)], [g.t(f'l{l}/offsets') for l in range(L)],
+                                      [g.t(f'l{l}/mask') for l in range(L)], pre_nms_topk=meta['pre_nms_topk'], ext_scores=g.t('ext'))
+    close(segs, g.t('segs'), atol=0, rtol=0)
+    close(scores, g.t('scores'), atol=0, rtol=0)
+
+
 # ------------------------------------------------------------------ G5
 def test_nms_known_answers():
     g = Golden('nms_kat.npz')
