@@ -192,11 +192,13 @@ def main():
         # dominant kernel = the dense-conv GEMM.  Default arithmetic: fp32-accurate bf16x6 operand split on
         # v_mfma_f32_32x32x16_bf16 (6 bf16 MFMA products per fp32 MAC) => fp32-equivalent peak = 2500 / 6 TFLOP/s;
         # with DCF_GEMM_MODE=fp32 the native fp32 MFMA (157.3 TFLOP/s) is used instead.
-        fam = 'gemm_bf16x6' if any(k.startswith('gemm_bf16x6') for k in prof) else \
-              ('gemm_bf16x3' if any(k.startswith('gemm_bf16x3') for k in prof) else 'gemm_f32')
+        # f16x3 (default): two fp16 planes per operand, 3 fp16 MFMA products per fp32 MAC => peak 2500 / 3 TFLOP/s; the two
+        # vid_map GEMMs on the raw features stay on bf16x6 and are listed under `stages`
+        fam = 'gemm_f16x3' if any(k.startswith('gemm_f16x3') for k in prof) else \
+              ('gemm_bf16x6' if any(k.startswith('gemm_bf16x6') for k in prof) else 'gemm_f32')
         gk = [k for k in prof if k.startswith(fam)]
         d = {f: sum(prof[k][f] for k in gk) for f in ('ms', 'flops', 'bytes', 'count')}
-        terms = {'gemm_bf16x6': 6, 'gemm_bf16x3': 3, 'gemm_f32': 0}[fam]
+        terms = {'gemm_bf16x6': 6, 'gemm_f16x3': 3, 'gemm_f32': 0}[fam]
         peak = PEAK_BF16_MFMA_TFLOPS / terms if terms else PEAK_F32_MFMA_TFLOPS
         ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
         result['roofline'] = {
@@ -205,7 +207,7 @@ def main():
             'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
             'launches': d['count'], 'avg_launch_us': 1e3 * d['ms'] / d['count'],
             'alg_flops_per_launch': d['flops'] / d['count'],
-            'peak_note': ('bf16 dense MFMA peak 2500 TFLOP/s / %d bf16 products per fp32 multiply-add (fp32-accurate operand split)' % terms)
+            'peak_note': ('fp16 / bf16 dense MFMA peak 2500 TFLOP/s / %d 16-bit MFMA products per fp32 multiply-add (fp32-accurate operand split)' % terms)
                          if terms else 'native fp32 MFMA dense peak',
             'frac_of_native_f32_mfma_peak': ach / PEAK_F32_MFMA_TFLOPS,
             'note': 'HIP events around every launch of this kernel, same K steps re-run right after the timed region; '
@@ -215,7 +217,7 @@ def main():
         # figure comes from the committed summary of tools/pmc_traffic.sh (same command, same build); null if absent
         try:
             with open(os.path.join(ROOT, 'profiles', 'r01_pmc_gemm_traffic.json')) as fh:
-                pmc = json.load(fh).get('gemm_bf16s' if terms else 'gemm_f32')
+                pmc = json.load(fh).get({6: 'gemm_bf16s', 3: 'gemm_f16x3', 0: 'gemm_f32'}[terms])
             if pmc:
                 result['roofline']['traffic'] = pmc['hbm_bytes_per_launch']
                 result['roofline']['traffic_note'] = ('bytes per launch, FETCH_SIZE x2 + WRITE_SIZE from two rocprofv3 --pmc passes '
@@ -223,7 +225,7 @@ def main():
                                                       'operand bytes per launch: %.3e' % (d['bytes'] / d['count']))
         except (OSError, ValueError, KeyError):
             pass
-        result['config']['gemm_mode'] = {6: 'bf16x6 split MFMA (fp32 accurate)', 3: 'bf16x3 split MFMA', 0: 'native fp32 MFMA'}[terms]
+        result['config']['gemm_mode'] = {6: 'bf16x6 split MFMA (fp32 accurate)', 3: 'f16x3 split MFMA (fp32 accurate)', 0: 'native fp32 MFMA'}[terms]
         xa = prof.get('xattn_core')
         if xa:
             result['xattn_in_forward'] = {'bound': 'hbm', 'achieved': xa['bytes'] / (xa['ms'] * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS,

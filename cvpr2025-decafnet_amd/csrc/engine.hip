@@ -147,7 +147,10 @@ struct dcf_model {
   std::vector<float*> owned;                 // packed weights
   std::unordered_map<const float*, const unsigned short*> wsplit;   // fp32 weight -> [3][N][K] bf16 planes
   std::unordered_map<const float*, int64_t> wsplit_ldw;             // row pitch of the fp32 weight the planes were made from
-  int gemm_terms = 6;                        // 6 / 3: bf16-split MFMA GEMM; 0: fp32 MFMA
+  std::unordered_map<const float*, int> wsplit_terms;               // mode the image of a weight was made for (16 / 6)
+  int gemm_terms = 16;                       // 16: f16x3 split MFMA GEMM (default); 6: bf16x6; 0: native fp32 MFMA
+  bool force_x6 = false;                     // a weight did not fit the scaled fp16 range: the model runs bf16x6
+  unsigned* status = nullptr;                // device words: [0] sticky numerics flag of the f16x3 GEMMs, [1] weight range flag
   bool finalized = false;
   const float* pe = nullptr;
   int64_t pe_T = 0;
@@ -211,10 +214,13 @@ static void drop_graph(dcf_model* m) {
 
 static int free_model(dcf_model* m) {
   drop_graph(m);
+  if (m->status) (void)hipFree(m->status);
+  m->status = nullptr;
   for (float* p : m->owned) (void)hipFree(p);
   m->owned.clear();
   m->wsplit.clear();
   m->wsplit_ldw.clear();
+  m->wsplit_terms.clear();
   for (auto& pl : m->plans) if (pl.d_lt) (void)hipFree(pl.d_lt);
   m->plans.clear();
   if (m->arena) (void)hipFree(m->arena);
@@ -253,14 +259,16 @@ static int pack3(dcf_model* m, const float* src, int d0, int d1, int d2, int p0,
 }
 
 // bf16 planes of a GEMM weight [N][K] (row pitch K); owned by the model
-static int split_weight(dcf_model* m, const float* W, int N, int K, hipStream_t st, int64_t ldw = 0) {
+static int split_weight(dcf_model* m, const float* W, int N, int K, hipStream_t st, int64_t ldw = 0, int terms = 0) {
   if (m->gemm_terms == 0 || m->wsplit.count(W)) return 0;
+  if (!terms) terms = m->gemm_terms;
   unsigned short* planes = nullptr;
   DCF_HIP(hipMalloc(&planes, (size_t)3 * N * K * sizeof(unsigned short)));
   m->owned.push_back(reinterpret_cast<float*>(planes));
-  if (launch_split_planes(W, planes, N, K, ldw ? ldw : K, st)) return -1;
+  if (launch_split_planes(W, planes, N, K, ldw ? ldw : K, st, terms, m->status ? m->status + 1 : nullptr)) return -1;
   m->wsplit[W] = planes;
   m->wsplit_ldw[W] = ldw ? ldw : K;
+  m->wsplit_terms[W] = terms;
   return 0;
 }
 #define SPLIT(W, N, K) do { if (split_weight(m, (W), (N), (K), st)) return -1; } while (0)
@@ -327,10 +335,16 @@ static int finalize(dcf_model* m, hipStream_t st) {
   m->owned.clear();
   m->wsplit.clear();
   m->wsplit_ldw.clear();
+  m->wsplit_terms.clear();
   {
     const int gm = c.gemm_mode;
-    m->gemm_terms = gm == 1 ? 0 : (gm == 3 ? 3 : 6);
-    if (const char* ev = getenv("DCF_GEMM_MODE")) m->gemm_terms = !strcmp(ev, "fp32") ? 0 : (!strcmp(ev, "x3") ? 3 : 6);
+    DCF_CHECK(gm == 0 || gm == 1 || gm == 6 || gm == 16, "gemm_mode %d: use 0 / 16 (f16x3), 6 (bf16x6) or 1 (fp32); the bf16x3 mode was replaced by f16x3", gm);
+    m->gemm_terms = gm == 1 ? 0 : (gm == 6 ? GEMM_BF16X6 : GEMM_F16X3);
+    if (const char* ev = getenv("DCF_GEMM_MODE"))
+      m->gemm_terms = !strcmp(ev, "fp32") ? 0 : (!strcmp(ev, "x6") || !strcmp(ev, "bf16x6") ? GEMM_BF16X6 : GEMM_F16X3);
+    if (m->force_x6 && m->gemm_terms == GEMM_F16X3) m->gemm_terms = GEMM_BF16X6;
+    if (!m->status) DCF_HIP(hipMalloc(&m->status, 2 * sizeof(unsigned)));
+    DCF_HIP(hipMemsetAsync(m->status, 0, 2 * sizeof(unsigned), st));
   }
   m->dec.clear(); m->stem.clear(); m->branch.clear();
   m->embd_conv.clear(); m->embd_ln_w.clear(); m->embd_ln_b.clear();
@@ -388,9 +402,11 @@ static int finalize(dcf_model* m, hipStream_t st) {
     m->vid_w1 = blk[0]; m->vid_w2 = blk[1]; m->vid_w3 = blk[2];
     m->vid_ldw = D;
   }
+  // these two GEMMs read the raw feature files, whose range the model does not control: always the three-plane bf16
+  // split (fp32 exponent range); everything downstream is bounded by LayerNorms and runs in the configured mode
   if (D % 32 == 0 && E % 32 == 0) {
-    if (m->vid_w1 && split_weight(m, m->vid_w1, E, D, st, m->vid_ldw)) return -1;
-    if (m->vid_w2 && split_weight(m, m->vid_w2, E, D, st, m->vid_ldw)) return -1;
+    if (m->vid_w1 && split_weight(m, m->vid_w1, E, D, st, m->vid_ldw, GEMM_BF16X6)) return -1;
+    if (m->vid_w2 && split_weight(m, m->vid_w2, E, D, st, m->vid_ldw, GEMM_BF16X6)) return -1;
   }
   for (int i = 0; i < c.fusion_layers; ++i) {
     const std::string p = "fusion.layers." + std::to_string(i);
@@ -472,6 +488,16 @@ static int finalize(dcf_model* m, hipStream_t st) {
   for (auto& pl : m->plans) if (pl.d_lt) (void)hipFree(pl.d_lt);
   m->plans.clear();                           // reg scales live in the level tables
   drop_graph(m);
+  if (m->gemm_terms == GEMM_F16X3) {
+    // did every weight fit the scaled fp16 range (|w| < 255.9)?  If not, rebuild the images for bf16x6.
+    unsigned flags[2] = {0u, 0u};
+    DCF_HIP(hipMemcpyAsync(flags, m->status, sizeof(flags), hipMemcpyDeviceToHost, st));
+    DCF_HIP(hipStreamSynchronize(st));
+    if (flags[1]) {
+      m->force_x6 = true;
+      return finalize(m, st);
+    }
+  }
   m->finalized = true;
   return 0;
 }
@@ -592,13 +618,18 @@ static int join_side(dcf_model* m, int which, hipStream_t st) {
 // dense GEMM dispatch: bf16-split MFMA when the weight has split planes, fp32 MFMA otherwise
 static int run_gemm(dcf_model* m, GemmArgs* g, int count, GemmAMode mode, hipStream_t st) {
   bool split = m->gemm_terms != 0;
+  int terms = 0;
   for (int i = 0; i < count && split; ++i) {
     auto it = m->wsplit.find(g[i].W);
-    if (it == m->wsplit.end() || (g[i].ldw ? g[i].ldw : g[i].K) != m->wsplit_ldw[g[i].W]) split = false;
-    else g[i].Ws = it->second;
+    if (it == m->wsplit.end() || (g[i].ldw ? g[i].ldw : g[i].K) != m->wsplit_ldw[g[i].W]) { split = false; break; }
+    const int t = m->wsplit_terms[g[i].W];
+    if (terms && t != terms) { split = false; break; }
+    terms = t;
+    g[i].Ws = it->second;
+    g[i].status = m->status;
   }
   if (split && mode == A_CHANMAJOR && (g[0].N % 128 != 0 || g[0].M % 4 != 0)) split = false;
-  return split ? launch_gemm_split(g, count, mode, m->gemm_terms, st) : launch_gemm(g, count, mode, st);
+  return split ? launch_gemm_split(g, count, mode, terms, st) : launch_gemm(g, count, mode, st);
 }
 
 // can this GEMM carry its LayerNorm in the epilogue?  (bf16-split path with planes for W, tile spanning the row)
@@ -1157,6 +1188,21 @@ int dcf_model_finalize(dcf_model* m, void* stream) {
   return dcf::finalize(m, (hipStream_t)stream);
 }
 
+int dcf_numerics_status(dcf_model* m, int32_t reset, void* stream) {
+  DCF_CHECK(m, "dcf_numerics_status: null model");
+  int out = m->gemm_terms == dcf::GEMM_BF16X6 ? 4 : (m->gemm_terms == 0 ? 8 : 0);
+  if (m->force_x6) out |= 2;
+  if (m->status) {
+    unsigned flag = 0u;
+    hipStream_t st = (hipStream_t)stream;
+    DCF_HIP(hipMemcpyAsync(&flag, m->status, sizeof(flag), hipMemcpyDeviceToHost, st));
+    if (reset) DCF_HIP(hipMemsetAsync(m->status, 0, sizeof(unsigned), st));
+    DCF_HIP(hipStreamSynchronize(st));
+    if (flag) out |= 1;
+  }
+  return out;
+}
+
 int64_t dcf_points_per_query(const dcf_model* m, int64_t T) {
   int64_t s = 0;
   for (int l = 0; l < m->cfg.n_levels; ++l) s += T >> l;
@@ -1312,7 +1358,7 @@ int dcf_op_linear_split(const float* A, const float* W, const float* bias, float
   hipStream_t st = (hipStream_t)stream;
   unsigned short* planes = nullptr;
   DCF_HIP(hipMallocAsync((void**)&planes, (size_t)3 * N * K * sizeof(unsigned short), st));
-  int rc = dcf::launch_split_planes(W, planes, N, K, K, st);
+  int rc = dcf::launch_split_planes(W, planes, N, K, K, st, nterms);
   if (rc == 0) {
     dcf::GemmArgs g = dcf::gemm(A, K, W, bias, C, N, M, N, K);
     g.Ws = planes;
@@ -1335,7 +1381,7 @@ int dcf_op_linear_ln(const float* A, const float* W, const float* bias, const fl
   DCF_CHECK(dcf::gemm_can_fuse_ln(M, N, K, dcf::A_ROWS), "dcf_op_linear_ln: %dx%dx%d cannot carry a fused LayerNorm (N = 256, M >= 28672)", M, N, K);
   unsigned short* planes = nullptr;
   DCF_HIP(hipMallocAsync((void**)&planes, (size_t)3 * N * K * sizeof(unsigned short), st));
-  int rc = dcf::launch_split_planes(W, planes, N, K, K, st);
+  int rc = dcf::launch_split_planes(W, planes, N, K, K, st, nterms);
   if (rc == 0) {
     dcf::GemmArgs g = dcf::gemm(A, K, W, bias, C, N, M, N, K);
     g.Ws = planes;
@@ -1351,7 +1397,7 @@ int dcf_op_linear_cm_split(const float* A_cm, const float* W, const float* bias,
   hipStream_t st = (hipStream_t)stream;
   unsigned short* planes = nullptr;
   DCF_HIP(hipMallocAsync((void**)&planes, (size_t)3 * N * K * sizeof(unsigned short), st));
-  int rc = dcf::launch_split_planes(W, planes, N, K, K, st);
+  int rc = dcf::launch_split_planes(W, planes, N, K, K, st, nterms);
   if (rc == 0) {
     dcf::GemmArgs g = dcf::gemm(A_cm, M, W, bias, C, N, M, N, K);
     g.Ws = planes;

@@ -49,14 +49,21 @@ struct GemmArgs {
   const float* ln_pe;      // optional (ln_T, N) position encoding added where ln_mask != 0
   const uint8_t* ln_mask;  // [M] (with ln_pe)
   int ln_T;
+  // f16x3 mode: sticky device word, bit 0 is set when an accumulator leaves the finite range (an operand overflowed the
+  // fp16 range, or the inputs already held inf / NaN); nullptr = not reported
+  unsigned* status;
 };
 
 // Launch up to 3 independent GEMMs of identical (M, N, K, mode) in one grid (blockIdx.z).
 int launch_gemm(const GemmArgs* g, int count, GemmAMode mode, hipStream_t stream);
 
-// fp32-accurate GEMM on the bf16 matrix cores by operand splitting (gemm_bf16s.hip); nterms = 6 or 3
+// fp32-accurate GEMM on the 16-bit matrix cores by operand splitting (gemm_bf16s.hip); nterms = 16 (f16x3: two fp16
+// planes, 3 products) or 6 (bf16x6: three bf16 planes, 6 products).  The weight image must have been made for the same mode.
+constexpr int GEMM_F16X3 = 16, GEMM_BF16X6 = 6;
 int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, hipStream_t stream);
-int launch_split_planes(const float* W, unsigned short* out, int N, int K, int64_t ldw, hipStream_t st);
+// overflow: optional device word, bit 0 set if a weight does not fit the scaled fp16 range (f16x3 only)
+int launch_split_planes(const float* W, unsigned short* out, int N, int K, int64_t ldw, hipStream_t st, int nterms = GEMM_BF16X6,
+                        unsigned* overflow = nullptr);
 // true if launch_gemm_split can run g with its LayerNorm fused (one tile spans all N columns and the grid still
 // fills the chip); otherwise the caller launches the LayerNorm kernel itself
 bool gemm_can_fuse_ln(int M, int N, int K, GemmAMode mode);

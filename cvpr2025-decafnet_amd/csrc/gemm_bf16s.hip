@@ -1,4 +1,4 @@
-// fp32-accurate GEMM on the bf16 matrix cores by operand splitting ("bf16x6").
+// fp32-accurate GEMM on the 16-bit matrix cores by operand splitting: "f16x3" (default, see below) and "bf16x6".
 //
 // Every fp32 operand x is written exactly as hi + mid + lo with three bf16 values (8 significant
 // bits each).  A product a*b is then the sum of 9 bf16 x bf16 products, each EXACT in fp32; the six
@@ -9,8 +9,8 @@
 //
 // Why: the fp32 MFMA (v_mfma_f32_32x32x2_f32) retires 2 k per 64 cycles = 32 cycles per k-step of a
 // 32x32 tile; the bf16 MFMA retires 16 k per 32 cycles, six of them 12 cycles per k -- 2.67x the rate
-// (fp32-equivalent peak 2.5 PFLOP/s / 6 = 417 TFLOP/s against 157).  NTERMS = 3 (hh, hm, mh; error
-// ~2^-16 per product) is kept as an opt-in mode.
+// (fp32-equivalent peak 2.5 PFLOP/s / 6 = 417 TFLOP/s against 157).  (A two-plane bf16 mode -- hh, hm, mh, error
+// ~2^-16 per product -- existed until the fp16 two-plane mode below replaced it: same MFMA count, 15x the accuracy.)
 //
 // Weights are split once at model finalisation ([3][N][K] bf16 planes); activations are split while
 // they are staged global -> LDS (v_cvt_pk_bf16_f32, ~6 VALU ops per element, hidden under the MFMAs).
@@ -30,9 +30,27 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
 constexpr int SBK = 32;            // k per LDS tile
 constexpr int ROWB = 80;           // bytes per (plane, row): 64 data + 16 pad
 
+// ---- "f16x3": the same idea on the fp16 matrix cores with TWO planes per operand -------------------------------
+// fp16 carries 11 significant bits, so x = hi + lo with two fp16 values holds 22 bits and the three products
+// hh, hl, lh (each exact in fp32) carry a*b down to ~2^-22 |ab|: measured against fp64 the result has the error of a plain
+// fp32 FMA chain (rms 2.9e-7 at K = 256, 3.4e-7 at K = 1024, both for the native fp32 path and for this one; bf16x3 is
+// 4.4e-6) at HALF the MFMA work of bf16x6 and 2/3 of its operand bytes.  What fp16 lacks is exponent range, so operands
+// are pre-scaled by exact powers of two -- activations by 2^4, weights by 2^8 -- and the accumulators un-scaled by 2^-12
+// in the epilogue: |a| < 4094 and |w| < 255.9 convert without overflow, the low planes stay normal fp16 numbers for
+// |a| >= 2^-7 / |w| >= 2^-11, and below that the absolute representation error is <= 2^-29 / 2^-33 (an fp32 ulp of 1.0
+// is 2^-23).  Out-of-range operands give inf/NaN accumulators: the epilogue raises the sticky status word the caller
+// passes in GemmArgs::status instead of letting a later ReLU / max swallow them.  Weights are range-checked once when
+// they are split (the model falls back to bf16x6 if they do not fit).
+constexpr int T_F16 = 16;          // `nterms` code of this mode (6 and 3 are the bf16 modes)
+constexpr float F16_SA = 16.f, F16_SW = 256.f, F16_UNSCALE = 1.f / 4096.f;
+
+// fp16 mode: hi = fp16(s x), "mid" = fp16(s x - hi); lo unused
 // split two floats into packed bf16 pairs: hi, mid, lo (round to nearest even at every level)
 __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
   bf16x2 h = __builtin_convertvector(f32x2{x0, x1}, bf16x2);
@@ -45,19 +63,61 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
   lo = __builtin_bit_cast(unsigned, l);
 }
 
+__device__ __forceinline__ void split2_f16(float x0, float x1, float s, unsigned& hi, unsigned& mid) {
+  const f16x2 h = __builtin_convertvector(f32x2{x0 * s, x1 * s}, f16x2);          // v_cvt_pk_f16_f32 (RTNE)
+  hi = __builtin_bit_cast(unsigned, h);
+  const float r0 = __builtin_fmaf(x0, s, -(float)h[0]), r1 = __builtin_fmaf(x1, s, -(float)h[1]);   // exact residuals
+  mid = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, f16x2));
+}
+// the A operand split of mode NTERMS
+template <int NTERMS>
+__device__ __forceinline__ void split_a(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+  if constexpr (NTERMS == T_F16) { split2_f16(x0, x1, F16_SA, hi, mid); lo = 0u; }
+  else split2(x0, x1, hi, mid, lo);
+}
+template <int NTERMS>
+__device__ __forceinline__ f32x16 mma(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (NTERMS == T_F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// f16 mode: un-scale a finished accumulator fragment and raise the status word on a non-finite value
+template <int NTERMS>
+__device__ __forceinline__ void finish_acc(f32x16& acc, bool& bad) {
+  if constexpr (NTERMS == T_F16) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float v = acc[e] * F16_UNSCALE;
+      bad |= !(__builtin_fabsf(v) <= 3.4028234664e38f);
+      acc[e] = v;
+    }
+  }
+}
+
 // Weight image = MFMA B fragments in the order the kernel consumes them.  One 6 KiB block per (32 output
 // rows n32, 32-wide K tile kt), blocks ordered [n32][kt]; inside a block
 //   [16-wide K chunk c = 0,1][plane][lane = h * 32 + r][8 bf16]  =  W[n32*32 + r][kt*32 + c*16 + h*8 .. +7]
 // so ONE fully coalesced 1 KiB wave load (global_load_dwordx4) delivers the bf16x8 B operand of every lane
 // for one (chunk, plane).  W never touches LDS: staging the 60 KiB W tile per K step through ds_write_b128
 // (~79 B/clk/CU) was the co-bottleneck of the first version of this kernel (MFMA busy 25 %).
-__global__ void k_split_planes(const float* __restrict__ W, unsigned short* __restrict__ out, int N, int K, int64_t ldw) {
+template <bool F16>
+__global__ void k_split_planes(const float* __restrict__ W, unsigned short* __restrict__ out, int N, int K, int64_t ldw,
+                               unsigned* __restrict__ overflow) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // pair index
   const int64_t pairs = (int64_t)N * K / 2;
   if (i >= pairs) return;
   const int n = (int)(i / (K / 2)), k = (int)(i % (K / 2)) * 2;
-  unsigned hi, mid, lo;
-  split2(W[n * ldw + k], W[n * ldw + k + 1], hi, mid, lo);
+  unsigned hi, mid, lo = 0u;
+  const float w0 = W[n * ldw + k], w1 = W[n * ldw + k + 1];
+  if constexpr (F16) {
+    split2_f16(w0, w1, F16_SW, hi, mid);
+    if (!(__builtin_fabsf(w0) * F16_SW <= 65504.f) || !(__builtin_fabsf(w1) * F16_SW <= 65504.f)) {
+      if (overflow) atomicOr(overflow, 1u);
+    }
+  } else {
+    split2(w0, w1, hi, mid, lo);
+  }
   const int64_t blk = (int64_t)(n >> 5) * (K >> 5) + (k >> 5);
   const int kk = k & 31, c = kk >> 4, h = (kk >> 3) & 1, j = kk & 7, r = n & 31;
   const int64_t o = blk * (2 * 3 * 64 * 8) + ((int64_t)(c * 3) * 64 + h * 32 + r) * 8 + j;
@@ -66,10 +126,14 @@ __global__ void k_split_planes(const float* __restrict__ W, unsigned short* __re
   *reinterpret_cast<unsigned*>(out + o + 2 * 64 * 8) = lo;
 }
 
-int launch_split_planes(const float* W, unsigned short* out, int N, int K, int64_t ldw, hipStream_t st) {
+int launch_split_planes(const float* W, unsigned short* out, int N, int K, int64_t ldw, hipStream_t st, int nterms,
+                        unsigned* overflow) {
   DCF_CHECK(K % 32 == 0 && N % 32 == 0, "split_planes: N and K must be multiples of 32");
   const int64_t pairs = (int64_t)N * K / 2;
-  hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, W, out, N, K, ldw);
+  if (nterms == T_F16)
+    hipLaunchKernelGGL(k_split_planes<true>, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, W, out, N, K, ldw, overflow);
+  else
+    hipLaunchKernelGGL(k_split_planes<false>, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, W, out, N, K, ldw, overflow);
   DCF_HIP(hipGetLastError());
   return 0;
 }
@@ -82,7 +146,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4) ? 2 : 3)) 
   constexpr int NT = WM * WN * 64;                    // 4 or 8 wavefronts
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
-  constexpr int NPL = NTERMS == 6 ? 3 : 2;            // planes used: hi, mid (, lo)
+  constexpr int NPL = NTERMS == 6 ? 3 : 2;            // planes used: hi, mid (, lo); T_F16: the two fp16 planes
   constexpr int ACH = (BM * 4 + NT - 1) / NT;         // 8-float chunks of the A tile per thread (the last may be partial)
   constexpr bool APART = (BM * 4) % NT != 0;          // 3-wave workgroups: chunk ids >= BM * 4 do not exist
   constexpr int BLK = 2 * 3 * 64 * 8;                 // bf16 elements of one weight block (6 KiB)
@@ -166,7 +230,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4) ? 2 : 3)) 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           unsigned hi, mid, lo;
-          split2(araw[i][0][e], araw[i][1][e], hi, mid, lo);
+          split_a<NTERMS>(araw[i][0][e], araw[i][1][e], hi, mid, lo);
           const int row = m4 * 4 + e;
           *reinterpret_cast<unsigned*>(As + (0 * BM + row) * ROWB + pk * 4) = hi;
           *reinterpret_cast<unsigned*>(As + (1 * BM + row) * ROWB + pk * 4) = mid;
@@ -176,10 +240,10 @@ __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4) ? 2 : 3)) 
         if (APART && id >= BM * 4) continue;
         const int row = id >> 2, c8 = id & 3;
         unsigned h0, h1, h2, h3, m0_, m1, m2, m3, l0, l1, l2, l3;
-        split2(araw[i][0].x, araw[i][0].y, h0, m0_, l0);
-        split2(araw[i][0].z, araw[i][0].w, h1, m1, l1);
-        split2(araw[i][1].x, araw[i][1].y, h2, m2, l2);
-        split2(araw[i][1].z, araw[i][1].w, h3, m3, l3);
+        split_a<NTERMS>(araw[i][0].x, araw[i][0].y, h0, m0_, l0);
+        split_a<NTERMS>(araw[i][0].z, araw[i][0].w, h1, m1, l1);
+        split_a<NTERMS>(araw[i][1].x, araw[i][1].y, h2, m2, l2);
+        split_a<NTERMS>(araw[i][1].z, araw[i][1].w, h3, m3, l3);
         const u32x4 hi = {h0, h1, h2, h3}, mid = {m0_, m1, m2, m3}, lo = {l0, l1, l2, l3};
         *reinterpret_cast<u32x4*>(As + (0 * BM + row) * ROWB + c8 * 16) = hi;
         *reinterpret_cast<u32x4*>(As + (1 * BM + row) * ROWB + c8 * 16) = mid;
@@ -236,16 +300,24 @@ __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4) ? 2 : 3)) 
         for (int i = 0; i < TM; ++i) {
           // smallest terms first
           if constexpr (NTERMS == 6) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bc[c][j][1], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bc[c][j][2], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], bc[c][j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = mma<NTERMS>(a[i][1], bc[c][j][1], acc[i][j]);
+            acc[i][j] = mma<NTERMS>(a[i][0], bc[c][j][2], acc[i][j]);
+            acc[i][j] = mma<NTERMS>(a[i][2], bc[c][j][0], acc[i][j]);
           }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bc[c][j][1], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bc[c][j][0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bc[c][j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = mma<NTERMS>(a[i][0], bc[c][j][1], acc[i][j]);
+          acc[i][j] = mma<NTERMS>(a[i][1], bc[c][j][0], acc[i][j]);
+          acc[i][j] = mma<NTERMS>(a[i][0], bc[c][j][0], acc[i][j]);
         }
       }
     }
+  }
+  if constexpr (NTERMS == T_F16) {
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) finish_acc<NTERMS>(acc[i][j], bad);
+    if (bad && p.status) atomicOr(p.status, 1u);
   }
   if constexpr (LN) {                                   // tile spans the whole output row (n0 = 0)
     __syncthreads();                                    // the A tile is dead: its LDS becomes the row-statistics scratch
@@ -338,10 +410,10 @@ __global__ __launch_bounds__(KS * 64) void gemm_bf16s_kslice_kernel(GemmBatch ba
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         unsigned h0, h1, h2, h3, m0_, m1, m2, m3, l0, l1, l2, l3;
-        split2(araw[i][c][0].x, araw[i][c][0].y, h0, m0_, l0);
-        split2(araw[i][c][0].z, araw[i][c][0].w, h1, m1, l1);
-        split2(araw[i][c][1].x, araw[i][c][1].y, h2, m2, l2);
-        split2(araw[i][c][1].z, araw[i][c][1].w, h3, m3, l3);
+        split_a<NTERMS>(araw[i][c][0].x, araw[i][c][0].y, h0, m0_, l0);
+        split_a<NTERMS>(araw[i][c][0].z, araw[i][c][0].w, h1, m1, l1);
+        split_a<NTERMS>(araw[i][c][1].x, araw[i][c][1].y, h2, m2, l2);
+        split_a<NTERMS>(araw[i][c][1].z, araw[i][c][1].w, h3, m3, l3);
         a[i][c][0] = __builtin_bit_cast(bf16x8, (u32x4){h0, h1, h2, h3});
         a[i][c][1] = __builtin_bit_cast(bf16x8, (u32x4){m0_, m1, m2, m3});
         if constexpr (NPL == 3) a[i][c][2] = __builtin_bit_cast(bf16x8, (u32x4){l0, l1, l2, l3});
@@ -361,13 +433,13 @@ __global__ __launch_bounds__(KS * 64) void gemm_bf16s_kslice_kernel(GemmBatch ba
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           if constexpr (NTERMS == 6) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][c][1], bc[c][j][1], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][c][0], bc[c][j][2], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][c][2], bc[c][j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = mma<NTERMS>(a[i][c][1], bc[c][j][1], acc[i][j]);
+            acc[i][j] = mma<NTERMS>(a[i][c][0], bc[c][j][2], acc[i][j]);
+            acc[i][j] = mma<NTERMS>(a[i][c][2], bc[c][j][0], acc[i][j]);
           }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][c][0], bc[c][j][1], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][c][1], bc[c][j][0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][c][0], bc[c][j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = mma<NTERMS>(a[i][c][0], bc[c][j][1], acc[i][j]);
+          acc[i][j] = mma<NTERMS>(a[i][c][1], bc[c][j][0], acc[i][j]);
+          acc[i][j] = mma<NTERMS>(a[i][c][0], bc[c][j][0], acc[i][j]);
         }
   }
 
@@ -404,6 +476,11 @@ __global__ __launch_bounds__(KS * 64) void gemm_bf16s_kslice_kernel(GemmBatch ba
       }
     }
   }
+  if constexpr (NTERMS == T_F16) {
+    bool bad = false;
+    finish_acc<NTERMS>(fin[0][0], bad);
+    if (bad && p.status) atomicOr(p.status, 1u);
+  }
   gemm_epilogue<TM, 2, 1, 1>(p, fin, m0, n0, wave >> 1, wave & 1, r, h);
 }
 
@@ -414,8 +491,9 @@ static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterm
   dim3 grid(tile_grid<BM, BN>(p), 1, count);
   char name[96];
   static const bool shapes = getenv("DCF_PROF_SHAPES") != nullptr;   // per-shape labels for tools/ (not used by bench.py)
-  if (shapes) snprintf(name, sizeof(name), "gemm_bf16x%d<%dx%d,%s>[%dx%dx%dx%d]", nterms, BM, BN, mode == A_ROWS ? "rows" : mode == A_ROWS_TAP3 ? "tap3" : "chanmajor", count, p.M, p.N, p.K);
-  else snprintf(name, sizeof(name), "gemm_bf16x%d<%dx%d,%s>", nterms, BM, BN, mode == A_ROWS ? "rows" : mode == A_ROWS_TAP3 ? "tap3" : "chanmajor");
+  const char* fam = nterms == 6 ? "gemm_bf16x6" : "gemm_f16x3";
+  if (shapes) snprintf(name, sizeof(name), "%s<%dx%d,%s>[%dx%dx%dx%d]", fam, BM, BN, mode == A_ROWS ? "rows" : mode == A_ROWS_TAP3 ? "tap3" : "chanmajor", count, p.M, p.N, p.K);
+  else snprintf(name, sizeof(name), "%s<%dx%d,%s>", fam, BM, BN, mode == A_ROWS ? "rows" : mode == A_ROWS_TAP3 ? "tap3" : "chanmajor");
   const double mnk = (double)count * p.M * (double)p.N * p.K;
   ProfScope prof(name, stream, 2.0 * mnk,
                  4.0 * count * ((double)p.M * p.K / (mode == A_ROWS_TAP3 ? 3 : 1) + 1.5 * (double)p.N * p.K + (double)p.M * p.N * ((p.flags & G_RES) ? 2 : 1)));
@@ -432,17 +510,17 @@ static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterm
   if (p.ln_w) {
     if constexpr (WM == 1 && TM == 2 && TN >= 2) {
       DCF_CHECK(mode != A_CHANMAJOR && count == 1, "launch_gemm_split: fused LayerNorm: unsupported mode");
-      if (mode == A_ROWS) { if (nterms == 6) LSN(A_ROWS, 6); else LSN(A_ROWS, 3); }
-      else { if (nterms == 6) LSN(A_ROWS_TAP3, 6); else LSN(A_ROWS_TAP3, 3); }
+      if (mode == A_ROWS) { if (nterms == 6) LSN(A_ROWS, 6); else LSN(A_ROWS, T_F16); }
+      else { if (nterms == 6) LSN(A_ROWS_TAP3, 6); else LSN(A_ROWS_TAP3, T_F16); }
     } else {
       DCF_CHECK(false, "launch_gemm_split: fused LayerNorm is not built for this tile");
     }
   } else
-  if (mode == A_ROWS) { if (nterms == 6) LS(A_ROWS, 6); else LS(A_ROWS, 3); }
-  else if (mode == A_ROWS_TAP3) { if (nterms == 6) LS(A_ROWS_TAP3, 6); else LS(A_ROWS_TAP3, 3); }
+  if (mode == A_ROWS) { if (nterms == 6) LS(A_ROWS, 6); else LS(A_ROWS, T_F16); }
+  else if (mode == A_ROWS_TAP3) { if (nterms == 6) LS(A_ROWS_TAP3, 6); else LS(A_ROWS_TAP3, T_F16); }
   else {
     // channel-major A is only instantiated for the 64-row tiles the vid_map shapes use
-    if constexpr (WM == 1 && WN == 4 && TM == 2) { if (nterms == 6) LS(A_CHANMAJOR, 6); else LS(A_CHANMAJOR, 3); }
+    if constexpr (WM == 1 && WN == 4 && TM == 2) { if (nterms == 6) LS(A_CHANMAJOR, 6); else LS(A_CHANMAJOR, T_F16); }
     else DCF_CHECK(false, "launch_gemm_split: channel-major A needs a 64-row tile");
   }
 #undef LS
@@ -460,16 +538,17 @@ static int launch_kslice(const GemmBatch& b, int count, int nterms, hipStream_t 
   dim3 grid(small ? tile_grid<32, 64>(p) : tile_grid<64, 64>(p), 1, count);
   char name[96];
   static const bool shapes = getenv("DCF_PROF_SHAPES") != nullptr;
-  if (shapes) snprintf(name, sizeof(name), "gemm_bf16x%d<%dx64,kslice>[%dx%dx%dx%d]", nterms, small ? 32 : 64, count, p.M, p.N, p.K);
-  else snprintf(name, sizeof(name), "gemm_bf16x%d<64x64,kslice>", nterms);
+  const char* fam = nterms == 6 ? "gemm_bf16x6" : "gemm_f16x3";
+  if (shapes) snprintf(name, sizeof(name), "%s<%dx64,kslice>[%dx%dx%dx%d]", fam, small ? 32 : 64, count, p.M, p.N, p.K);
+  else snprintf(name, sizeof(name), "%s<64x64,kslice>", fam);
   const double mnk = (double)count * p.M * (double)p.N * p.K;
   ProfScope prof(name, stream, 2.0 * mnk, 4.0 * count * ((double)p.M * p.K + 1.5 * (double)p.N * p.K + (double)p.M * p.N * ((p.flags & G_RES) ? 2 : 1)));
   if (small) {   // (eight K slices for K = 1024 on these tiles measured the same as four: 2.34 vs 2.35 ms per step)
     if (nterms == 6) hipLaunchKernelGGL((gemm_bf16s_kslice_kernel<6, 1>), grid, dim3(256), 0, stream, b);
-    else hipLaunchKernelGGL((gemm_bf16s_kslice_kernel<3, 1>), grid, dim3(256), 0, stream, b);
+    else hipLaunchKernelGGL((gemm_bf16s_kslice_kernel<T_F16, 1>), grid, dim3(256), 0, stream, b);
   } else {
     if (nterms == 6) hipLaunchKernelGGL((gemm_bf16s_kslice_kernel<6, 2>), grid, dim3(256), 0, stream, b);
-    else hipLaunchKernelGGL((gemm_bf16s_kslice_kernel<3, 2>), grid, dim3(256), 0, stream, b);
+    else hipLaunchKernelGGL((gemm_bf16s_kslice_kernel<T_F16, 2>), grid, dim3(256), 0, stream, b);
   }
   DCF_HIP(hipGetLastError());
   return 0;
@@ -487,7 +566,7 @@ bool gemm_can_fuse_ln(int M, int N, int K, GemmAMode mode) {
 // same contract as launch_gemm; every g[i].Ws must hold the pre-tiled bf16 planes of g[i].W (launch_split_planes)
 int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, hipStream_t stream) {
   DCF_CHECK(count >= 1 && count <= 3, "launch_gemm_split: count %d out of range", count);
-  DCF_CHECK(nterms == 3 || nterms == 6, "launch_gemm_split: nterms must be 3 or 6");
+  DCF_CHECK(nterms == T_F16 || nterms == 6, "launch_gemm_split: nterms must be 16 (f16x3) or 6 (bf16x6)");
   GemmBatch b;
   for (int i = 0; i < 3; ++i) b.g[i] = g[i < count ? i : 0];
   static const bool narrow = getenv("DCF_NARROW_EPILOGUE") != nullptr;

@@ -337,6 +337,9 @@ def _encode_text(model, tokens, token_masks):
     return out, out_mask
 
 
+GEMM_MODES = {'f16x3': 16, 'bf16x6': 6, 'fp32': 1}
+
+
 class PtTransformerEarlyFusionIterative(nn.Module):
     """Drop-in for libs/modeling/model.py:397-565 (created by libs/worker_v2.py:182-211).
 
@@ -382,9 +385,9 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         self.second_fusion = second_fusion
         self.head_layers = ch.get('n_layers', 2)
         self.max_batch = int(mo.get('max_batch', 0) or 0)
-        # dense-conv arithmetic (extension key opt.model.gemm_mode): 'bf16x6' (default, fp32 accurate),
-        # 'fp32' (native fp32 MFMA) or 'bf16x3'
-        self.gemm_mode = {'bf16x6': 6, 'fp32': 1, 'bf16x3': 3}[mo.get('gemm_mode', 'bf16x6')]
+        # dense-conv arithmetic (extension key opt.model.gemm_mode), all fp32 accurate: 'f16x3' (default: two fp16 planes
+        # per operand on the fp16 matrix cores), 'bf16x6' (three bf16 planes) or 'fp32' (native fp32 MFMA)
+        self.gemm_mode = GEMM_MODES[mo.get('gemm_mode', 'f16x3')]
         self._engine = None
         # Serving option (off by default: the reference returns fresh tensors every call).  When True the three flat
         # output buffers are reused between calls of the same shape, which lets the engine replay one captured HIP
@@ -402,6 +405,16 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         if not eval:
             raise NotImplementedError('only the eval forward (eval=True) is implemented; training is out of scope')
         return self._drop_forward_eval(vid, shallow_vid, vid_masks, text, text_cls, text_masks, text_size, mv_data, eval)
+
+    def numerics_status(self, reset=False):
+        """dcf_numerics_status of the engine (blocking): bit 0 = a GEMM of the f16x3 mode produced a non-finite value since
+        the last reset (an activation beyond |a| < 4094): re-run with opt.model.gemm_mode = 'bf16x6'."""
+        if self._engine is None:
+            return 0
+        rc = self._engine.lib.dcf_numerics_status(self._engine.handle, int(bool(reset)), _lib.current_stream())
+        if rc < 0:
+            _lib.check(rc, 'dcf_numerics_status')
+        return rc
 
     def replica(self):
         """A second handle on the SAME parameters with its own engine (workspace, repacked weights, HIP graph): run it on
@@ -554,7 +567,7 @@ class PtTransformer(PtTransformerEarlyFusionIterative):
         self.second_fusion = False
         self.head_layers = ch.get('n_layers', 2)
         self.max_batch = int(mo.get('max_batch', 0) or 0)
-        self.gemm_mode = {'bf16x6': 6, 'fp32': 1, 'bf16x3': 3}[mo.get('gemm_mode', 'bf16x6')]
+        self.gemm_mode = GEMM_MODES[mo.get('gemm_mode', 'f16x3')]
         self._engine = None
         self.reuse_output_buffers = False
         self._out_cache = {}

@@ -46,8 +46,9 @@ typedef struct dcf_config {
   int32_t norm;           /* opt.model.norm                                                        */
   int32_t use_abs_pe;     /* opt.model.vid_net.use_abs_pe                                          */
   int32_t max_batch;      /* queries processed together (>= 1); 0 = library default                */
-  int32_t gemm_mode;      /* dense-conv arithmetic: 0/6 = fp32-accurate bf16x6 split MFMA (default),
-                           * 1 = native fp32 MFMA, 3 = bf16x3 split (~2^-16 per product)           */
+  int32_t gemm_mode;      /* dense-conv arithmetic, all fp32-accurate: 0/16 = f16x3 (two fp16 planes per operand,
+                           * 3 MFMA products, default), 6 = bf16x6 (three bf16 planes, 6 products),
+                           * 1 = native fp32 MFMA                                                   */
   int32_t model_kind;     /* 0 = PtTransformerEarlyFusionIterative (libs/modeling/model.py:397),
                            * 1 = PtTransformer, late fusion (model.py:30)                            */
   int32_t second_fusion;  /* model_kind 0: also fuse every pyramid level before the heads (model.py:443) */
@@ -73,6 +74,13 @@ void dcf_model_destroy(dcf_model* m);
  * text_net.* tensors feed dcf_text_encode (ignored when cfg.text_in == 0).
  * Replaces nn.Module.load_state_dict(ckpt['model_ema']) (libs/worker_v2.py:806-812). */
 int dcf_model_bind(dcf_model* m, const char* name, const float* data, const int64_t* shape, int32_t ndim);
+
+/* Numerics status of the f16x3 GEMMs (blocking: synchronises `stream`).  Returns a bit set, or -1 on error:
+ *   1 = some GEMM accumulator left the finite range since the last reset (an activation beyond the fp16 operand range
+ *       |a| < 4094 of the f16x3 mode, or inf/NaN in the inputs): outputs since then are not trustworthy -- re-run with
+ *       gemm_mode = 6;   2 = a weight did not fit (|w| >= 255.9) and the model fell back to bf16x6 at finalize;
+ *   4 = the model runs bf16x6;  8 = the model runs the native fp32 MFMA path.   reset != 0 clears bit 1's source. */
+int dcf_numerics_status(dcf_model* m, int32_t reset, void* stream);
 
 /* Absolute position encoding buffer `vid_net.pe` (non-persistent in the reference,
  * libs/modeling/video_net.py:75-78): token-major (T, E) fp32 already resampled for length T

@@ -70,12 +70,12 @@ def test_linear(L, M, N, K, act):
     torch.testing.assert_close(C.cpu().double(), ref, rtol=1e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize('nterms,tol', [(6, 2e-5), (3, 3e-4)])
+@pytest.mark.parametrize('nterms,tol', [(6, 2e-5), (16, 2e-5)])
 @pytest.mark.parametrize('M,N,K,act', [(64, 256, 256, 0), (1000, 256, 1024, 1), (333, 1024, 256, 0), (77, 288, 864, 2),
                                          (50, 160, 128, 0), (200, 96, 64, 0), (129, 64, 32, 0), (65, 32, 32, 0), (4096, 512, 256, 0),
                                          (65600, 256, 256, 1), (32704, 288, 96, 0), (20000, 256, 128, 2)])   # 128x256 / 128x96 / 64x256 tiles
 def test_linear_bf16_split(L, M, N, K, act, nterms, tol):
-    """fp32-accurate GEMM on the bf16 matrix cores (operand splitting, gemm_bf16s.hip) vs fp64"""
+    """fp32-accurate GEMM on the 16-bit matrix cores (operand splitting, gemm_bf16s.hip: 6 = bf16x6, 16 = f16x3) vs fp64"""
     pkg, lib = L
     g = torch.Generator().manual_seed(M * 5 + N + nterms)
     A = torch.randn(M, K, generator=g) * 3
@@ -89,7 +89,7 @@ def test_linear_bf16_split(L, M, N, K, act, nterms, tol):
     C = torch.empty(M, N, device='cuda')
     pkg._lib.check(lib.dcf_op_linear_split(P(A.cuda()), P(W.cuda()), P(b.cuda()), P(C), M, N, K, act, nterms, st()))
     torch.testing.assert_close(C.cpu().double(), ref, rtol=tol, atol=tol)
-    if nterms == 6:     # not worse than the native fp32 MFMA GEMM
+    if True:            # not worse than the native fp32 MFMA GEMM
         C32 = torch.empty(M, N, device='cuda')
         pkg._lib.check(lib.dcf_op_linear(P(A.cuda()), P(W.cuda()), P(b.cuda()), P(C32), M, N, K, act, st()))
         e6 = (C.cpu().double() - ref).abs().max()
@@ -120,7 +120,7 @@ def test_linear_with_fused_layernorm(L, M, K, relu, raw):
         torch.testing.assert_close(C.cpu().double(), v, rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize('nterms,tol', [(6, 2e-5), (3, 3e-4)])
+@pytest.mark.parametrize('nterms,tol', [(6, 2e-5), (16, 2e-5)])
 @pytest.mark.parametrize('M,N,K', [(256, 256, 512), (1000, 128, 64), (4096, 256, 1024), (16384, 256, 96), (20, 128, 32)])
 def test_linear_channel_major_split(L, M, N, K, nterms, tol):
     """channel-major A on the bf16-split path (vid_map): transposed LDS staging of packed (k, k+1) pairs"""
