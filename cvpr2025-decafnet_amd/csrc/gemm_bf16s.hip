@@ -18,6 +18,7 @@
 // ds_read_b128 group covers 64 distinct banks).  Lane (r = lane & 31, h = lane >> 5) reads the 8
 // consecutive k values 8h..8h+7 of row r of a 16-wide chunk with one ds_read_b128 per plane.
 #include <cstdio>
+#include <type_traits>
 #include <cstdlib>
 
 #include "gemm_common.h"
@@ -141,8 +142,12 @@ int launch_split_planes(const float* W, unsigned short* out, int N, int K, int64
 // 3 waves per SIMD (<= 168 registers): measured 3.16 -> 3.00 ms per step over the compiler's default of 2
 // LN = true: the variant with the fused LayerNorm epilogue (its own kernel so that the extra scalars and the
 // statistics registers do not cost the plain kernel its third wave per SIMD)
-template <int WM, int WN, int TM, int TN, int AMODE, int NTERMS, bool LN = false>
-__global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4) ? 2 : 3)) void gemm_bf16s_kernel(GemmBatch batch) {
+// NST = depth of the register pipeline: the global loads of K tile kt + NST - 1 (A raw fp32, B fragments) are issued
+// during step kt.  One K step is only 12 (64x32 wave tile, f16x3) .. 48 MFMAs = 400 .. 1500 cycles while an L2 /
+// Infinity Cache hit takes ~1000 and HBM ~2000+, and at T = 16384 most grids give one wave per SIMD, so nothing but
+// the prefetch distance hides that latency.  Buffers are indexed statically (steps unrolled in groups of NST).
+template <int WM, int WN, int TM, int TN, int AMODE, int NTERMS, bool LN = false, int NST = 3>
+__global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4 || (NST > 2 && TM * TN >= 4)) ? 2 : 3)) void gemm_bf16s_kernel(GemmBatch batch) {
   constexpr int NT = WM * WN * 64;                    // 4 or 8 wavefronts
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
@@ -196,8 +201,8 @@ __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4) ? 2 : 3)) 
   for (int j = 0; j < TN; ++j)
     w_ptr[j] = reinterpret_cast<const bf16x8*>(p.Ws + ((int64_t)(n0 / 32 + wn * TN + j) * KT) * BLK) + lane;
 
-  f32x4 araw[ACH][2];
-  auto load_a = [&](int kt) __attribute__((always_inline)) {
+  f32x4 araw_[NST][ACH][2];
+  auto load_a = [&](int kt, f32x4 (&araw)[ACH][2]) __attribute__((always_inline)) {
     const int k0 = kt * SBK;
     int64_t shift = k0;
     unsigned bit = 1u;
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4) ? 2 : 3)) 
       araw[i][1] = v1;
     }
   };
-  auto store_a = [&]() __attribute__((always_inline)) {
+  auto store_a = [&](const f32x4 (&araw)[ACH][2]) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
       const int id = i * NT + tid;
@@ -252,8 +257,8 @@ __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4) ? 2 : 3)) 
     }
   };
   // B fragments of one K tile: [chunk][tile][plane]
-  bf16x8 bfr[2][TN][NPL];
-  auto load_b = [&](int kt) __attribute__((always_inline)) {
+  bf16x8 bfr_[NST][2][TN][NPL];
+  auto load_b = [&](int kt, bf16x8 (&bfr)[2][TN][NPL]) __attribute__((always_inline)) {
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -270,22 +275,17 @@ __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4) ? 2 : 3)) 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  load_a(0);
-  load_b(0);
-  for (int kt = 0; kt < KT; ++kt) {
+  // one K step: tile kt is in stage S of the register buffers; stage (S + NST - 1) % NST (consumed by step kt - 1) takes
+  // the loads of tile kt + NST - 1 (clamped to the last tile: a redundant load instead of a branch)
+  auto step = [&](int kt, auto stage) __attribute__((always_inline)) {
+    constexpr int S = decltype(stage)::value;
+    constexpr int SN = (S + NST - 1) % NST;
     __syncthreads();                    // every wave finished reading As (tile kt-1)
-    store_a();
+    store_a(araw_[S]);
     __syncthreads();
-    load_a(kt + 1 < KT ? kt + 1 : kt);
-    // the B fragments of tile kt are in registers; copy them so the next tile's loads can be issued now
-    bf16x8 bc[2][TN][NPL];
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) bc[c][j][pl] = bfr[c][j][pl];
-    load_b(kt + 1 < KT ? kt + 1 : kt);
+    const int kn = kt + NST - 1 < KT ? kt + NST - 1 : KT - 1;
+    load_a(kn, araw_[SN]);
+    load_b(kn, bfr_[SN]);
 #pragma unroll
     for (int c = 0; c < SBK / 16; ++c) {
       bf16x8 a[TM][NPL];
@@ -300,17 +300,37 @@ __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4) ? 2 : 3)) 
         for (int i = 0; i < TM; ++i) {
           // smallest terms first
           if constexpr (NTERMS == 6) {
-            acc[i][j] = mma<NTERMS>(a[i][1], bc[c][j][1], acc[i][j]);
-            acc[i][j] = mma<NTERMS>(a[i][0], bc[c][j][2], acc[i][j]);
-            acc[i][j] = mma<NTERMS>(a[i][2], bc[c][j][0], acc[i][j]);
+            acc[i][j] = mma<NTERMS>(a[i][1], bfr_[S][c][j][1], acc[i][j]);
+            acc[i][j] = mma<NTERMS>(a[i][0], bfr_[S][c][j][2], acc[i][j]);
+            acc[i][j] = mma<NTERMS>(a[i][2], bfr_[S][c][j][0], acc[i][j]);
           }
-          acc[i][j] = mma<NTERMS>(a[i][0], bc[c][j][1], acc[i][j]);
-          acc[i][j] = mma<NTERMS>(a[i][1], bc[c][j][0], acc[i][j]);
-          acc[i][j] = mma<NTERMS>(a[i][0], bc[c][j][0], acc[i][j]);
+          acc[i][j] = mma<NTERMS>(a[i][0], bfr_[S][c][j][1], acc[i][j]);
+          acc[i][j] = mma<NTERMS>(a[i][1], bfr_[S][c][j][0], acc[i][j]);
+          acc[i][j] = mma<NTERMS>(a[i][0], bfr_[S][c][j][0], acc[i][j]);
         }
       }
     }
+  };
+  auto group = [&](int kt, int count) __attribute__((always_inline)) {   // count == NST in the main loop
+    if constexpr (NST >= 1) { if (count > 0) step(kt + 0, std::integral_constant<int, 0>{}); }
+    if constexpr (NST >= 2) { if (count > 1) step(kt + 1, std::integral_constant<int, 1 % NST>{}); }
+    if constexpr (NST >= 3) { if (count > 2) step(kt + 2, std::integral_constant<int, 2 % NST>{}); }
+    if constexpr (NST >= 4) { if (count > 3) step(kt + 3, std::integral_constant<int, 3 % NST>{}); }
+  };
+#pragma unroll
+  for (int s_ = 0; s_ < NST - 1; ++s_) {
+    const int k_ = s_ < KT ? s_ : KT - 1;
+    load_a(k_, araw_[s_]);
+    load_b(k_, bfr_[s_]);
   }
+  int kt = 0;
+  for (; kt + NST <= KT; kt += NST) {
+    step(kt + 0, std::integral_constant<int, 0>{});
+    if constexpr (NST >= 2) step(kt + 1, std::integral_constant<int, 1 % NST>{});
+    if constexpr (NST >= 3) step(kt + 2, std::integral_constant<int, 2 % NST>{});
+    if constexpr (NST >= 4) step(kt + 3, std::integral_constant<int, 3 % NST>{});
+  }
+  group(kt, KT - kt);                   // the last KT % NST tiles
   if constexpr (NTERMS == T_F16) {
     bool bad = false;
 #pragma unroll
@@ -505,8 +525,19 @@ static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterm
     const size_t need = ((size_t)WN * BM * LN_PITCH + BM) * sizeof(float);
     if (need > lds) lds = need;
   }
-#define LS(MODE_, NT_) hipLaunchKernelGGL((gemm_bf16s_kernel<WM, WN, TM, TN, MODE_, NT_>), grid, dim3(WM * WN * 64), lds, stream, b)
-#define LSN(MODE_, NT_) hipLaunchKernelGGL((gemm_bf16s_kernel<WM, WN, TM, TN, MODE_, NT_, true>), grid, dim3(WM * WN * 64), lds, stream, b)
+  // register pipeline depth: the small wave tiles of the f16x3 mode (64x32 / 32x32 per wave) keep a third stage of A / B
+  // registers at 3 waves per SIMD; measured per step of one video (tools/nst_sweep.sh): 64x128 tiles 0.220 / 0.210 /
+  // 0.220 ms and 64x64 tiles 0.056 / 0.051 / 0.055 ms at depth 2 / 3 / 4; the 64x64-per-wave tiles lose their third
+  // wave at depth 3 (227 registers) and run 0.217 -> 0.222 ms, larger tiles spill (tools/kernel_resources.py).
+  constexpr bool DEEP = TM * TN <= 2 && WM * TM <= 2;
+#define LSK(MODE_, NT_, LN_) do { \
+    if constexpr (NT_ == T_F16 && DEEP) \
+      hipLaunchKernelGGL((gemm_bf16s_kernel<WM, WN, TM, TN, MODE_, NT_, LN_, 3>), grid, dim3(WM * WN * 64), lds, stream, b); \
+    else \
+      hipLaunchKernelGGL((gemm_bf16s_kernel<WM, WN, TM, TN, MODE_, NT_, LN_, 2>), grid, dim3(WM * WN * 64), lds, stream, b); \
+  } while (0)
+#define LS(MODE_, NT_) LSK(MODE_, NT_, false)
+#define LSN(MODE_, NT_) LSK(MODE_, NT_, true)
   if (p.ln_w) {
     if constexpr (WM == 1 && TM == 2 && TN >= 2) {
       DCF_CHECK(mode != A_CHANMAJOR && count == 1, "launch_gemm_split: fused LayerNorm: unsupported mode");
@@ -525,6 +556,7 @@ static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterm
   }
 #undef LS
 #undef LSN
+#undef LSK
   DCF_HIP(hipGetLastError());
   return 0;
 }

@@ -1,4 +1,4 @@
-"""Run one GEMM shape repeatedly (for rocprofv3 --pmc).  usage: gemm_one.py MODE M N K [reps]   MODE = f32|x6|x3"""
+"""Run one GEMM shape repeatedly (for rocprofv3 --pmc).  usage: gemm_one.py MODE M N K [reps]   MODE = f32|x6|f16"""
 import ctypes, importlib, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +14,7 @@ P = lambda t: ctypes.c_void_p(t.data_ptr())
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 import time, json
 for _ in range(3):
-    lib.dcf_op_linear_split(P(A), P(W), P(b), P(C), M, N, K, act, 6, st) if mode != 'f32' else lib.dcf_op_linear(P(A), P(W), P(b), P(C), M, N, K, act, st)
+    lib.dcf_op_linear_split(P(A), P(W), P(b), P(C), M, N, K, act, 6 if mode == 'x6' else 16, st) if mode != 'f32' else lib.dcf_op_linear(P(A), P(W), P(b), P(C), M, N, K, act, st)
 torch.cuda.synchronize()
 lib.dcf_profile_enable(1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -23,7 +23,7 @@ for _ in range(reps):
     if mode == 'f32':
         lib.dcf_op_linear(P(A), P(W), P(b), P(C), M, N, K, act, st)
     else:
-        lib.dcf_op_linear_split(P(A), P(W), P(b), P(C), M, N, K, act, 6 if mode == 'x6' else 3, st)
+        lib.dcf_op_linear_split(P(A), P(W), P(b), P(C), M, N, K, act, 6 if mode == 'x6' else 16, st)
 torch.cuda.synchronize()
 e1.record(); torch.cuda.synchronize()
 print(mode, M, N, K, 'us/launch (incl. weight split for x6/x3):', round(e0.elapsed_time(e1) * 1e3 / reps, 1))
