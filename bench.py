@@ -156,6 +156,9 @@ def main():
         tt = torch.tensor([elapsed], device='cpu' if args.debug_gloo_one_gpu else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # the f16x3 GEMMs flag any accumulator that left the finite range (operands beyond the fp16 range): must be clean
+    for mk in [model] + [o[0] for o in others]:
+        assert mk.numerics_status() & 1 == 0, 'f16x3 GEMM range overflow flagged: the timed outputs are not valid'
     n_videos = 1 + len(others)
     clips_per_step = n_videos * vid_len * args.nq
     value = world * clips_per_step * args.steps / elapsed

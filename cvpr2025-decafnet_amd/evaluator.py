@@ -181,6 +181,7 @@ class GroundingEvaluator:
         if n_streams <= 1:
             for data in dataset:
                 counter.update(self.predict(data), data['segment'])
+            self._check_numerics([self.model])
             return counter
         # throughput mode: n_streams videos in flight, one model replica (shared parameters, own workspace) and one HIP
         # stream each; the decode / NMS of a video (host syncs on its own stream only) overlaps the forwards of the others
@@ -204,4 +205,13 @@ class GroundingEvaluator:
                 finish()
         finish()
         torch.cuda.synchronize()
+        self._check_numerics([m for m, _ in lanes])
         return counter
+
+    @staticmethod
+    def _check_numerics(models):
+        """the f16x3 GEMM mode flags operands beyond the fp16 range (|a| >= 4094) instead of passing inf / NaN on"""
+        for m in models:
+            if hasattr(m, 'numerics_status') and m.numerics_status(reset=True) & 1:
+                raise RuntimeError("an activation left the fp16 operand range of the f16x3 GEMM mode: results are not valid; "
+                                   "set opt.model.gemm_mode = 'bf16x6'")
