@@ -5,13 +5,22 @@ import csv, json, sys
 csv.field_size_limit(1 << 30)
 
 
+def family(name):
+    """gemm_f16x3 / gemm_bf16s (= bf16x6) by the NTERMS template argument of the split kernels, gemm_f32 for the native one"""
+    import re
+    m = re.search(r'gemm_bf16s_kernel<\s*\d+,\s*\d+,\s*\d+,\s*\d+,\s*\d+,\s*(\d+)', name) or re.search(r'gemm_bf16s_kslice_kernel<\s*(\d+)', name)
+    if m:
+        return 'gemm_f16x3' if m.group(1) == '16' else 'gemm_bf16s'
+    return 'gemm_f32' if 'gemm_f32' in name else None
+
+
 def collect(path, counter):
     per = {}
     for r in csv.DictReader(open(path)):
         if r['Counter_Name'] != counter:
             continue
         n = r['Kernel_Name']
-        fam = 'gemm_bf16s' if 'gemm_bf16s' in n else ('gemm_f32' if 'gemm_f32' in n else None)
+        fam = family(n)
         if fam is None:
             continue
         d = per.setdefault(fam, {'launches': 0, 'kib': 0.0})
@@ -30,6 +39,6 @@ for fam in f:
                 'write_bytes_per_launch': write, 'hbm_bytes_per_launch': fetch + write}
 out['note'] = ('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 3 --warmup 2 '
                '--no-cpu-baseline --no-post`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per '
-               '128-B request); counters in KiB; averages over every launch of the kernel family (gemm_bf16s = tile kernel + '
-               'k-sliced kernel)')
+               '128-B request); counters in KiB; averages over every launch of the kernel family (tile kernel + k-sliced kernel; gemm_f16x3 = the '
+               'default two-plane fp16 mode, gemm_bf16s = the bf16x6 instantiations, here the two vid_map products)')
 print(json.dumps(out, indent=1))
