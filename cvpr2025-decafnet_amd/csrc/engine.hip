@@ -402,11 +402,13 @@ static int finalize(dcf_model* m, hipStream_t st) {
     m->vid_w1 = blk[0]; m->vid_w2 = blk[1]; m->vid_w3 = blk[2];
     m->vid_ldw = D;
   }
-  // these two GEMMs read the raw feature files, whose range the model does not control: always the three-plane bf16
-  // split (fp32 exponent range); everything downstream is bounded by LayerNorms and runs in the configured mode
+  // these two GEMMs read the raw feature files, whose range the model does not control; everything downstream is
+  // bounded by LayerNorms.  In f16x3 mode they run without the activation pre-scale (|x| < 65504 instead of 4094; an
+  // absolute representation floor of 2^-25 on the features); DCF_VIDMAP_X6=1 keeps them on the three-plane bf16 split.
+  static const bool vidmap_x6 = getenv("DCF_VIDMAP_X6") != nullptr;
   if (D % 32 == 0 && E % 32 == 0) {
-    if (m->vid_w1 && split_weight(m, m->vid_w1, E, D, st, m->vid_ldw, GEMM_BF16X6)) return -1;
-    if (m->vid_w2 && split_weight(m, m->vid_w2, E, D, st, m->vid_ldw, GEMM_BF16X6)) return -1;
+    if (m->vid_w1 && split_weight(m, m->vid_w1, E, D, st, m->vid_ldw, vidmap_x6 ? GEMM_BF16X6 : 0)) return -1;
+    if (m->vid_w2 && split_weight(m, m->vid_w2, E, D, st, m->vid_ldw, vidmap_x6 ? GEMM_BF16X6 : 0)) return -1;
   }
   for (int i = 0; i < c.fusion_layers; ++i) {
     const std::string p = "fusion.layers." + std::to_string(i);
@@ -866,7 +868,7 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
     int ng = 0;
     if (m->vid_w1) g[ng++] = gemm(vid, T0, m->vid_w1, nullptr, b.P1, E, T0, E, D);
     if (m->vid_w2) g[ng++] = gemm(shallow, T0, m->vid_w2, nullptr, b.P2, E, T0, E, D);
-    for (int i = 0; i < ng; ++i) g[i].ldw = m->vid_ldw;
+    for (int i = 0; i < ng; ++i) { g[i].ldw = m->vid_ldw; g[i].a_scale = 1.f; }
     TRY(run_gemm(m, g, ng, A_CHANMAJOR, st));
     if (forked) TRY(join_side(m, 0, st));
   }

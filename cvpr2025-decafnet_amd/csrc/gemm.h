@@ -52,6 +52,9 @@ struct GemmArgs {
   // f16x3 mode: sticky device word, bit 0 is set when an accumulator leaves the finite range (an operand overflowed the
   // fp16 range, or the inputs already held inf / NaN); nullptr = not reported
   unsigned* status;
+  // f16x3 mode: power-of-two pre-scale of the A operand (0 = default 2^4: |a| < 4094, small values exact down to 2^-7);
+  // 1 widens the range to |a| < 65504 at an absolute representation floor of 2^-25
+  float a_scale;
 };
 
 // Launch up to 3 independent GEMMs of identical (M, N, K, mode) in one grid (blockIdx.z).

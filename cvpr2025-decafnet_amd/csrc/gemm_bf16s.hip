@@ -42,7 +42,8 @@ constexpr int ROWB = 80;           // bytes per (plane, row): 64 data + 16 pad
 // hh, hl, lh (each exact in fp32) carry a*b down to ~2^-22 |ab|: measured against fp64 the result has the error of a plain
 // fp32 FMA chain (rms 2.9e-7 at K = 256, 3.4e-7 at K = 1024, both for the native fp32 path and for this one; bf16x3 is
 // 4.4e-6) at HALF the MFMA work of bf16x6 and 2/3 of its operand bytes.  What fp16 lacks is exponent range, so operands
-// are pre-scaled by exact powers of two -- activations by 2^4, weights by 2^8 -- and the accumulators un-scaled by 2^-12
+// are pre-scaled by exact powers of two -- activations by 2^4 (GemmArgs::a_scale overrides: the vid_map GEMMs on the raw
+// feature files use 1, i.e. |a| < 65504), weights by 2^8 -- and the accumulators un-scaled by 2^-12
 // in the epilogue: |a| < 4094 and |w| < 255.9 convert without overflow, the low planes stay normal fp16 numbers for
 // |a| >= 2^-7 / |w| >= 2^-11, and below that the absolute representation error is <= 2^-29 / 2^-33 (an fp32 ulp of 1.0
 // is 2^-23).  Out-of-range operands give inf/NaN accumulators: the epilogue raises the sticky status word the caller
@@ -72,10 +73,12 @@ __device__ __forceinline__ void split2_f16(float x0, float x1, float s, unsigned
 }
 // the A operand split of mode NTERMS
 template <int NTERMS>
-__device__ __forceinline__ void split_a(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
-  if constexpr (NTERMS == T_F16) { split2_f16(x0, x1, F16_SA, hi, mid); lo = 0u; }
+__device__ __forceinline__ void split_a(float x0, float x1, float sa, unsigned& hi, unsigned& mid, unsigned& lo) {
+  if constexpr (NTERMS == T_F16) { split2_f16(x0, x1, sa, hi, mid); lo = 0u; }
   else split2(x0, x1, hi, mid, lo);
 }
+// activation pre-scale of a launch: 2^4 unless the caller knows better (GemmArgs::a_scale, a power of two)
+__device__ __forceinline__ float a_scale_of(const GemmArgs& p) { return p.a_scale > 0.f ? p.a_scale : F16_SA; }
 template <int NTERMS>
 __device__ __forceinline__ f32x16 mma(bf16x8 a, bf16x8 b, f32x16 c) {
   if constexpr (NTERMS == T_F16)
@@ -85,11 +88,11 @@ __device__ __forceinline__ f32x16 mma(bf16x8 a, bf16x8 b, f32x16 c) {
 }
 // f16 mode: un-scale a finished accumulator fragment and raise the status word on a non-finite value
 template <int NTERMS>
-__device__ __forceinline__ void finish_acc(f32x16& acc, bool& bad) {
+__device__ __forceinline__ void finish_acc(f32x16& acc, float unscale, bool& bad) {
   if constexpr (NTERMS == T_F16) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const float v = acc[e] * F16_UNSCALE;
+      const float v = acc[e] * unscale;
       bad |= !(__builtin_fabsf(v) <= 3.4028234664e38f);
       acc[e] = v;
     }
@@ -170,6 +173,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4 || (NST > 2
   if (!tile_origin<BM, BN>(p, m0, n0)) return;
   const int M = p.M, K = p.K;
   const int KT = K / SBK;
+  const float sa = a_scale_of(p);
 
   // K-invariant addressing (see gemm.hip: nothing but 16-byte loads inside the K loop)
   // A_ROWS / TAP3: thread -> (row, 8-float piece); A_CHANMAJOR (A[m][k] = X[k*lda + m]): thread -> (k pair p, 4 rows)
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4 || (NST > 2
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           unsigned hi, mid, lo;
-          split_a<NTERMS>(araw[i][0][e], araw[i][1][e], hi, mid, lo);
+          split_a<NTERMS>(araw[i][0][e], araw[i][1][e], sa, hi, mid, lo);
           const int row = m4 * 4 + e;
           *reinterpret_cast<unsigned*>(As + (0 * BM + row) * ROWB + pk * 4) = hi;
           *reinterpret_cast<unsigned*>(As + (1 * BM + row) * ROWB + pk * 4) = mid;
@@ -245,10 +249,10 @@ __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4 || (NST > 2
         if (APART && id >= BM * 4) continue;
         const int row = id >> 2, c8 = id & 3;
         unsigned h0, h1, h2, h3, m0_, m1, m2, m3, l0, l1, l2, l3;
-        split_a<NTERMS>(araw[i][0].x, araw[i][0].y, h0, m0_, l0);
-        split_a<NTERMS>(araw[i][0].z, araw[i][0].w, h1, m1, l1);
-        split_a<NTERMS>(araw[i][1].x, araw[i][1].y, h2, m2, l2);
-        split_a<NTERMS>(araw[i][1].z, araw[i][1].w, h3, m3, l3);
+        split_a<NTERMS>(araw[i][0].x, araw[i][0].y, sa, h0, m0_, l0);
+        split_a<NTERMS>(araw[i][0].z, araw[i][0].w, sa, h1, m1, l1);
+        split_a<NTERMS>(araw[i][1].x, araw[i][1].y, sa, h2, m2, l2);
+        split_a<NTERMS>(araw[i][1].z, araw[i][1].w, sa, h3, m3, l3);
         const u32x4 hi = {h0, h1, h2, h3}, mid = {m0_, m1, m2, m3}, lo = {l0, l1, l2, l3};
         *reinterpret_cast<u32x4*>(As + (0 * BM + row) * ROWB + c8 * 16) = hi;
         *reinterpret_cast<u32x4*>(As + (1 * BM + row) * ROWB + c8 * 16) = mid;
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4 || (NST > 2
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) finish_acc<NTERMS>(acc[i][j], bad);
+      for (int j = 0; j < TN; ++j) finish_acc<NTERMS>(acc[i][j], 1.f / (sa * F16_SW), bad);
     if (bad && p.status) atomicOr(p.status, 1u);
   }
   if constexpr (LN) {                                   // tile spans the whole output row (n0 = 0)
@@ -377,6 +381,7 @@ __global__ __launch_bounds__(KS * 64) void gemm_bf16s_kslice_kernel(GemmBatch ba
   if (!tile_origin<TM * 32, 64>(p, m0, n0)) return;
   const int M = p.M;
   const int KT = p.K / SBK;
+  const float sa = a_scale_of(p);
   const int kb = KT * wave / KS, ke = KT * (wave + 1) / KS;
 
   const float* a_ptr[TM];
@@ -430,10 +435,10 @@ __global__ __launch_bounds__(KS * 64) void gemm_bf16s_kslice_kernel(GemmBatch ba
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         unsigned h0, h1, h2, h3, m0_, m1, m2, m3, l0, l1, l2, l3;
-        split_a<NTERMS>(araw[i][c][0].x, araw[i][c][0].y, h0, m0_, l0);
-        split_a<NTERMS>(araw[i][c][0].z, araw[i][c][0].w, h1, m1, l1);
-        split_a<NTERMS>(araw[i][c][1].x, araw[i][c][1].y, h2, m2, l2);
-        split_a<NTERMS>(araw[i][c][1].z, araw[i][c][1].w, h3, m3, l3);
+        split_a<NTERMS>(araw[i][c][0].x, araw[i][c][0].y, sa, h0, m0_, l0);
+        split_a<NTERMS>(araw[i][c][0].z, araw[i][c][0].w, sa, h1, m1, l1);
+        split_a<NTERMS>(araw[i][c][1].x, araw[i][c][1].y, sa, h2, m2, l2);
+        split_a<NTERMS>(araw[i][c][1].z, araw[i][c][1].w, sa, h3, m3, l3);
         a[i][c][0] = __builtin_bit_cast(bf16x8, (u32x4){h0, h1, h2, h3});
         a[i][c][1] = __builtin_bit_cast(bf16x8, (u32x4){m0_, m1, m2, m3});
         if constexpr (NPL == 3) a[i][c][2] = __builtin_bit_cast(bf16x8, (u32x4){l0, l1, l2, l3});
@@ -498,7 +503,7 @@ __global__ __launch_bounds__(KS * 64) void gemm_bf16s_kslice_kernel(GemmBatch ba
   }
   if constexpr (NTERMS == T_F16) {
     bool bad = false;
-    finish_acc<NTERMS>(fin[0][0], bad);
+    finish_acc<NTERMS>(fin[0][0], 1.f / (sa * F16_SW), bad);
     if (bad && p.status) atomicOr(p.status, 1u);
   }
   gemm_epilogue<TM, 2, 1, 1>(p, fin, m0, n0, wave >> 1, wave & 1, r, h);
@@ -628,6 +633,7 @@ int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, 
       if (bm == 64 && bn == 128) return launch_cfg_s<1, 4, 2, 1>(b, count, mode, nterms, stream);
       if (bm == 64 && bn == 64) return launch_cfg_s<2, 2, 1, 1>(b, count, mode, nterms, stream);
       if (bm == 128 && bn == 128) return launch_cfg_s<2, 2, 2, 2>(b, count, mode, nterms, stream);
+      if (bm == 128 && bn == 256) return launch_cfg_s<1, 4, 4, 2>(b, count, mode, nterms, stream);
     }
   }
   if (p.ln_w) {                                          // fused LayerNorm: the tile must span the row
@@ -638,7 +644,8 @@ int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, 
   // small grids: split K over the waves instead of the tile (see gemm_bf16s_kslice_kernel)
   static const long kslice_max = getenv("DCF_KSLICE_MAX") ? atol(getenv("DCF_KSLICE_MAX")) : 512;
   // (8192x256x256, 512 tiles: tile kernel 14.9 us vs 18.0 k-sliced; 8192x256x1024: 40 vs 38 -> short K switches at 256 tiles)
-  if (mode == A_ROWS && N % 64 == 0 && p.K >= 4 * SBK && wgs(64, 64) <= (p.K >= 16 * SBK ? kslice_max : kslice_max / 2))
+  // (f16x3: 8192x256x1024, 512 tiles: tile kernel 22.7 us vs 30.4 k-sliced -> 256 tiles for every K)
+  if (mode == A_ROWS && N % 64 == 0 && p.K >= 4 * SBK && wgs(64, 64) <= ((p.K >= 16 * SBK && nterms != T_F16) ? kslice_max : kslice_max / 2))
     return launch_kslice(b, count, nterms, stream);
   if (mode == A_CHANMAJOR) {
     DCF_CHECK(N % 128 == 0, "launch_gemm_split: channel-major A needs N %% 128 == 0");
@@ -654,7 +661,14 @@ int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, 
   // with the LayerNorm fused (each weight fragment fetched once, but 252 registers = 2 waves/SIMD) 122 us, 64x96
   // tiles of two 32x96 waves 107 us, 128x96 tiles of six 64x32 waves 117 us, against 100 + 16 us (LayerNorm kernel) for the
   // four-wave 128x96 tile below.
-  if (N % 96 == 0 && N % 64 != 0) return launch_cfg_s<4, 1, 1, 3>(b, count, mode, nterms, stream);              // 128x96
+  if (N % 96 == 0 && N % 64 != 0) {                                                                             // 128x96
+    // f16x3: three waves side by side, 128x32 each (every weight fragment fetched by exactly one wave, 4 row tiles of
+    // A per fragment).  The four-wave stack of 32x96 tiles fetches each fragment four times through the 64 B/clk
+    // vector-memory path: ~135 B/clk per CU at full MFMA rate once the MFMA work halved (bf16x6: half that).
+    static const bool stack = getenv("DCF_HEADS_STACK") != nullptr;
+    if (nterms == T_F16 && !stack) return launch_cfg_s<1, 3, 4, 1>(b, count, mode, nterms, stream);
+    return launch_cfg_s<4, 1, 1, 3>(b, count, mode, nterms, stream);
+  }
   if (N % 160 == 0 && N % 64 != 0) return launch_cfg_s<4, 1, 1, 5>(b, count, mode, nterms, stream);             // 128x160
   if (N % 128 == 0 && wgs(64, 128) >= WANT) return launch_cfg_s<1, 4, 2, 1>(b, count, mode, nterms, stream);   // 64x128
   if (N % 64 == 0) return launch_cfg_s<2, 2, 1, 1>(b, count, mode, nterms, stream);                             // 64x64

@@ -5,8 +5,8 @@ import ctypes, importlib, json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 SHAPES = [(16384, 256, 256), (16384, 1024, 256), (16384, 256, 1024), (16384, 512, 256), (8192, 256, 256), (8192, 1024, 256),
-          (8192, 256, 1024), (32640, 256, 768), (131072, 256, 256), (131072, 256, 1024), (131072, 1024, 256)]
-TILES = ['x6:auto', 'x6:64x256', 'x6:64x128']
+          (8192, 256, 1024), (4096, 256, 256), (4096, 1024, 256), (4096, 256, 1024), (32640, 256, 768), (49152, 256, 256), (49152, 1024, 256), (49152, 256, 1024)]
+TILES = ['f16:auto', 'f16:64x256', 'f16:64x128', 'f16:64x64', 'f16:128x128', 'f16:128x256']
 
 def child():
     import torch
@@ -20,7 +20,7 @@ def child():
         P = lambda t: ctypes.c_void_p(t.data_ptr())
         mode = os.environ.get('SWEEP_MODE', 'f32')
         call = (lambda: lib.dcf_op_linear(P(A), P(W), P(b), P(C), M, N, K, 0, st)) if mode == 'f32' else \
-               (lambda: lib.dcf_op_linear_split(P(A), P(W), P(b), P(C), M, N, K, 0, 6 if mode == 'x6' else 3, st))
+               (lambda: lib.dcf_op_linear_split(P(A), P(W), P(b), P(C), M, N, K, 0, 6 if mode == 'x6' else 16, st))
         for _ in range(3):
             call()
         torch.cuda.synchronize()
