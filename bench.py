@@ -47,6 +47,9 @@ def parse():
     ap.add_argument('--max-batch', type=int, default=8)
     ap.add_argument('--videos', type=int, default=3,
                     help='videos per step: independent videos in flight on their own HIP streams (one model instance each)')
+    ap.add_argument('--batch', type=int, default=3,
+                    help='videos per forward (forward_videos: same-length videos batched through every kernel); a step then '
+                         'holds --videos x --batch videos')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--debug-gloo-one-gpu', action='store_true',
                     help='flow check of the multi-rank path on a one-GPU box: gloo rendezvous, every rank on cuda:0 (timings meaningless)')
@@ -103,7 +106,22 @@ def main():
         tmasks.append(m)
     texts, tmasks = tuple(texts), tuple(tmasks)
 
+    def lane_inputs(mdl, seed0):
+        """the --batch - 1 further videos of a lane (its first video is given): argument tuples of forward"""
+        extra = []
+        for j in range(1, max(1, args.batch)):
+            ij = pkg.synth.make_inputs(kw['D'], T, vid_len, args.nq, kw['text_in'], 32, seed0 + 100000 * j)
+            tj, mj = zip(*[mdl.encode_text(tok[None].to(dev), torch.ones(1, 1, tok.size(-1), dtype=torch.bool, device=dev))
+                           for tok in ij['tokens']])
+            extra.append((ij['vid'].to(dev), ij['shallow_vid'].to(dev), ij['vid_masks'].to(dev), tuple(tj), ij['text_cls'].to(dev), tuple(mj)))
+        return extra
+
+    first = (vid, shallow, vmask, texts, text_cls, tmasks)
+    batch0 = [first] + lane_inputs(model, 2025 + 3 + rank)
+
     def step1():
+        if args.batch > 1:
+            return model.forward_videos(batch0)
         return model(vid, shallow, vmask, texts, text_cls, tmasks, eval=True)
 
     # A step = one batch of `--videos` different synthetic videos, each an independent forward (own model instance =
@@ -118,8 +136,8 @@ def main():
         ik = pkg.synth.make_inputs(kw['D'], T, vid_len, args.nq, kw['text_in'], 32, 2025 + 3 + rank + 1000 * k)
         tk, mkk = zip(*[mk.encode_text(tok[None].to(dev), torch.ones(1, 1, tok.size(-1), dtype=torch.bool, device=dev))
                         for tok in ik['tokens']])
-        others.append((mk, (ik['vid'].to(dev), ik['shallow_vid'].to(dev), ik['vid_masks'].to(dev), tuple(tk),
-                            ik['text_cls'].to(dev), tuple(mkk)), torch.cuda.Stream()))
+        ak = (ik['vid'].to(dev), ik['shallow_vid'].to(dev), ik['vid_masks'].to(dev), tuple(tk), ik['text_cls'].to(dev), tuple(mkk))
+        others.append((mk, ak, torch.cuda.Stream(), [ak] + lane_inputs(mk, 2025 + 3 + rank + 1000 * k)))
     stream0 = torch.cuda.Stream() if others else None
     torch.cuda.synchronize()
 
@@ -128,9 +146,12 @@ def main():
             return step1()
         with torch.cuda.stream(stream0):
             out0 = step1()
-        for mk, a, sk in others:
+        for mk, a, sk, bk in others:
             with torch.cuda.stream(sk):
-                mk(*a, eval=True)
+                if args.batch > 1:
+                    mk.forward_videos(bk)
+                else:
+                    mk(*a, eval=True)
         return out0
 
     # setup, not steps: the engine runs a new argument set eagerly once, captures its HIP graph on the second call and
@@ -159,7 +180,8 @@ def main():
     # the f16x3 GEMMs flag any accumulator that left the finite range (operands beyond the fp16 range): must be clean
     for mk in [model] + [o[0] for o in others]:
         assert mk.numerics_status() & 1 == 0, 'f16x3 GEMM range overflow flagged: the timed outputs are not valid'
-    n_videos = 1 + len(others)
+    n_lanes = 1 + len(others)
+    n_videos = n_lanes * max(1, args.batch)
     clips_per_step = n_videos * vid_len * args.nq
     value = world * clips_per_step * args.steps / elapsed
 
@@ -168,10 +190,11 @@ def main():
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'BASELINE configs[2]: T={T} D=1024 full multi-scale pyramid + sidekick top-k 30% + expert path, '
-                               f'NQ={args.nq} queries/video, {n_videos} independent videos per step in flight on {n_videos} HIP streams, one replica of this per GPU',
+                               f'NQ={args.nq} queries/video, {n_videos} independent videos per step: {n_lanes} forwards in flight on {n_lanes} HIP streams x '
+                               f'{max(1, args.batch)} videos per forward, one replica of this per GPU',
                    'T': T, 'vid_len': vid_len, 'D': 1024, 'E': 256, 'TE': 256, 'levels': 8, 'win': 9, 'heads': 4,
                    'fusion_layers': 2, 'sn': 60, 'sratio': 0.3, 'msf': True, 'norm': True, 'Lq': 32, 'nq': args.nq,
-                   'max_batch': args.max_batch, 'videos_per_step': n_videos, 'parallelism': f'replicas x{world}',
+                   'max_batch': args.max_batch, 'videos_per_step': n_videos, 'forwards_in_flight': n_lanes, 'videos_per_forward': max(1, args.batch), 'parallelism': f'replicas x{world}',
                    'launch': 'HIP graph replay of the forward (captured on the 2nd identical call); DCF_NO_GRAPH=1 = eager'},
     }
 
@@ -280,8 +303,9 @@ def main():
                 step1()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t1) / args.steps
-            result['one_video_in_flight'] = {'value': vid_len * args.nq / dt, 'unit': 'clips/s', 'ms_per_forward': 1e3 * dt,
-                                             'note': 'a single forward at a time on one stream (HIP-graph replay), rank 0 only'}
+            result['one_video_in_flight'] = {'value': max(1, args.batch) * vid_len * args.nq / dt, 'unit': 'clips/s', 'ms_per_forward': 1e3 * dt,
+                                             'note': 'a single forward at a time on one stream (HIP-graph replay), rank 0 only'
+                                                     + (f'; {args.batch} videos per forward' if args.batch > 1 else '')}
 
         # ---- proposal decode + NMS (reported separately) and the NMS index match
         if extras:

@@ -520,16 +520,17 @@ struct Arena {
 
 struct Buffers {
   float *P1, *P2, *tn, *partial, *correl, *gate;
-  uint8_t *mask_all, *nbr_all, *kvmask;
+  uint8_t *mask_all, *nbr_all, *kvmask, *maskv;
   float *X, *R[7], *H2, *HID, *F, *HA, *HB, *HC, *HD, *logits1, *tcnA, *tcnB, *kvn, *Kt, *Vt;
 };
 
-static void carve(Arena& a, const dcf_config& c, int T0, int B, int nq, int S, int Lk, Buffers& b) {
+static void carve(Arena& a, const dcf_config& c, int T0, int B, int nq, int S, int Lk, int nvid, Buffers& b) {
   const size_t rows0 = (size_t)B * T0, rowsAll = (size_t)B * S;
   const size_t rowsF = (c.model_kind == 1 || c.second_fusion) ? rowsAll : rows0;   // rows the fusion stack sees
   const int E = c.E, EH = c.E + TCN_HID;
-  b.P1 = a.take<float>((size_t)T0 * E);
-  b.P2 = a.take<float>((size_t)T0 * E);
+  b.P1 = a.take<float>((size_t)nvid * T0 * E);
+  b.P2 = a.take<float>((size_t)nvid * T0 * E);
+  b.maskv = a.take<uint8_t>(nvid > 1 ? (size_t)nvid * T0 : 0);     // the videos' masks side by side (several videos only)
   b.tn = a.take<float>((size_t)nq * c.D);
   b.partial = a.take<float>((size_t)SCORE_SLICES * (nq + 1) * T0);
   b.correl = a.take<float>((size_t)nq * T0);
@@ -809,20 +810,47 @@ static int run_fusion(dcf_model* m, Buffers& b, float* X, int64_t ldx, int B, in
   return 0;
 }
 
-static int forward(dcf_model* m, const float* vid, const float* shallow, const uint8_t* vid_mask, int T0, int nq,
+// The videos of one forward: all padded to the same T, video v with nq[v] queries; the queries of all videos are one flat
+// list (text / outputs in video order).  One video is the reference's call (model.py:496 asserts bs == 1); several are
+// the throughput extension dcf_forward_eval_videos: after vid_map every kernel works on rows [query][t] and does not
+// care which video a query belongs to.
+constexpr int DCF_MAX_VIDEOS = 16;
+struct VideoSet {
+  int nvid = 0;
+  const float* vid[DCF_MAX_VIDEOS];
+  const float* shallow[DCF_MAX_VIDEOS];
+  const uint8_t* mask[DCF_MAX_VIDEOS];
+  const float* text_cls[DCF_MAX_VIDEOS];      // (nq[v], D); with gate_override: the gate (nq, T)
+  int nq[DCF_MAX_VIDEOS];
+};
+
+static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
                    const float* const* text, const uint8_t* const* text_mask, const int32_t* text_len,
-                   const float* text_cls, const float* gate_override, float* logits_out, float* offsets_out,
+                   const float* gate_override, float* logits_out, float* offsets_out,
                    uint8_t* masks_out, hipStream_t st) {
   const dcf_config& c = m->cfg;
   const int E = c.E, D = c.D, L = c.n_levels;
+  const int nvid = vs.nvid;
   DCF_CHECK(m->finalized, "dcf_forward_eval: model not finalized");
-  DCF_CHECK(T0 > 0 && nq > 0, "dcf_forward_eval: empty input");
+  DCF_CHECK(T0 > 0 && nq > 0 && nvid >= 1 && nvid <= DCF_MAX_VIDEOS, "dcf_forward_eval: empty input");
+  DCF_CHECK(!(gate_override && nvid != 1), "the externally gated forward takes one video");
+  int video_of[DCF_MAX_VIDEOS * 64];           // flat query -> video
+  {
+    int tot = 0;
+    for (int v = 0; v < nvid; ++v) {
+      DCF_CHECK(vs.nq[v] >= 1 && tot + vs.nq[v] <= DCF_MAX_VIDEOS * 64, "dcf_forward_eval: bad query count of video %d", v);
+      for (int i = 0; i < vs.nq[v]; ++i) video_of[tot++] = v;
+    }
+    DCF_CHECK(tot == nq, "dcf_forward_eval: query counts do not add up");
+  }
+  const uint8_t* vid_mask = vs.mask[0];
   DCF_CHECK(T0 % (1 << (L - 1)) == 0, "T=%d must be a multiple of 2^(levels-1)=%d", T0, 1 << (L - 1));
   const int half = c.win / 2;
   DCF_CHECK(half == 0 || (T0 >> (L - 1)) % half == 0, "T=%d: coarsest level must be a multiple of win//2=%d (blocks.py:216)", T0, half);
   if (c.use_abs_pe) DCF_CHECK(m->pe && m->pe_T == T0, "position encoding for T=%d not set (dcf_model_set_pe)", T0);
   const int Bmax = std::min(nq, c.max_batch > 0 ? c.max_batch : 8);
   DCF_CHECK(Bmax <= DCF_MAX_BATCH, "max_batch %d > %d", Bmax, DCF_MAX_BATCH);
+  DCF_CHECK(nvid == 1 || Bmax <= 16, "several videos per forward need max_batch <= 16 (got %d)", Bmax);
   int Lk = 1;
   for (int q = 0; q < nq; ++q) {
     DCF_CHECK(text_len[q] >= 1 && text[q], "text %d is empty", q);
@@ -835,7 +863,7 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
   Buffers b{};
   {
     Arena dry{nullptr, 0, 0, true};
-    carve(dry, c, T0, Bmax, nq, S, Lk, b);
+    carve(dry, c, T0, Bmax, nq, S, Lk, nvid, b);
     if (dry.off > m->arena_bytes) {
       DCF_CHECK(!m->capturing, "internal: workspace growth during graph capture");
       drop_graph(m);
@@ -846,32 +874,34 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
       m->arena_bytes = dry.off;
     }
     Arena real{m->arena, 0, m->arena_bytes, false};
-    carve(real, c, T0, Bmax, nq, S, Lk, b);
+    carve(real, c, T0, Bmax, nq, S, Lk, nvid, b);
   }
   // ---- per video: sidekick scores and the query-independent halves of vid_map
-  bool forked = false;
   DCF_CHECK(!(gate_override && c.scat), "opt.model.scat needs the sidekick scores: the externally gated (T-sharded) forward does not take them");
-  if (!gate_override) {
-    // HBM-bound scoring of the shallow features next to the MFMA-bound vid_map GEMMs
-    ScoreArgs sa{shallow, text_cls, b.tn, b.partial, b.correl, D, T0, nq, c.norm};
-    if (fork_enabled(0)) {
-      TRY(fork_side(m, 0, st));
-      forked = true;
-      TRY(launch_sidekick(sa, m->side));
-    } else {
-      TRY(launch_sidekick(sa, st));
+  for (int v = 0, q_off = 0; v < nvid; q_off += vs.nq[v], ++v) {
+    bool forked = false;
+    if (!gate_override) {
+      // HBM-bound scoring of the shallow features next to the MFMA-bound vid_map GEMMs
+      ScoreArgs sa{vs.shallow[v], vs.text_cls[v], b.tn + (size_t)q_off * D, b.partial, b.correl + (size_t)q_off * T0, D, T0, vs.nq[v], c.norm};
+      if (fork_enabled(0)) {
+        TRY(fork_side(m, 0, st));
+        forked = true;
+        TRY(launch_sidekick(sa, m->side));
+      } else {
+        TRY(launch_sidekick(sa, st));
+      }
     }
-  }
-  {
     // deep and shallow halves of vid_map share one grid (same shape, blockIdx.z selects the operand set)
     GemmArgs g[2];
     int ng = 0;
-    if (m->vid_w1) g[ng++] = gemm(vid, T0, m->vid_w1, nullptr, b.P1, E, T0, E, D);
-    if (m->vid_w2) g[ng++] = gemm(shallow, T0, m->vid_w2, nullptr, b.P2, E, T0, E, D);
+    if (m->vid_w1) g[ng++] = gemm(vs.vid[v], T0, m->vid_w1, nullptr, b.P1 + (size_t)v * T0 * E, E, T0, E, D);
+    if (m->vid_w2) g[ng++] = gemm(vs.shallow[v], T0, m->vid_w2, nullptr, b.P2 + (size_t)v * T0 * E, E, T0, E, D);
     for (int i = 0; i < ng; ++i) { g[i].ldw = m->vid_ldw; g[i].a_scale = 1.f; }
     TRY(run_gemm(m, g, ng, A_CHANMAJOR, st));
     if (forked) TRY(join_side(m, 0, st));
+    if (nvid > 1) DCF_HIP(hipMemcpyAsync(b.maskv + (size_t)v * T0, vs.mask[v], (size_t)T0, hipMemcpyDeviceToDevice, st));
   }
+  if (nvid > 1) vid_mask = b.maskv;
 
   for (int q0 = 0; q0 < nq; q0 += Bmax) {
     const int B = std::min(Bmax, nq - q0);
@@ -879,6 +909,8 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
     TRY(get_plan(m, T0, B, st, &pl));
     const LevelTable& lt = pl->lt;
     const int rows0 = B * T0, rowsAll = B * S;
+    unsigned long long vmap = 0;           // video of batch element i in nibble i (B <= 16 with several videos, <= 16 videos)
+    for (int i = 0; i < B && i < 16; ++i) vmap |= (unsigned long long)video_of[q0 + i] << (4 * i);
 
     // ---- gate + masks for every level
     if (gate_override) {
@@ -887,7 +919,7 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
                          b.gate, b.mask_all, T0, rows0, c.msf);
       DCF_HIP(hipGetLastError());
     } else {
-      GateArgs ga{b.correl, vid_mask, b.gate, b.mask_all, T0, B, q0, c.sn, c.msf, (double)c.sratio};
+      GateArgs ga{b.correl, vid_mask, b.gate, b.mask_all, T0, B, q0, c.sn, c.msf, (double)c.sratio, vmap};
       TRY(launch_gate(ga, st));
     }
     TRY(launch_pyramid_masks(b.mask_all, b.nbr_all, B, T0, L, rowsAll, st));
@@ -895,7 +927,7 @@ static int forward(dcf_model* m, const float* vid, const float* shallow, const u
 
     // ---- vid_map (model.py:543-555)
     TRY(launch_vidmap_combine(m->vid_w1 ? b.P1 : nullptr, m->vid_w2 ? b.P2 : nullptr, m->vid_map_b, b.gate, mask0,
-                              m->vid_w3, m->vid_w3 ? b.correl + (int64_t)q0 * T0 : nullptr, b.X, T0, rows0, E, st));
+                              m->vid_w3, m->vid_w3 ? b.correl + (int64_t)q0 * T0 : nullptr, b.X, T0, rows0, E, vmap, st));
     if (m->keep_debug && m->dbg_vidmap) DCF_HIP(hipMemcpyAsync(m->dbg_vidmap, b.X, (size_t)rows0 * E * 4, hipMemcpyDeviceToDevice, st));
 
     // ---- text side: pointers of this chunk
@@ -1109,15 +1141,18 @@ int dcf_model_bind(dcf_model* m, const char* name, const float* data, const int6
 
 namespace dcf {
 // eager on the first call with a given argument set, capture + replay from the second identical call on
-static int forward_maybe_graph(dcf_model* m, const float* vid, const float* shallow, const uint8_t* vid_mask, int T0, int nq,
+static int forward_maybe_graph(dcf_model* m, const VideoSet& vs, int T0, int nq,
                                const float* const* text, const uint8_t* const* text_mask, const int32_t* text_len,
-                               const float* text_cls, const float* gate, float* lo, float* oo, uint8_t* mo, hipStream_t st) {
+                               const float* gate, float* lo, float* oo, uint8_t* mo, hipStream_t st) {
   static const bool no_graph = getenv("DCF_NO_GRAPH") != nullptr;
-  const int Bmax = std::min(nq, m->cfg.max_batch > 0 ? m->cfg.max_batch : 8);
   const bool eligible = !no_graph && !g_prof_on && !m->keep_debug && nq > 0;
-  if (!eligible) return forward(m, vid, shallow, vid_mask, T0, nq, text, text_mask, text_len, text_cls, gate, lo, oo, mo, st);
-  std::vector<uint64_t> key = {(uint64_t)vid, (uint64_t)shallow, (uint64_t)vid_mask, (uint64_t)T0, (uint64_t)nq, (uint64_t)text_cls,
+  if (!eligible) return forward(m, vs, T0, nq, text, text_mask, text_len, gate, lo, oo, mo, st);
+  std::vector<uint64_t> key = {(uint64_t)vs.nvid, (uint64_t)T0, (uint64_t)nq,
                                (uint64_t)gate, (uint64_t)lo, (uint64_t)oo, (uint64_t)mo, (uint64_t)st, (uint64_t)m->pe, (uint64_t)m->pe_T};
+  for (int v = 0; v < vs.nvid; ++v) {
+    key.push_back((uint64_t)vs.vid[v]); key.push_back((uint64_t)vs.shallow[v]); key.push_back((uint64_t)vs.mask[v]);
+    key.push_back((uint64_t)vs.text_cls[v]); key.push_back((uint64_t)vs.nq[v]);
+  }
   for (int q = 0; q < nq; ++q) {
     key.push_back((uint64_t)text[q]);
     key.push_back(text_mask ? (uint64_t)text_mask[q] : 0);
@@ -1129,17 +1164,17 @@ static int forward_maybe_graph(dcf_model* m, const float* vid, const float* shal
   }
   if (key != m->last_key) {                          // first sighting: run eagerly (allocates workspace / plans)
     m->last_key = key;
-    return forward(m, vid, shallow, vid_mask, T0, nq, text, text_mask, text_len, text_cls, gate, lo, oo, mo, st);
+    return forward(m, vs, T0, nq, text, text_mask, text_len, gate, lo, oo, mo, st);
   }
   // second identical call: capture
   drop_graph(m);
   m->last_key = key;
   if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
     (void)hipGetLastError();
-    return forward(m, vid, shallow, vid_mask, T0, nq, text, text_mask, text_len, text_cls, gate, lo, oo, mo, st);
+    return forward(m, vs, T0, nq, text, text_mask, text_len, gate, lo, oo, mo, st);
   }
   m->capturing = true;
-  const int rc = forward(m, vid, shallow, vid_mask, T0, nq, text, text_mask, text_len, text_cls, gate, lo, oo, mo, st);
+  const int rc = forward(m, vs, T0, nq, text, text_mask, text_len, gate, lo, oo, mo, st);
   m->capturing = false;
   hipGraph_t g = nullptr;
   const hipError_t ec = hipStreamEndCapture(st, &g);
@@ -1147,7 +1182,7 @@ static int forward_maybe_graph(dcf_model* m, const float* vid, const float* shal
     (void)hipGetLastError();
     if (g) (void)hipGraphDestroy(g);
     const std::string err = g_err;
-    const int rc2 = forward(m, vid, shallow, vid_mask, T0, nq, text, text_mask, text_len, text_cls, gate, lo, oo, mo, st);
+    const int rc2 = forward(m, vs, T0, nq, text, text_mask, text_len, gate, lo, oo, mo, st);
     if (rc2 != 0 && !err.empty()) g_err = err;
     return rc2;
   }
@@ -1155,7 +1190,7 @@ static int forward_maybe_graph(dcf_model* m, const float* vid, const float* shal
   if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) {
     (void)hipGetLastError();
     (void)hipGraphDestroy(g);
-    return forward(m, vid, shallow, vid_mask, T0, nq, text, text_mask, text_len, text_cls, gate, lo, oo, mo, st);
+    return forward(m, vs, T0, nq, text, text_mask, text_len, gate, lo, oo, mo, st);
   }
   m->graph = g;
   m->graph_exec = ge;
@@ -1217,8 +1252,30 @@ int dcf_forward_eval(dcf_model* m, const float* vid, const float* shallow_vid, c
   DCF_CHECK(m && vid && shallow_vid && vid_mask && text && text_len && text_cls && logits_out && offsets_out && masks_out,
             "dcf_forward_eval: null argument");
   DCF_CHECK(T < (1ll << 24), "T too large");
-  return dcf::forward_maybe_graph(m, vid, shallow_vid, vid_mask, (int)T, nq, text, text_mask, text_len, text_cls, nullptr,
+  dcf::VideoSet vs;
+  vs.nvid = 1; vs.vid[0] = vid; vs.shallow[0] = shallow_vid; vs.mask[0] = vid_mask; vs.text_cls[0] = text_cls; vs.nq[0] = nq;
+  return dcf::forward_maybe_graph(m, vs, (int)T, nq, text, text_mask, text_len, nullptr,
                                   logits_out, offsets_out, masks_out, (hipStream_t)stream);
+}
+
+int dcf_forward_eval_videos(dcf_model* m, int32_t nvid, const float* const* vid, const float* const* shallow_vid,
+                            const uint8_t* const* vid_mask, int64_t T, const int32_t* nq_per_video, const float* const* text,
+                            const uint8_t* const* text_mask, const int32_t* text_len, const float* const* text_cls,
+                            float* logits_out, float* offsets_out, uint8_t* masks_out, void* stream) {
+  DCF_CHECK(m && vid && shallow_vid && vid_mask && nq_per_video && text && text_len && text_cls && logits_out && offsets_out && masks_out,
+            "dcf_forward_eval_videos: null argument");
+  DCF_CHECK(nvid >= 1 && nvid <= dcf::DCF_MAX_VIDEOS, "dcf_forward_eval_videos: 1 .. %d videos per call", dcf::DCF_MAX_VIDEOS);
+  DCF_CHECK(T < (1ll << 24), "T too large");
+  dcf::VideoSet vs;
+  vs.nvid = nvid;
+  int nq = 0;
+  for (int v = 0; v < nvid; ++v) {
+    DCF_CHECK(vid[v] && shallow_vid[v] && vid_mask[v] && text_cls[v] && nq_per_video[v] >= 1, "dcf_forward_eval_videos: video %d is incomplete", v);
+    vs.vid[v] = vid[v]; vs.shallow[v] = shallow_vid[v]; vs.mask[v] = vid_mask[v]; vs.text_cls[v] = text_cls[v]; vs.nq[v] = nq_per_video[v];
+    nq += nq_per_video[v];
+  }
+  return dcf::forward_maybe_graph(m, vs, (int)T, nq, text, text_mask, text_len, nullptr, logits_out, offsets_out, masks_out,
+                                  (hipStream_t)stream);
 }
 
 int dcf_forward_eval_gated(dcf_model* m, const float* vid, const float* shallow_vid, const uint8_t* vid_mask, int64_t T,
@@ -1227,7 +1284,9 @@ int dcf_forward_eval_gated(dcf_model* m, const float* vid, const float* shallow_
   DCF_CHECK(m && vid && shallow_vid && vid_mask && text && text_len && gate && logits_out && offsets_out && masks_out,
             "dcf_forward_eval_gated: null argument");
   DCF_CHECK(T < (1ll << 24), "T too large");
-  return dcf::forward_maybe_graph(m, vid, shallow_vid, vid_mask, (int)T, nq, text, text_mask, text_len, nullptr, gate,
+  dcf::VideoSet vs;
+  vs.nvid = 1; vs.vid[0] = vid; vs.shallow[0] = shallow_vid; vs.mask[0] = vid_mask; vs.text_cls[0] = nullptr; vs.nq[0] = nq;
+  return dcf::forward_maybe_graph(m, vs, (int)T, nq, text, text_mask, text_len, gate,
                                   logits_out, offsets_out, masks_out, (hipStream_t)stream);
 }
 

@@ -76,7 +76,8 @@ int launch_rowflags(const uint8_t* mask, uint8_t* nbr, int T, int rows, hipStrea
 int launch_pyramid_masks(uint8_t* mask_all, uint8_t* nbr_all, int B, int T0, int L, int rows_all, hipStream_t st);
 int launch_mask_down(const uint8_t* in, uint8_t* out, int rows_out, hipStream_t st);
 int launch_vidmap_combine(const float* P1, const float* P2, const float* bias, const float* gate, const uint8_t* mask,
-                          const float* w3, const float* correl, float* X, int T, int rows, int E, hipStream_t st);
+                          const float* w3, const float* correl, float* X, int T, int rows, int E, unsigned long long vmap,
+                          hipStream_t st);
 int launch_ln(const LnArgs& a, hipStream_t st);
 int launch_dec_pre(const DecPreArgs& a, hipStream_t st);
 int launch_dec_mid(const float* Xa, const float* H, const float* ln_w, const float* ln_b, float* Q3, float* Xn, int rows,

@@ -70,11 +70,13 @@ __global__ __launch_bounds__(256) void k_vidmap_combine(const float* __restrict_
                                                          const float* __restrict__ bias, const float* __restrict__ gate,
                                                          const uint8_t* __restrict__ mask,
                                                          const float* __restrict__ w3, const float* __restrict__ correl,
-                                                         float* __restrict__ X, int T, int rows, int E) {
+                                                         float* __restrict__ X, int T, int rows, int E,
+                                                         unsigned long long vmap) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
-  const int t = r % T;
+  // row of the video's products: video (vmap >> 4b) & 15 of batch element b = r / T (0 for one video)
+  const int t = r % T + (int)((vmap >> (4 * ((r / T) & 15))) & 15ull) * T;
   const float m = mask[r] ? 1.f : 0.f;
   const float g = gate[r];
   const float s = w3 ? correl[r] : 0.f;     // scat: the clip's raw sidekick score is one more input channel
@@ -391,11 +393,12 @@ int launch_mask_down(const uint8_t* in, uint8_t* out, int rows_out, hipStream_t 
 }
 
 int launch_vidmap_combine(const float* P1, const float* P2, const float* bias, const float* gate, const uint8_t* mask,
-                          const float* w3, const float* correl, float* X, int T, int rows, int E, hipStream_t st) {
+                          const float* w3, const float* correl, float* X, int T, int rows, int E, unsigned long long vmap,
+                          hipStream_t st) {
   if (rows <= 0) return 0;
   ProfScope prof("vidmap_combine", st, 3.0 * rows * E, 4.0 * 3.0 * rows * E);
   DISPATCH_NCH(E, hipLaunchKernelGGL((k_vidmap_combine<NCH>), dim3((rows + 3) / 4), dim3(256), 0, st, P1, P2, bias, gate,
-                                     mask, w3, correl, X, T, rows, E));
+                                     mask, w3, correl, X, T, rows, E, vmap));
   return 0;
 }
 

@@ -125,17 +125,18 @@ __global__ __launch_bounds__(1024) void k_gate(GateArgs p) {
   __shared__ int s_len;
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* correl = p.correl + (size_t)(p.q0 + b) * p.T;
+  const uint8_t* vid_mask = p.vid_mask + (size_t)((p.vmap >> (4 * (b & 15))) & 15ull) * p.T;
   // vid_len = vid_masks.sum()  (model.py:531), computed on device: no host sync
   if (tid == 0) s_len = 0;
   __syncthreads();
   int cnt = 0;
   {
     const int T16 = p.T & ~15;                        // 16 mask bytes per load (the mask pointer is 16-byte aligned
-    const bool al = (reinterpret_cast<uintptr_t>(p.vid_mask) & 15) == 0;   // for torch storage; else byte loop)
+    const bool al = (reinterpret_cast<uintptr_t>(vid_mask) & 15) == 0;   // for torch storage; else byte loop)
     int t0 = 0;
     if (al) {
       for (int t = tid * 16; t < T16; t += 1024 * 16) {
-        const uint4 v = *reinterpret_cast<const uint4*>(p.vid_mask + t);
+        const uint4 v = *reinterpret_cast<const uint4*>(vid_mask + t);
         const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(1024) void k_gate(GateArgs p) {
       }
       t0 = T16;
     }
-    for (int t = t0 + tid; t < p.T; t += 1024) cnt += p.vid_mask[t] ? 1 : 0;
+    for (int t = t0 + tid; t < p.T; t += 1024) cnt += vid_mask[t] ? 1 : 0;
   }
   cnt = (int)wave_sum((float)cnt);
   if ((tid & 63) == 0 && cnt) atomicAdd(&s_len, cnt);
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(1024) void k_gate(GateArgs p) {
       g = sel[src] ? 1.f : 0.f;
     }
     p.gate[(size_t)b * p.T + t] = g;
-    const bool m = p.vid_mask[t] != 0;
+    const bool m = vid_mask[t] != 0;
     p.mask_out[(size_t)b * p.T + t] = p.msf ? m : (m && g != 0.f);
   }
 }

@@ -115,10 +115,9 @@ class GroundingEvaluator:
         self.time_dict = defaultdict(list)
 
     @torch.no_grad()
-    def forward(self, data, model=None):
-        """data: vid (D,T), shallow_vid (D,T), text: tuple of (C_t, Lq) token tensors, text_cls (NQ,D).
-        Returns the flat device outputs (logits (NQ,S), offsets (NQ,S,2), masks (NQ,S)) and T_padded.
-        ``model``: a ``self.model.replica()`` when several videos are kept in flight (``run(n_streams > 1)``)."""
+    def prepare(self, data, model=None):
+        """pad -> encode_text (worker_v2.py:930-996): the argument tuple of ``model.forward`` for one video, its padded length
+        and the padded external scores (or None)."""
         model_ = model or self.model
         dev = next(model_.parameters()).device
         t0 = time.perf_counter()
@@ -139,10 +138,19 @@ class GroundingEvaluator:
         text_cls = data['text_cls'].to(dev, non_blocking=True)
         # external per-clip scores (NQ, vid_len), zero-padded like the features (worker_v2.py:964-967,992-994)
         ext = data.get('ext_scores') if isinstance(data, dict) else None
-        self._window_ext = None if ext is None else F.pad(ext.float(), (0, T - vid_len)).to(dev, non_blocking=True)
+        ext = None if ext is None else F.pad(ext.float(), (0, T - vid_len)).to(dev, non_blocking=True)
         self.time_dict['prepare'].append(time.perf_counter() - t0)
+        return (window, shallow_window, mask, tuple(texts), text_cls, tuple(tmasks)), T, ext
+
+    @torch.no_grad()
+    def forward(self, data, model=None):
+        """data: vid (D,T), shallow_vid (D,T), text: tuple of (C_t, Lq) token tensors, text_cls (NQ,D).
+        Returns the flat device outputs (logits (NQ,S), offsets (NQ,S,2), masks (NQ,S)) and T_padded.
+        ``model``: a ``self.model.replica()`` when several videos are kept in flight (``run(n_streams > 1)``)."""
+        model_ = model or self.model
+        args, T, self._window_ext = self.prepare(data, model_)
         t0 = time.perf_counter()
-        out = model_(window, shallow_window, mask, tuple(texts), text_cls, tuple(tmasks), eval=True)
+        out = model_(*args, eval=True)
         self.time_dict['forward'].append(time.perf_counter() - t0)
         self.outputs = out
         return model_._last_flat, T
@@ -174,10 +182,39 @@ class GroundingEvaluator:
         flat, T = self.forward(data)
         return self.generate_proposals(flat, T, data, self._window_ext)
 
-    def run(self, dataset, counter: RecallCounter = None, n_streams: int = 1):
+    def run(self, dataset, counter: RecallCounter = None, n_streams: int = 1, batch_videos: int = 1):
         """Evaluator.run (worker_v2.py:815-910) over an iterable of per-video dicts (keys as in
-        libs/data/dataset.py:977-994: vid, shallow_vid, text, text_cls, segment, fps, clip_stride, clip_size, duration)."""
+        libs/data/dataset.py:977-994: vid, shallow_vid, text, text_cls, segment, fps, clip_stride, clip_size, duration).
+        ``batch_videos > 1``: consecutive videos of the same padded length (every video up to max_vid_len is one) share a
+        forward (``model.forward_videos``); same proposals, fewer and larger kernel launches."""
         counter = counter or RecallCounter(self.opt['eval'].get('ranks', (1, 5)), self.opt['eval'].get('iou_threshs', (0.3, 0.5)))
+        if batch_videos > 1:
+            pending = []                              # (data, args, T, ext)
+
+            def flush():
+                if not pending:
+                    return
+                T = pending[0][2]
+                t0 = time.perf_counter()
+                self.model.forward_videos([p[1] for p in pending])
+                self.time_dict['forward'].append(time.perf_counter() - t0)
+                logits, offsets, masks = self.model._last_flat
+                q = 0
+                for data, args, _, ext in pending:
+                    n = len(args[3])
+                    res = self.generate_proposals((logits[q:q + n], offsets[q:q + n], masks[q:q + n]), T, data, ext)
+                    counter.update(res, data['segment'])
+                    q += n
+                pending.clear()
+
+            for data in dataset:
+                args, T, ext = self.prepare(data)
+                if pending and (pending[0][2] != T or len(pending) == batch_videos):
+                    flush()
+                pending.append((data, args, T, ext))
+            flush()
+            self._check_numerics([self.model])
+            return counter
         if n_streams <= 1:
             for data in dataset:
                 counter.update(self.predict(data), data['segment'])

@@ -469,6 +469,75 @@ class PtTransformerEarlyFusionIterative(nn.Module):
             self._engine = _Engine(self._config())
         return self._position_encoding(T, device)
 
+    def forward_videos(self, videos):
+        """Throughput extension (no reference counterpart: model.py:496 asserts one video per call): several videos of the
+        SAME padded length in one forward (dcf_forward_eval_videos).  ``videos``: sequence of tuples
+        ``(vid (1,D,T), shallow_vid (1,D,T), vid_masks (1,T), text: tuple, text_cls (NQ,D), text_masks: tuple)`` --
+        the arguments of ``forward`` per video.  Returns a list with, per video, what ``forward(..., eval=True)`` returns."""
+        assert len(videos) >= 1
+        if not videos[0][0].is_cuda:
+            raise RuntimeError('the grounding forward runs on the MI355X only: move the inputs to the GPU')
+        dev = videos[0][0].device
+        if self._engine is None:
+            self._engine = _Engine(self._config())
+        eng = self._engine
+        eng.bind(self._named_engine_tensors())
+        lib = eng.lib
+        T = videos[0][0].size(-1)
+        nv = len(videos)
+        keep = []
+        vptr, sptr, mptr_v, cptr = ((ctypes.c_void_p * nv)() for _ in range(4))
+        nqs = (ctypes.c_int32 * nv)()
+        flat_text, flat_masks = [], []
+        for v, (vid, shallow, vmask, text, text_cls, tmasks) in enumerate(videos):
+            assert vid.size(0) == 1 and vid.size(-1) == T, 'videos of one call share the padded length'
+            vc, sc = vid[0].contiguous().float(), shallow[0].contiguous().float()
+            mc = vmask.reshape(-1).to(torch.bool).contiguous()
+            if not isinstance(text, (tuple, list)):
+                text, tmasks = (text,), (tmasks,)
+            cc = text_cls.contiguous().float()
+            assert sc.shape == vc.shape == (self.D, T) and mc.numel() == T and cc.shape == (len(text), self.D)
+            keep += [vc, sc, mc, cc]
+            vptr[v], sptr[v], mptr_v[v], cptr[v], nqs[v] = vc.data_ptr(), sc.data_ptr(), mc.data_ptr(), cc.data_ptr(), len(text)
+            flat_text += list(text)
+            flat_masks += list(tmasks)
+        nq = len(flat_text)
+        tptr, mptr, tlen = (ctypes.c_void_p * nq)(), (ctypes.c_void_p * nq)(), (ctypes.c_int32 * nq)()
+        for q in range(nq):
+            t = flat_text[q][0].contiguous().float()
+            m = flat_masks[q].reshape(-1).to(torch.bool).contiguous()
+            assert t.dim() == 2 and m.numel() == t.size(1)
+            keep += [t, m]
+            tptr[q], mptr[q], tlen[q] = t.data_ptr(), m.data_ptr(), t.size(1)
+        pe = None
+        if self.vid_net.use_abs_pe:
+            pe = self._position_encoding(T, dev)
+            _lib.check(lib.dcf_model_set_pe(eng.handle, _lib.ptr(pe), T), 'dcf_model_set_pe')
+        S = lib.dcf_points_per_query(eng.handle, T)
+        okey = (nq, S, dev)
+        if self.reuse_output_buffers and okey in self._out_cache:
+            logits, offsets, masks = self._out_cache[okey]
+        else:
+            logits = torch.empty(nq, S, device=dev, dtype=torch.float32)
+            offsets = torch.empty(nq, S, 2, device=dev, dtype=torch.float32)
+            masks = torch.empty(nq, S, device=dev, dtype=torch.bool)
+            if self.reuse_output_buffers:
+                self._out_cache = {okey: (logits, offsets, masks)}
+        _lib.check(lib.dcf_forward_eval_videos(eng.handle, nv, vptr, sptr, mptr_v, T, nqs, tptr, mptr, tlen, cptr, _lib.ptr(logits),
+                                               _lib.ptr(offsets), _lib.ptr(masks), _lib.current_stream()), 'dcf_forward_eval_videos')
+        self._last_inputs = (keep, pe)
+        self._last_flat = (logits, offsets, masks)
+        L = self.vid_net.arch[2]
+        sizes = [T >> l for l in range(L)]
+        out, q = [], 0
+        for v in range(nv):
+            n = nqs[v]
+            out.append(([tuple(x.unsqueeze(0) for x in logits[i].split(sizes)) for i in range(q, q + n)],
+                        [tuple(x.unsqueeze(0) for x in offsets[i].split(sizes)) for i in range(q, q + n)],
+                        [tuple(x.unsqueeze(0) for x in masks[i].split(sizes)) for i in range(q, q + n)]))
+            q += n
+        return out
+
     def _drop_forward_eval(self, vid, shallow_vid, vid_masks, text, text_cls, text_masks, text_size=None, mv_data=None,
                            eval=False, gate=None, pe_tokens=None):
         assert mv_data is None and eval

@@ -128,6 +128,17 @@ int dcf_forward_eval_gated(dcf_model* m, const float* vid, const float* shallow_
                            int32_t nq, const float* const* text, const uint8_t* const* text_mask, const int32_t* text_len,
                            const float* gate, float* logits_out, float* offsets_out, uint8_t* masks_out, void* stream);
 
+/* Throughput extension: several videos of the SAME padded length T in one forward (the reference evaluates one video per
+ * call, model.py:496; videos no longer than opt.model.max_vid_len are all padded to that length, worker_v2.py:969-976).
+ * Video v has nq_per_video[v] queries; text / text_mask / text_len and the outputs list the queries of all videos in
+ * video order (sum(nq) entries, outputs (sum(nq), S) ...); text_cls[v] is (nq_per_video[v], D).  After vid_map every
+ * kernel works on rows [query][t], so the result of each query is the one dcf_forward_eval gives for its video alone.
+ * 1 <= nvid <= 16; with nvid > 1 max_batch must be <= 16.  ABI version 3. */
+int dcf_forward_eval_videos(dcf_model* m, int32_t nvid, const float* const* vid, const float* const* shallow_vid,
+                            const uint8_t* const* vid_mask, int64_t T, const int32_t* nq_per_video, const float* const* text,
+                            const uint8_t* const* text_mask, const int32_t* text_len, const float* const* text_cls,
+                            float* logits_out, float* offsets_out, uint8_t* masks_out, void* stream);
+
 /* Debug taps for parity tests: copy an intermediate of the LAST forward chunk into `dst` (device).
  * what: 0 = sidekick scores (nq, T); 1 = gate (B, T); 2 = vid_map output (B*T, E) token-major;
  *       3 = fusion output (B*T, E); 4 = pyramid features (B*S rows [level][b][t], E+32). */
