@@ -171,6 +171,7 @@ struct dcf_model {
   std::vector<const float*> tcn_wd, tcn_bd, tcn_wp, tcn_bp, tcn_lnw, tcn_lnb;
   // text_net (TextTransformer, text_net.py:92-188); empty when cfg.text_layers == 0
   const float *text_embd_w = nullptr, *text_embd_b = nullptr, *text_bkgd = nullptr;
+  TextEncW text_pool{};                      // TextIdentity: attn_pool.attn.{query,key,value,proj} (text_net.py:50-53)
   std::vector<TextEncW> text_enc;
   const float* text_pe = nullptr;            // (text_pe_L, TE) token-major, borrowed
   int64_t text_pe_L = 0;
@@ -354,6 +355,25 @@ static int finalize(dcf_model* m, hipStream_t st) {
 
   m->text_enc.clear();
   m->text_embd_w = m->text_embd_b = m->text_bkgd = nullptr;
+  m->text_pool = TextEncW();
+  if (c.text_kind == 1) {
+    // TextIdentity (text_net.py:22-89): optional 1x1 embedding, optional AttNPool1D token (use_bkgd_token)
+    DCF_CHECK(c.text_in > 0 && c.text_heads >= 1 && TE % c.text_heads == 0, "text_net (identity): in_dim=%d heads=%d do not fit TE=%d", c.text_in, c.text_heads, TE);
+    if (m->bound.count("text_net.embd_fc.conv.weight")) {
+      GET("text_net.embd_fc.conv.weight", SH(TE, c.text_in), m->text_embd_w); GET("text_net.embd_fc.conv.bias", SH(TE), m->text_embd_b);
+    } else {
+      DCF_CHECK(c.text_in == TE, "text_net (identity) without embd_fc needs in_dim == embd_dim (%d vs %d)", c.text_in, TE);
+    }
+    if (c.text_bkgd) {
+      TextEncW& w = m->text_pool;
+      const std::string p = "text_net.attn_pool.attn";
+      GET(p + ".query.weight", SH(TE, TE), w.wq); GET(p + ".query.bias", SH(TE), w.bq);
+      GET(p + ".key.weight", SH(TE, TE), w.wk); GET(p + ".key.bias", SH(TE), w.bk);
+      GET(p + ".value.weight", SH(TE, TE), w.wv); GET(p + ".value.bias", SH(TE), w.bv);
+      GET(p + ".proj.weight", SH(TE, TE), w.wp); GET(p + ".proj.bias", SH(TE), w.bp);
+      SPLIT(w.wq, TE, TE); SPLIT(w.wk, TE, TE); SPLIT(w.wv, TE, TE); SPLIT(w.wp, TE, TE);
+    }
+  } else
   if (c.text_layers > 0 || c.text_in > 0) {
     DCF_CHECK(c.text_in > 0 && c.text_layers >= 0 && c.text_heads >= 1 && TE % c.text_heads == 0,
               "text_net: in_dim=%d layers=%d heads=%d do not fit TE=%d", c.text_in, c.text_layers, c.text_heads, TE);
@@ -1049,7 +1069,7 @@ static int text_encode(dcf_model* m, const float* tokens, const uint8_t* token_m
                        hipStream_t st) {
   const dcf_config& c = m->cfg;
   DCF_CHECK(m->finalized, "dcf_text_encode: model not finalized");
-  DCF_CHECK(m->text_embd_w, "dcf_text_encode: the model was created without a text encoder (text_in / text_layers = 0)");
+  DCF_CHECK(m->text_embd_w || c.text_kind == 1, "dcf_text_encode: the model was created without a text encoder (text_in / text_layers = 0)");
   DCF_CHECK(Lq >= 1 && tokens && text_out && mask_out, "dcf_text_encode: bad arguments");
   const int TE = c.TE, Lk = Lq + (c.text_bkgd ? 1 : 0);
   if (c.text_abs_pe) DCF_CHECK(m->text_pe && m->text_pe_L >= Lq, "text position encoding for %d tokens not set (dcf_model_set_text_pe)", Lq);
@@ -1067,8 +1087,23 @@ static int text_encode(dcf_model* m, const float* tokens, const uint8_t* token_m
   float *X = buf(0), *X2 = buf(1), *R0 = buf(2), *Q = buf(3), *K = buf(4), *V = buf(5), *HID = buf(6);   // HID spans 4 slots
 
   TextEmbedArgs te{tokens, token_mask, m->text_embd_w, m->text_embd_b, c.text_abs_pe ? m->text_pe : nullptr, m->text_bkgd, X, mask_out,
-                   c.text_in, Lq, TE};
+                   c.text_in, Lq, TE, (c.text_kind == 1 && c.text_bkgd) ? 1 : 0};
   TRY(launch_text_embed(te, st));
+  if (c.text_kind == 1) {
+    if (c.text_bkgd) {
+      // AttNPool1D (blocks.py:396-411): h = [masked mean ; x], pooled token = MaskedMHA(h, kv_mask)[..., :1], out = [pool ; x]
+      const TextEncW& w = m->text_pool;
+      GemmArgs g3[3] = {gemm(X, TE, w.wq, w.bq, Q, TE, Lk, TE, TE), gemm(X, TE, w.wk, w.bk, K, TE, Lk, TE, TE),
+                        gemm(X, TE, w.wv, w.bv, V, TE, Lk, TE, TE)};
+      TRY(run_gemm(m, g3, 3, A_ROWS, st));
+      XAttnArgs xa{Q, K, V, mask_out, R0, 1, Lk, Lk, TE, c.text_heads};
+      TRY(launch_xattn(xa, st));
+      GemmArgs gp = gemm(R0, TE, w.wp, w.bp, X, TE, 1, TE, TE);                       // only the pooled row is kept
+      TRY(run_gemm(m, &gp, 1, A_ROWS, st));
+    }
+    TRY(launch_rows_to_chanmajor(X, text_out, Lk, TE, st));
+    return 0;
+  }
   for (const TextEncW& w : m->text_enc) {
     TRY(launch_mask_rows(X, mask_out, Lk, TE, st));                                   // x = x * mask   (blocks.py:581)
     LnArgs ln{}; ln.X = X; ln.ldx = TE; ln.Y = R0; ln.ldy = TE; ln.w = w.ln_attn_w; ln.b = w.ln_attn_b; ln.rows = Lk; ln.C = TE;

@@ -59,6 +59,7 @@ struct TextEmbedArgs {
   float* X;                         // [Lk][TE]
   uint8_t* mask_out;                // [Lk]
   int Ct, Lq, TE;
+  int pool;                         // TextIdentity + AttNPool1D: row 0 = masked mean of the embedded tokens (blocks.py:405)
 };
 int launch_text_embed(const TextEmbedArgs& a, hipStream_t st);
 int launch_mask_rows(float* X, const uint8_t* mask, int rows, int C, hipStream_t st);                 // X[r][:] *= mask[r]

@@ -320,25 +320,46 @@ __global__ __launch_bounds__(64) void k_text_ln(TextLnArgs p) {
 // tokens too, blocks.py:63-106), + pe * mask, background token prepended, mask = cat(mask[:1], mask).
 // One workgroup per output row; a few hundred KFLOP per query, T independent.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float text_embed_one(const TextEmbedArgs& p, int t, int c, float mk) {
+  float acc;
+  if (p.W) {
+    const float* w = p.W + (int64_t)c * p.Ct;
+    acc = 0.f;
+    for (int k = 0; k < p.Ct; ++k) acc += w[k] * (p.tokens[(int64_t)k * p.Lq + t] * mk);
+    acc += p.bias ? p.bias[c] : 0.f;
+  } else {
+    acc = p.tokens[(int64_t)c * p.Lq + t];               // TextIdentity without embd_fc: the raw token, not masked
+  }
+  if (p.pe) acc += p.pe[(int64_t)t * p.TE + c] * mk;
+  return acc;
+}
+
 __global__ __launch_bounds__(256) void k_text_embed(TextEmbedArgs p) {
   const int j = blockIdx.x;                              // output row
-  const int off = p.bkgd ? 1 : 0;
+  const int off = (p.bkgd || p.pool) ? 1 : 0;
   float* out = p.X + (int64_t)j * p.TE;
   if (j < off) {
-    for (int c = threadIdx.x; c < p.TE; c += 256) out[c] = p.bkgd[c];
+    if (p.pool) {
+      // masked_avg_pool1d (blocks.py:10-17): sum_t x[t] * mask[t] / sum_t mask[t], tokens summed in order
+      float n = 0.f;
+      for (int t = 0; t < p.Lq; ++t) n += (!p.mask || p.mask[t]) ? 1.f : 0.f;
+      for (int c = threadIdx.x; c < p.TE; c += 256) {
+        float s = 0.f;
+        for (int t = 0; t < p.Lq; ++t) {
+          const float mk = (!p.mask || p.mask[t]) ? 1.f : 0.f;
+          s += text_embed_one(p, t, c, mk) * mk;
+        }
+        out[c] = s / n;
+      }
+    } else {
+      for (int c = threadIdx.x; c < p.TE; c += 256) out[c] = p.bkgd[c];
+    }
     if (threadIdx.x == 0) p.mask_out[0] = p.mask ? p.mask[0] : 1;
     return;
   }
   const int t = j - off;
   const float mk = (!p.mask || p.mask[t]) ? 1.f : 0.f;
-  for (int c = threadIdx.x; c < p.TE; c += 256) {
-    const float* w = p.W + (int64_t)c * p.Ct;
-    float acc = 0.f;
-    for (int k = 0; k < p.Ct; ++k) acc += w[k] * (p.tokens[(int64_t)k * p.Lq + t] * mk);
-    acc += p.bias ? p.bias[c] : 0.f;
-    if (p.pe) acc += p.pe[(int64_t)t * p.TE + c] * mk;
-    out[c] = acc;
-  }
+  for (int c = threadIdx.x; c < p.TE; c += 256) out[c] = text_embed_one(p, t, c, mk);
   if (threadIdx.x == 0) p.mask_out[j] = mk != 0.f;
 }
 
@@ -453,7 +474,8 @@ int launch_enc_pre(const EncPreArgs& a_, int stride, hipStream_t st) {
 
 int launch_text_embed(const TextEmbedArgs& a, hipStream_t st) {
   DCF_CHECK(a.Lq >= 1 && a.Ct >= 1 && a.TE >= 1, "text_embed: empty input");
-  const int Lk = a.Lq + (a.bkgd ? 1 : 0);
+  const int Lk = a.Lq + ((a.bkgd || a.pool) ? 1 : 0);
+  DCF_CHECK(a.W || a.Ct == a.TE, "text_embed: no embedding weight needs in_dim == embd_dim");
   hipLaunchKernelGGL(k_text_embed, dim3(Lk), dim3(256), 0, st, a);
   DCF_HIP(hipGetLastError());
   return 0;

@@ -256,6 +256,65 @@ class TextTransformer(nn.Module):
                            'which runs the text encoder on the MI355X (dcf_text_encode); there is no CPU path')
 
 
+class _MHAParams(nn.Module):
+    """parameter names of MaskedMHA (blocks.py:166-201): query / key / value / proj 1x1 convolutions"""
+
+    def __init__(self, embd_dim):
+        super().__init__()
+        self.query = nn.Conv1d(embd_dim, embd_dim, 1)
+        self.key = nn.Conv1d(embd_dim, embd_dim, 1)
+        self.value = nn.Conv1d(embd_dim, embd_dim, 1)
+        self.proj = nn.Conv1d(embd_dim, embd_dim, 1)
+
+
+class _AttNPool1D(nn.Module):
+    """AttNPool1D (blocks.py:396-411): parameter container (`attn_pool.attn.*`)"""
+
+    def __init__(self, embd_dim, n_heads):
+        super().__init__()
+        self.attn = _MHAParams(embd_dim)
+        self.n_heads = n_heads
+
+
+class TextIdentity(nn.Module):
+    """text_net.py:22-89 (`opt.model.text_net.name == 'identity'`): optional 1x1 embedding, optional position encoding,
+    an attention-pooled summary token in place of the learned background token.  Parameter container: the forward runs
+    on the MI355X (dcf_text_encode, dcf_config.text_kind = 1)."""
+
+    def __init__(self, in_dim, embd_dim, max_seq_len, n_heads=4, use_abs_pe=False, use_bkgd_token=True, **_):
+        super().__init__()
+        self.max_seq_len, self.n_heads, self.in_dim = max_seq_len, n_heads, in_dim
+        self.embd_fc = MaskedConv1D(in_dim, embd_dim, 1) if embd_dim is not None else None
+        self.embd_dim = embd_dim if embd_dim is not None else in_dim
+        self.use_abs_pe, self.use_bkgd_token = bool(use_abs_pe), bool(use_bkgd_token)
+        if use_abs_pe:
+            pe = sinusoid_encoding(max_seq_len, self.embd_dim // 2) / self.embd_dim ** 0.5
+            self.register_buffer('pe', pe, persistent=False)
+        else:
+            self.pe = None
+        self.attn_pool = _AttNPool1D(self.embd_dim, n_heads) if use_bkgd_token else None
+        self.transformer = ()
+        for mod in self.modules():
+            if isinstance(mod, nn.Conv1d) and mod.bias is not None:
+                nn.init.zeros_(mod.bias)
+
+    def forward(self, x, mask):
+        raise RuntimeError('TextIdentity is a parameter container here: call model.encode_text(tokens, token_masks), '
+                           'which runs the text path on the MI355X (dcf_text_encode); there is no CPU path')
+
+
+def make_text_net(tn):
+    """make_text_net (text_net.py:191-193): 'transformer' or 'identity'"""
+    tn = dict(tn)
+    name = tn.pop('name', 'transformer')
+    if name == 'transformer':
+        return TextTransformer(**tn)
+    if name == 'identity':
+        tn.pop('n_layers', None)
+        return TextIdentity(**tn)
+    raise NotImplementedError(f'text_net.name = {name!r}: only the transformer and identity text backbones are supported')
+
+
 # ------------------------------------------------------------------------------------------
 # the model
 # ------------------------------------------------------------------------------------------
@@ -300,6 +359,7 @@ class _Engine:
 def _text_config(c, tn):
     c.text_in, c.text_layers, c.text_heads = tn.in_dim, len(tn.transformer), tn.n_heads
     c.text_abs_pe, c.text_bkgd = int(tn.use_abs_pe), int(tn.use_bkgd_token)
+    c.text_kind = int(isinstance(tn, TextIdentity))
 
 
 def _encode_text(model, tokens, token_masks):
@@ -355,8 +415,8 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         mo = copy.deepcopy(mo)
         self.opt = opt
         vn, tn, fu = dict(mo['vid_net']), dict(mo['text_net']), dict(mo['fusion'])
-        if vn.get('name', 'transformer') != 'transformer' or tn.get('name', 'transformer') != 'transformer':
-            raise NotImplementedError('only the transformer video / text backbones are supported')
+        if vn.get('name', 'transformer') != 'transformer':
+            raise NotImplementedError('only the transformer video backbone is supported')
         self.sn, self.sratio = int(mo['sn']), float(mo['sratio'])
         self.msf, self.norm = bool(mo['msf']), bool(mo['norm'])
         self.scat, self.sfonly = bool(mo.get('scat', False)), bool(mo.get('sfonly', False))
@@ -367,8 +427,7 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         D = map_in if (self.msf and self.sfonly) else in_dim
         self.D, self.E = D, E
 
-        tn.pop('name', None)
-        self.text_net = TextTransformer(**tn)
+        self.text_net = make_text_net(tn)
         self.vid_map = MaskedConv1D(map_in + int(self.scat), E, 1)
         vn.pop('name', None)
         vn['in_dim'] = E
@@ -622,8 +681,7 @@ class PtTransformer(PtTransformerEarlyFusionIterative):
         self.scat, self.sfonly = bool(mo.get('scat', False)), False     # model.py:30-161 never reads opt.model.sfonly
         D, E = int(vn['in_dim']), int(vn['embd_dim'])
         self.D, self.E = D, E
-        tn.pop('name', None)
-        self.text_net = TextTransformer(**tn)
+        self.text_net = make_text_net(tn)
         vn.pop('name', None)
         vn['in_dim'] = (2 * D if self.msf else D) + int(self.scat)      # model.py:43-48
         self.vid_net = VideoTransformer(**vn)

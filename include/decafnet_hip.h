@@ -63,6 +63,8 @@ typedef struct dcf_config {
                            * (model.py:413-414,550-551; PtTransformer model.py:46-47,128-129)      */
   int32_t sfonly;         /* opt.model.sfonly: with msf, vid_map sees the sidekick features only (model.py:546-547);
                            * D is then the sidekick feature dim = 2 * opt.model.vid_net.in_dim; ignored by model_kind 1 */
+  int32_t text_kind;      /* 0 = TextTransformer (text_net.py:92-188), 1 = TextIdentity (text_net.py:22-89: optional embd_fc,
+                           * optional AttNPool1D token when text_bkgd != 0; text_layers is ignored)  */
 } dcf_config;
 
 int dcf_model_create(const dcf_config* cfg, dcf_model** out);

@@ -414,8 +414,33 @@ def fuse_and_predict(sd: SD, cfg, fpn, fpn_masks, text=None, text_masks=None, se
     return logits1, logits2, offsets, out_masks
 
 
+def text_identity(sd: SD, cfg, tokens: Tensor, token_mask: Tensor, p: str = 'text_net'):
+    """TextIdentity.forward (text_net.py:62-89) with AttNPool1D (blocks.py:396-411) and masked_avg_pool1d (blocks.py:10-17)."""
+    x, mask = tokens, token_mask
+    if mask.dim() == 2:
+        mask = mask.unsqueeze(1)
+    t = x.size(-1)
+    if f'{p}.embd_fc.conv.weight' in sd:
+        x, _ = masked_conv1d(x, mask, sd[f'{p}.embd_fc.conv.weight'], sd.get(f'{p}.embd_fc.conv.bias'))
+    if cfg.get('use_abs_pe', False):
+        e = x.size(1)
+        pe = position_encoding(cfg['max_seq_len'], e)
+        if t > cfg['max_seq_len']:
+            pe = resample_pe(pe, t, cfg['max_seq_len'])
+        x = x + pe[..., :t] * mask.to(x.dtype)
+    if cfg.get('use_bkgd_token', True):
+        x_mean = torch.sum(x * mask.to(x.dtype), dim=-1, keepdim=True) / torch.sum(mask, dim=-1, keepdim=True)
+        h = torch.cat((x_mean, x), dim=-1)
+        mask = torch.cat((mask[..., :1], mask), dim=-1)
+        pool = mha_global(sd, f'{p}.attn_pool.attn', h, h, mask, cfg.get('n_heads', 4))[..., :1]
+        x = torch.cat((pool, x), dim=-1)
+    return x, mask
+
+
 def encode_text(sd: SD, cfg, tokens: Tensor, token_masks: Tensor):
-    """model.py:434-436."""
+    """model.py:434-436 (make_text_net, text_net.py:191-193: 'transformer' or 'identity')."""
+    if cfg['text_net'].get('name', 'transformer') == 'identity':
+        return text_identity(sd, cfg['text_net'], tokens, token_masks)
     return text_transformer(sd, cfg['text_net'], tokens, token_masks)
 
 

@@ -333,6 +333,49 @@ def gen_e2e():
         save(f'e2e_{name}.npz', out)
 
 
+@torch.no_grad()
+def gen_text_identity():
+    """TextIdentity (text_net.py:22-89) in its three shapes -- embedding + attention-pooled token, position encoding with
+    padded tokens, pure identity -- and one model whose text_net is 'identity' (reference encode_text + forward)."""
+    from libs.modeling.text_net import make_text_net
+    from libs.modeling.model import PtTransformerEarlyFusionIterative
+    out = {}
+    cases = [dict(in_dim=48, embd_dim=64, max_seq_len=16, n_heads=4, use_abs_pe=False, use_bkgd_token=True, lq=9, valid=9),
+             dict(in_dim=48, embd_dim=64, max_seq_len=8, n_heads=2, use_abs_pe=True, use_bkgd_token=True, lq=12, valid=7),
+             dict(in_dim=64, embd_dim=None, max_seq_len=16, n_heads=4, use_abs_pe=False, use_bkgd_token=False, lq=5, valid=5)]
+    for i, c in enumerate(cases):
+        kw = {k: v for k, v in c.items() if k not in ('lq', 'valid')}
+        net = make_text_net(dict(name='identity', **kw)).eval()
+        shapes = {k: list(v.shape) for k, v in net.state_dict().items()}
+        sd = synth.make_state_dict(shapes, 700 + i) if shapes else {}
+        net.load_state_dict(sd)
+        g = torch.Generator().manual_seed(710 + i)
+        tok = torch.randn(1, c['in_dim'], c['lq'], generator=g)
+        mask = (torch.arange(c['lq']) < c['valid']).view(1, 1, -1)
+        y, m = net(tok, mask)
+        out[f't{i}/tokens'], out[f't{i}/mask'], out[f't{i}/out'], out[f't{i}/out_mask'] = tok, mask, y, m
+        out[f't{i}/shapes'] = shapes
+    out['cases'] = cases
+    # a model with the identity text path
+    kw = dict(D=64, E=64, TE=32, text_in=32, n_levels=3, win=5, n_heads=2, sn=8, sratio=0.4, msf=True, norm=True,
+              max_seq_len=128, text_max_len=24, text_name='identity')
+    opt = make_opt(**kw)
+    model = PtTransformerEarlyFusionIterative(opt.clone(), second_fusion=False).eval()
+    shapes = {k: list(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(synth.make_state_dict(shapes, 720))
+    inp = synth.make_inputs(64, 128, 111, 2, 32, 6, 721)
+    texts, tmasks = zip(*[model.encode_text(t[None], torch.ones(1, 1, t.size(-1), dtype=torch.bool)) for t in inp['tokens']])
+    logits, offsets, masks = model(inp['vid'], inp['shallow_vid'], inp['vid_masks'], tuple(texts), inp['text_cls'], tuple(tmasks), eval=True)
+    out['model/opt_kwargs'] = kw
+    out['model/meta'] = dict(T=128, vid_len=111, nq=2, lq=6, wseed=720, iseed=721)
+    out['model/shapes'] = shapes
+    for q in range(2):
+        out[f'model/q{q}/text'], out[f'model/q{q}/text_mask'] = texts[q], tmasks[q]
+        for l in range(3):
+            out[f'model/q{q}/l{l}/logits'], out[f'model/q{q}/l{l}/offsets'], out[f'model/q{q}/l{l}/mask'] = logits[q][l], offsets[q][l], masks[q][l]
+    save('text_identity.npz', out)
+
+
 # ------------------------------------------------------------------ G4: post-processing
 @torch.no_grad()
 def gen_postproc():
@@ -492,6 +535,8 @@ if __name__ == '__main__':
         gen_e2e()
     if 'variants' in which or 'e2e' in which:
         gen_e2e_variants()
+    if 'text_identity' in which or 'e2e' in which:
+        gen_text_identity()
     if 'postproc' in which:
         gen_postproc()
     if 'postproc_ext' in which or 'postproc' in which:

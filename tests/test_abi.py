@@ -67,6 +67,17 @@ def test_parameter_abi_matches_reference(name):
     assert repr(opt) == before, 'the constructor must not mutate opt (the reference does, model.py:426-428)'
 
 
+def test_text_identity_parameter_abi():
+    """opt.model.text_net.name == 'identity': state_dict keys / shapes of the reference (text_net.attn_pool.attn.*)"""
+    pkg = load_pkg()
+    g = Golden('text_identity.npz')
+    model = pkg.modeling.create_model(pkg.config.make_opt(**g.js('model/opt_kwargs')))
+    assert {k: list(v.shape) for k, v in model.state_dict().items()} == g.js('model/shapes')
+    assert isinstance(model.text_net, pkg.modeling.TextIdentity)
+    with pytest.raises(RuntimeError):
+        model.text_net(torch.zeros(1, 32, 4), torch.ones(1, 1, 4, dtype=torch.bool))
+
+
 def test_points_match_reference_and_text_encoder_has_no_cpu_path():
     pkg = load_pkg()
     g = Golden('e2e_c1.npz')

@@ -244,3 +244,28 @@ def test_secondary_compositions(name):
             close(out[0][q][l], g.t(f'q{q}/l{l}/logits'), atol=1e-4, rtol=1e-4)
             close(out[1][q][l], g.t(f'q{q}/l{l}/offsets'), atol=1e-4, rtol=1e-4)
             assert torch.equal(out[2][q][l], g.t(f'q{q}/l{l}/mask'))
+
+
+def test_text_identity():
+    """TextIdentity + AttNPool1D restatement (text_net.py:22-89, blocks.py:396-411) vs the reference, alone and inside a model"""
+    g = Golden('text_identity.npz')
+    pkg = load_pkg()
+    for i, c in enumerate(g.js('cases')):
+        shapes = g.js(f't{i}/shapes')
+        sd = {'text_net.' + k: v for k, v in pkg.synth.make_state_dict(shapes, 700 + i).items()} if shapes else {}
+        cfg = dict(name='identity', max_seq_len=c['max_seq_len'], n_heads=c['n_heads'], use_abs_pe=c['use_abs_pe'], use_bkgd_token=c['use_bkgd_token'])
+        y, m = R.text_identity(sd, cfg, g.t(f't{i}/tokens'), g.t(f't{i}/mask'))
+        close(y, g.t(f't{i}/out'), atol=1e-5)
+        assert torch.equal(m, g.t(f't{i}/out_mask'))
+    kw, meta = g.js('model/opt_kwargs'), g.js('model/meta')
+    opt = pkg.config.make_opt(**kw)
+    sd = pkg.synth.make_state_dict(g.js('model/shapes'), meta['wseed'])
+    inp = pkg.synth.make_inputs(kw['D'], meta['T'], meta['vid_len'], meta['nq'], kw['text_in'], meta['lq'], meta['iseed'])
+    texts, tmasks = zip(*[R.encode_text(sd, opt.model, t[None], torch.ones(1, 1, t.size(-1), dtype=torch.bool)) for t in inp['tokens']])
+    lg, of, mk = R.forward_eval(sd, opt.model, inp['vid'], inp['shallow_vid'], inp['vid_masks'], list(texts), inp['text_cls'], list(tmasks))
+    for q in range(meta['nq']):
+        close(texts[q], g.t(f'model/q{q}/text'), atol=1e-5)
+        for l in range(kw['n_levels']):
+            close(lg[q][l], g.t(f'model/q{q}/l{l}/logits'), atol=1e-4, rtol=1e-4)
+            close(of[q][l], g.t(f'model/q{q}/l{l}/offsets'), atol=1e-4, rtol=1e-4)
+            assert torch.equal(mk[q][l], g.t(f'model/q{q}/l{l}/mask'))
