@@ -242,6 +242,9 @@ def main():
         # HBM-side bytes per launch of this kernel family: rocprofv3 PMC passes cannot run inside this process, so the
         # figure comes from the committed summary of tools/pmc_traffic.sh (same command, same build); null if absent
         try:
+            # the committed summary was collected on the DEFAULT workload: only a default run may quote it
+            if (args.T, args.nq, args.videos, args.batch, args.vid_len) != (16384, 1, 3, 3, 0):
+                raise KeyError('non-default workload')
             with open(os.path.join(ROOT, 'profiles', 'r01_pmc_gemm_traffic.json')) as fh:
                 pmc = json.load(fh).get({6: 'gemm_bf16s', 3: 'gemm_f16x3', 0: 'gemm_f32'}[terms])
             if pmc:
