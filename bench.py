@@ -249,6 +249,10 @@ def main():
                 pmc = json.load(fh).get({6: 'gemm_bf16s', 3: 'gemm_f16x3', 0: 'gemm_f32'}[terms])
             if pmc:
                 result['roofline']['traffic'] = pmc['hbm_bytes_per_launch']
+                # the other roofline of the same kernels: with f16x3 the fp32 activations are the larger cost
+                gbps = pmc['hbm_bytes_per_launch'] / (1e-6 * result['roofline']['avg_launch_us']) / 1e9
+                result['roofline']['hbm_view'] = {'achieved': gbps, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbps / PEAK_HBM_GBS,
+                                                  'note': 'HBM-side bytes per launch (PMC) / average launch time of the GEMM family'}
                 result['roofline']['traffic_note'] = ('bytes per launch, FETCH_SIZE x2 + WRITE_SIZE from two rocprofv3 --pmc passes '
                                                       '(profiles/r01_pmc_gemm_traffic.json, tools/pmc_traffic.sh); algorithmic '
                                                       'operand bytes per launch: %.3e' % (d['bytes'] / d['count']))
