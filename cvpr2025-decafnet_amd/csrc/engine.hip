@@ -655,6 +655,23 @@ static int run_gemm(dcf_model* m, GemmArgs* g, int count, GemmAMode mode, hipStr
   return split ? launch_gemm_split(g, count, mode, terms, st) : launch_gemm(g, count, mode, st);
 }
 
+// fc + GELU + proj as one kernel (ffn_f16.hip): f16x3 images for both weights, E = 128 / 256, enough rows
+static int run_ffn(dcf_model* m, const float* X, const float* fc_w, const float* fc_b, GemmArgs go, float* HID, int rows, int E,
+                   hipStream_t st) {
+  static const long min_rows = getenv("DCF_FFN_FUSE_MIN_ROWS") ? atol(getenv("DCF_FFN_FUSE_MIN_ROWS")) : 1000000000L;
+  const bool fused = !go.ln_w && rows >= min_rows && ffn_fused_supported(E) && m->wsplit.count(fc_w) && m->wsplit.count(go.W) &&
+                     m->wsplit_terms[fc_w] == GEMM_F16X3 && m->wsplit_terms[go.W] == GEMM_F16X3 &&
+                     m->wsplit_ldw[fc_w] == E && m->wsplit_ldw[go.W] == 4 * E;
+  if (fused) {
+    go.A = X; go.lda = E; go.Ws = m->wsplit[go.W]; go.status = m->status;
+    return launch_ffn_f16(go, m->wsplit[fc_w], fc_b, st);
+  }
+  GemmArgs gf = gemm(X, E, fc_w, fc_b, HID, 4 * E, rows, 4 * E, E);
+  gf.flags = G_GELU;
+  TRY(run_gemm(m, &gf, 1, A_ROWS, st));
+  return run_gemm(m, &go, 1, A_ROWS, st);
+}
+
 // can this GEMM carry its LayerNorm in the epilogue?  (bf16-split path with planes for W, tile spanning the row)
 static bool can_fuse_ln(dcf_model* m, const float* W, int M, int N, int K, GemmAMode mode) {
   return m->gemm_terms != 0 && m->wsplit.count(W) && m->wsplit_ldw[W] == K && gemm_can_fuse_ln(M, N, K, mode);
@@ -689,13 +706,10 @@ static int run_encoder(dcf_model* m, const EncW& w, Buffers& b, const float* Xin
     LnArgs ln{}; ln.X = b.R[1]; ln.ldx = E; ln.Y = b.R[2]; ln.ldy = E; ln.w = w.ln_ffn_w; ln.b = w.ln_ffn_b; ln.rows = rows; ln.C = E;
     TRY(launch_ln(ln, st));
   }
-  GemmArgs gf = gemm(b.R[2], E, w.fc_w, w.fc_b, b.HID, 4 * E, rows, 4 * E, E);
-  gf.flags = G_GELU;
-  TRY(run_gemm(m, &gf, 1, A_ROWS, st));
   // out = x' + ls_ffn * ((ffn) * mask)                                  (blocks.py:589-590)
   GemmArgs go = gemm(b.HID, 4 * E, w.pj_w, w.pj_b, Xout, ldo, rows, E, 4 * E);
   go.flags = G_RES | G_OUT_MASK; go.rowmask = mask_out; go.ls = w.ls_ffn; go.R = b.R[1]; go.ldr = E;
-  TRY(run_gemm(m, &go, 1, A_ROWS, st));
+  TRY(run_ffn(m, b.R[2], w.fc_w, w.fc_b, go, b.HID, rows, E, st));
   return 0;
 }
 
@@ -812,18 +826,19 @@ static int run_fusion(dcf_model* m, Buffers& b, float* X, int64_t ldx, int B, in
     GemmArgs gh = gemm(b.R[0], E, w.wp, w.bp, b.H2, 2 * E, rows, 2 * E, E);
     TRY(run_gemm(m, &gh, 1, A_ROWS, st));
     TRY(launch_dec_mid(b.R[1], b.H2, w.ln_ffn_w, w.ln_ffn_b, b.R[2], b.R[0], rows, E, st));
-    GemmArgs gf = gemm(b.R[0], E, w.fc_w, w.fc_b, b.HID, 4 * E, rows, 4 * E, E);
-    gf.flags = G_GELU;
-    TRY(run_gemm(m, &gf, 1, A_ROWS, st));
     GemmArgs go = gemm(b.HID, 4 * E, w.pj_w, w.pj_b, X, ldx, rows, E, 4 * E);
     go.flags = G_RES | G_OUT_MASK; go.rowmask = mask; go.ls = w.ls_ffn; go.R = b.R[2]; go.ldr = E;
-    if (li + 1 == m->dec.size() && can_fuse_ln(m, w.pj_w, rows, E, 4 * E, A_ROWS)) {
+    static const bool ffn_first = getenv("DCF_FFN_FUSE_MIN_ROWS") != nullptr;   // the fused FFN has no LayerNorm epilogue
+    if (li + 1 == m->dec.size() && !ffn_first && can_fuse_ln(m, w.pj_w, rows, E, 4 * E, A_ROWS)) {
       // last layer: only ln_out(x) is consumed afterwards (fusion.py:64-66), the raw stream is not written
+      GemmArgs gf = gemm(b.R[0], E, w.fc_w, w.fc_b, b.HID, 4 * E, rows, 4 * E, E);
+      gf.flags = G_GELU;
+      TRY(run_gemm(m, &gf, 1, A_ROWS, st));
       go.C = nullptr; go.ln_w = m->fus_out_w; go.ln_b = m->fus_out_b; go.Y = out; go.ldy = ld_out;
       TRY(run_gemm(m, &go, 1, A_ROWS, st));
       return 0;
     }
-    TRY(run_gemm(m, &go, 1, A_ROWS, st));
+    TRY(run_ffn(m, b.R[0], w.fc_w, w.fc_b, go, b.HID, rows, E, st));
   }
   LnArgs ln{}; ln.X = X; ln.ldx = ldx; ln.Y = out; ln.ldy = ld_out; ln.w = m->fus_out_w; ln.b = m->fus_out_b; ln.rows = rows; ln.C = E;
   TRY(launch_ln(ln, st));
@@ -1462,6 +1477,26 @@ int dcf_op_linear_split(const float* A, const float* W, const float* bias, float
     rc = dcf::launch_gemm_split(&g, 1, dcf::A_ROWS, nterms, st);
   }
   DCF_HIP(hipFreeAsync(planes, st));
+  return rc;
+}
+
+int dcf_op_ffn(const float* X, const float* W1, const float* b1, const float* W2, const float* b2, const float* R, const float* ls,
+               const uint8_t* rowmask, float* C, int32_t M, int32_t E, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DCF_CHECK(dcf::ffn_fused_supported(E), "dcf_op_ffn: E = %d unsupported (128 or 256)", E);
+  unsigned short *p1 = nullptr, *p2 = nullptr;
+  DCF_HIP(hipMallocAsync((void**)&p1, (size_t)3 * 4 * E * E * sizeof(unsigned short), st));
+  DCF_HIP(hipMallocAsync((void**)&p2, (size_t)3 * 4 * E * E * sizeof(unsigned short), st));
+  int rc = dcf::launch_split_planes(W1, p1, 4 * E, E, E, st, dcf::GEMM_F16X3);
+  if (rc == 0) rc = dcf::launch_split_planes(W2, p2, E, 4 * E, 4 * E, st, dcf::GEMM_F16X3);
+  if (rc == 0) {
+    dcf::GemmArgs g = dcf::gemm(X, E, W2, b2, C, E, M, E, 4 * E);
+    g.Ws = p2;
+    if (R) { g.flags = dcf::G_RES | (rowmask ? dcf::G_OUT_MASK : 0); g.R = R; g.ldr = E; g.ls = ls; g.rowmask = rowmask; }
+    rc = dcf::launch_ffn_f16(g, p1, b1, st);
+  }
+  DCF_HIP(hipFreeAsync(p1, st));
+  DCF_HIP(hipFreeAsync(p2, st));
   return rc;
 }
 

@@ -1,0 +1,240 @@
+// Fused FFN (blocks.py:535-538 inside TransformerEncoder / TransformerDecoder): Y = epilogue(GELU(X W1^T + b1) W2^T + b2)
+// in ONE kernel, f16x3 arithmetic (see gemm_bf16s.hip), so that the 4E-wide hidden activations never leave the CU.
+//
+// Why: with several videos per forward the two FFN GEMMs are bound by the traffic of their fp32 activations -- fc reads
+// M x E and WRITES M x 4E floats, proj reads them back (251 MB each way at M = 49152, E = 256; ~3 TB/s sustained, 85-91 us
+// per GEMM whatever the tile).  Here a workgroup owns 64 rows: the X tile is split once into two fp16 planes in LDS, the
+// hidden dimension is walked in 4 chunks of E columns -- GEMM 1 of a chunk (K = E) -> bias, GELU, split -> LDS as the A
+// operand of GEMM 2 of the chunk (K = E of the 4E) -- and the E-wide output accumulators stay in registers across the
+// chunks.  HBM traffic: M x E in, M x E out (+ the residual); both weight images (2 x 2 MiB at E = 256 in two planes)
+// stream from L2 once per 64-row tile: 43 B/clk/CU at full MFMA rate.
+//
+// Four waves side by side along the columns, wave tile 64 x (TN * 32), E = TN * 128.  LDS: X planes and H planes
+// [2][64][E * 2 + 16 B] (row pitch = 4 dwords mod 64: conflict-free ds_read_b128) + a wave-private transpose tile each:
+// 150 KiB at E = 256, one workgroup per CU.
+//
+// STATUS: correct (tests/test_gpu_ops.py::test_fused_ffn, and end to end with DCF_FFN_FUSE_MIN_ROWS=64) but NOT the
+// default: measured at M = 49152, E = 256 the kernel takes 300 us (172 TFLOP/s) against 175 us for the fc + proj pair --
+// with one wave per SIMD (150 KiB of LDS) the GELU epilogue (20 k cycles per tile), the A-fragment LDS reads (16 k) and
+// the weight stream (32 k) serialise with the 49 k MFMA cycles instead of overlapping them; the 32-row variant (two
+// workgroups per CU) doubles the weight bytes per row and is slower still (450 us).  Enabled by
+// DCF_FFN_FUSE_MIN_ROWS=<rows>; kept as the starting point for a version with two waves per SIMD.
+#include <cstdio>
+#include <cstdlib>
+
+#include "gemm_common.h"
+
+namespace dcf {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr float FFN_SA = 16.f, FFN_SW = 256.f;          // the f16x3 operand scales of gemm_bf16s.hip
+constexpr int FFN_BLK = 2 * 3 * 64 * 8;                 // elements of one weight-image block (gemm_bf16s.hip)
+
+__device__ __forceinline__ void ffn_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+  const f16x2 h = __builtin_convertvector(f32x2{x0 * FFN_SA, x1 * FFN_SA}, f16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  const float r0 = __builtin_fmaf(x0, FFN_SA, -(float)h[0]), r1 = __builtin_fmaf(x1, FFN_SA, -(float)h[1]);
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, f16x2));
+}
+
+struct FfnArgs {
+  GemmArgs p;                   // the second GEMM's view: A = X (lda), Ws = W2 image, bias = b2, C, R, ls, rowmask, flags, M, N = E, K = 4E
+  const unsigned short* W1s;    // image of fc.weight (4E, E)
+  const float* b1;              // (4E)
+};
+
+// TM = row tiles of 32 per workgroup (BM = 32 TM).  TM = 1: 75 KiB of LDS at E = 256, two workgroups per CU (the GELU
+// epilogue of one overlaps the MFMAs of the other) at twice the weight bytes per row; TM = 2: 150 KiB, one per CU.
+// The weight fragments of a chunk form ONE stream of 2 KT tiles (KT of W1, then KT of W2) through a four-deep register
+// ring: the tile of step s + 3 -- which may belong to the next product or the next chunk -- is requested at step s.
+template <int TN, int TM>
+__global__ __launch_bounds__(256, TM == 1 ? 2 : 1) void ffn_f16_kernel(FfnArgs a) {
+  constexpr int E = TN * 128, KT = E / 32, NC = 4, KT2 = NC * KT, BM = TM * 32;
+  constexpr int ROWX = E * 2 + 16;                      // bytes per (plane, row)
+  constexpr int PLANE = BM * ROWX;
+  constexpr int TPR = 256 / BM, PPT = (E / 8) / TPR;    // threads per row, 8-float pieces per thread
+  constexpr int NS = 4;                                 // depth of the weight-fragment ring
+  static_assert((2 * KT) % NS == 0, "the ring index must be static inside a chunk");
+  extern __shared__ unsigned char smem_f[];
+  unsigned char* Xs = smem_f;                           // [2][BM][ROWX]
+  unsigned char* Hs = smem_f + 2 * PLANE;               // [2][BM][ROWX]
+  float* tile = reinterpret_cast<float*>(smem_f + 4 * PLANE) + (threadIdx.x >> 6) * EPI_WAVE_FLOATS;
+
+  const GemmArgs& p = a.p;
+  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * BM;
+  const int M = p.M;
+  if (m0 >= M) return;
+
+  const bf16x8* w1 = reinterpret_cast<const bf16x8*>(a.W1s) + lane;
+  const bf16x8* w2 = reinterpret_cast<const bf16x8*>(p.Ws) + lane;
+  // step s of chunk c: s < KT -> W1 block (n32 = c * E/32 + wn TN + j, kt = s); else W2 block (n32 = wn TN + j, kt = c KT + s - KT)
+  bf16x8 ring[NS][2][TN][2];                            // [slot][16-k chunk][tile][plane]
+  auto request = [&](int c, int s, bf16x8 (&b)[2][TN][2]) __attribute__((always_inline)) {
+    if (s >= 2 * KT) { s -= 2 * KT; c = c + 1 < NC ? c + 1 : c; }        // into the next chunk (clamped at the end: redundant)
+    const bool first = s < KT;
+    const bf16x8* base = first ? w1 : w2;
+    const int64_t nb = first ? (int64_t)c * (E / 32) + wn * TN : (int64_t)wn * TN;
+    const int64_t ktot = first ? KT : KT2, kt = first ? s : c * KT + (s - KT);
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) b[cc][j][pl] = base[((nb + j) * ktot + kt) * (FFN_BLK / 8) + (cc * 3 + pl) * 64];
+  };
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) request(0, s, ring[s]);
+
+  // ---- X tile -> two fp16 planes in LDS (pieces of 8 floats, TPR consecutive threads read TPR * 32 contiguous bytes)
+  {
+    const int row = tid / TPR;
+    const bool ok = m0 + row < M;
+    const float* src = p.A + (int64_t)(ok ? m0 + row : 0) * p.lda;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const int pc = j * TPR + (tid % TPR);             // piece of 8 floats
+      f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        v0 = *reinterpret_cast<const f32x4*>(src + pc * 8);
+        v1 = *reinterpret_cast<const f32x4*>(src + pc * 8 + 4);
+      }
+      unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+      ffn_split2(v0.x, v0.y, h0, l0); ffn_split2(v0.z, v0.w, h1, l1);
+      ffn_split2(v1.x, v1.y, h2, l2); ffn_split2(v1.z, v1.w, h3, l3);
+      *reinterpret_cast<u32x4*>(Xs + row * ROWX + pc * 16) = u32x4{h0, h1, h2, h3};
+      *reinterpret_cast<u32x4*>(Xs + PLANE + row * ROWX + pc * 16) = u32x4{l0, l1, l2, l3};
+    }
+  }
+  __syncthreads();
+
+  f32x16 acc2[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc2[i][j][e] = 0.f;
+
+  const float unscale = 1.f / (FFN_SA * FFN_SW);
+  bool bad = false;
+
+  // K tile kt of one product: A fragments from the LDS planes at As, B fragments from ring slot `b`
+  auto mfmas = [&](f32x16 (&acc)[TM][TN], const unsigned char* As, int kt, const bf16x8 (&b)[2][TN][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      bf16x8 af[TM][2];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+          af[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PLANE + (i * 32 + r) * ROWX + kt * 64 + c * 32 + h * 16);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][0]), __builtin_bit_cast(f16x8, b[c][j][1]), acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][1]), __builtin_bit_cast(f16x8, b[c][j][0]), acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][0]), __builtin_bit_cast(f16x8, b[c][j][0]), acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+
+  const int rr = lane >> 3, c4 = (lane & 7) * 4;        // read-back role of the transpose tile: row rr + 8 q, columns c4 .. c4 + 3
+  for (int c = 0; c < NC; ++c) {
+    // ---- GEMM 1 of the chunk: hidden columns c * E + [wn * TN * 32, ...)
+    f32x16 acc1[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc1[i][j][e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KT; ++s) {
+      request(c, s + NS - 1, ring[(s + NS - 1) % NS]);
+      mfmas(acc1, Xs, s, ring[s % NS]);
+    }
+    // ---- bias, GELU, split -> H planes (through the wave-private transpose tile: 4 consecutive columns of a row per lane)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int colb = (wn * TN + j) * 32 + c4;        // column inside the chunk
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.b1 + c * E + colb);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float v = acc1[i][j][e] * unscale;
+          bad |= !(__builtin_fabsf(v) <= 3.4028234664e38f);
+          tile[((e & 3) + 8 * (e >> 2) + 4 * h) * EPI_PITCH + r] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(tile + (rr + 8 * q) * EPI_PITCH + c4) + bias;
+          v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+          unsigned h0, h1, l0, l1;
+          ffn_split2(v.x, v.y, h0, l0); ffn_split2(v.z, v.w, h1, l1);
+          const int row = i * 32 + rr + 8 * q;
+          *reinterpret_cast<u32x2*>(Hs + row * ROWX + colb * 2) = u32x2{h0, h1};
+          *reinterpret_cast<u32x2*>(Hs + PLANE + row * ROWX + colb * 2) = u32x2{l0, l1};
+        }
+      }
+    __syncthreads();                                     // the chunk of H is complete
+    // ---- GEMM 2 of the chunk: K tiles c * KT .. of the 4E-wide K
+#pragma unroll
+    for (int s = KT; s < 2 * KT; ++s) {
+      request(c, s + NS - 1, ring[(s + NS - 1) % NS]);
+      mfmas(acc2, Hs, s - KT, ring[s % NS]);
+    }
+    __syncthreads();                                     // H may be overwritten
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float v = acc2[i][j][e] * unscale;
+        bad |= !(__builtin_fabsf(v) <= 3.4028234664e38f);
+        acc2[i][j][e] = v;
+      }
+  if (bad && p.status) atomicOr(p.status, 1u);
+  if (gemm_wide_ok(p)) gemm_epilogue_wide<1, 4, TM, TN>(p, acc2, m0, 0, 0, wn, lane, tile);
+  else gemm_epilogue<1, 4, TM, TN>(p, acc2, m0, 0, 0, wn, r, h);
+}
+
+bool ffn_fused_supported(int E) { return E == 128 || E == 256; }
+
+// p: the proj GEMM as launch_gemm_split would take it (A = the fc input X, K = 4E, N = E, Ws = proj image, bias = proj bias);
+// W1s / b1: fc image and bias.  Both images must be f16x3 images.
+int launch_ffn_f16(const GemmArgs& p, const unsigned short* W1s, const float* b1, hipStream_t st) {
+  const int E = p.N;
+  DCF_CHECK(ffn_fused_supported(E) && p.K == 4 * E, "launch_ffn_f16: E=%d K=%d unsupported", E, p.K);
+  DCF_CHECK(p.A && p.Ws && W1s && b1 && p.bias && p.C && p.lda % 4 == 0, "launch_ffn_f16: null / misaligned operand");
+  if (p.M <= 0) return 0;
+  FfnArgs a{p, W1s, b1};
+  static const int tm = getenv("DCF_FFN_TM") ? atoi(getenv("DCF_FFN_TM")) : 2;
+  const int bm = tm == 2 ? 64 : 32;
+  const int rowx = E * 2 + 16;
+  const size_t lds = (size_t)4 * bm * rowx + (size_t)4 * EPI_WAVE_FLOATS * sizeof(float);
+  ProfScope prof("ffn_fused_f16x3", st, 2.0 * 2.0 * p.M * (double)E * 4.0 * E, 4.0 * (3.0 * p.M * E + 2.0 * 8.0 * E * E));
+  dim3 grid((p.M + bm - 1) / bm);
+#define FFN_LAUNCH(TN_, TM_) do { \
+    static bool done = false; \
+    if (!done) { DCF_HIP(hipFuncSetAttribute((const void*)ffn_f16_kernel<TN_, TM_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; } \
+    hipLaunchKernelGGL((ffn_f16_kernel<TN_, TM_>), grid, dim3(256), lds, st, a); } while (0)
+  if (E == 256) { if (tm == 2) FFN_LAUNCH(2, 2); else FFN_LAUNCH(2, 1); }
+  else { if (tm == 2) FFN_LAUNCH(1, 2); else FFN_LAUNCH(1, 1); }
+#undef FFN_LAUNCH
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace dcf
