@@ -18,7 +18,10 @@
 // with one wave per SIMD (150 KiB of LDS) the GELU epilogue (20 k cycles per tile), the A-fragment LDS reads (16 k) and
 // the weight stream (32 k) serialise with the 49 k MFMA cycles instead of overlapping them; the 32-row variant (two
 // workgroups per CU) doubles the weight bytes per row and is slower still (450 us).  Enabled by
-// DCF_FFN_FUSE_MIN_ROWS=<rows>; kept as the starting point for a version with two waves per SIMD.
+// DCF_FFN_FUSE_MIN_ROWS=<rows>.  The warp-specialised variant below (DCF_FFN_TM=3: producer waves run GEMM 1 + GELU of
+// unit u while consumer waves run GEMM 2 of unit u - 1, two waves per SIMD) overlaps the phases and reaches 255 us, but
+// its 32-row units fetch every weight fragment twice: 4 MB of weights per 64-row tile = 12.4 TB/s of L2 -> CU traffic over
+// the chip, which is where that path saturates in practice.  The floor for 64-row tiles (2 MB per tile) is ~125 us.
 #include <cstdio>
 #include <cstdlib>
 
@@ -210,6 +213,169 @@ __global__ __launch_bounds__(256, TM == 1 ? 2 : 1) void ffn_f16_kernel(FfnArgs a
   else gemm_epilogue<1, 4, TM, TN>(p, acc2, m0, 0, 0, wn, r, h);
 }
 
+// ---- warp-specialised variant ---------------------------------------------------------------------------------------
+// Eight waves, two per SIMD.  Waves 0-3 ("producers") run GEMM 1 + GELU for units u = (chunk, row half) = 0 .. 7 of the
+// 64-row tile -- 32 rows x E hidden columns each -- into H buffer u & 1; waves 4-7 ("consumers") run GEMM 2 of unit u - 1
+// out of H buffer (u - 1) & 1 into the output accumulators of that row half.  One workgroup barrier per unit; on every
+// SIMD the consumer's MFMAs run under the producer's GELU / split / LDS writes.  Producers stream W1, consumers W2, each
+// through its own four-deep fragment ring.  LDS: X planes [2][64][ROWX], two H buffers [2][32][ROWX], four transpose tiles.
+template <int TN>
+__global__ __launch_bounds__(512, 2) void ffn_f16_ws_kernel(FfnArgs a) {
+  constexpr int E = TN * 128, KT = E / 32, NC = 4, KT2 = NC * KT, NU = 2 * NC;
+  constexpr int ROWX = E * 2 + 16;
+  constexpr int XPL = 64 * ROWX, HPL = 32 * ROWX;       // bytes of one X plane / one H-buffer plane
+  constexpr int NS = 4;
+  static_assert(KT % NS == 0, "ring index static per unit");
+  extern __shared__ unsigned char smem_f[];
+  unsigned char* Xs = smem_f;                           // [2][64][ROWX]
+  unsigned char* Hb = smem_f + 2 * XPL;                 // [2 buffers][2 planes][32][ROWX]
+  const GemmArgs& p = a.p;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool producer = wave < 4;
+  const int wn = wave & 3;
+  const int r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * 64;
+  const int M = p.M;
+  if (m0 >= M) return;
+  float* tile = reinterpret_cast<float*>(smem_f + 2 * XPL + 4 * HPL) + wn * EPI_WAVE_FLOATS;   // producers (and the final epilogue)
+
+  bf16x8 ring[NS][2][TN][2];
+  const bf16x8* wimg = reinterpret_cast<const bf16x8*>(producer ? a.W1s : p.Ws) + lane;
+  // fragment tile t of this wave's stream, t = 0 .. NU * KT - 1 (unit u = t / KT, k tile kt = t % KT, chunk c = u >> 1):
+  // producer: W1 block (n32 = c * E/32 + wn TN + j, kt) of KT;  consumer: W2 block (n32 = wn TN + j, c KT + kt) of KT2
+  auto request = [&](int t, bf16x8 (&b)[2][TN][2]) __attribute__((always_inline)) {
+    if (t >= NU * KT) t = NU * KT - 1;
+    const int u = t / KT, kt = t - u * KT, c = u >> 1;
+    const int64_t nb = producer ? (int64_t)c * (E / 32) + wn * TN : (int64_t)wn * TN;
+    const int64_t ktot = producer ? KT : KT2, kk = producer ? kt : c * KT + kt;
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) b[cc][j][pl] = wimg[((nb + j) * ktot + kk) * (FFN_BLK / 8) + (cc * 3 + pl) * 64];
+  };
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) request(s, ring[s]);
+
+  {  // X tile -> planes, all 512 threads: 8 threads per row, E / 64 pieces of 8 floats each
+    const int row = tid >> 3;
+    const bool ok = m0 + row < M;
+    const float* src = p.A + (int64_t)(ok ? m0 + row : 0) * p.lda;
+#pragma unroll
+    for (int j = 0; j < E / 64; ++j) {
+      const int pc = j * 8 + (tid & 7);
+      f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        v0 = *reinterpret_cast<const f32x4*>(src + pc * 8);
+        v1 = *reinterpret_cast<const f32x4*>(src + pc * 8 + 4);
+      }
+      unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+      ffn_split2(v0.x, v0.y, h0, l0); ffn_split2(v0.z, v0.w, h1, l1);
+      ffn_split2(v1.x, v1.y, h2, l2); ffn_split2(v1.z, v1.w, h3, l3);
+      *reinterpret_cast<u32x4*>(Xs + row * ROWX + pc * 16) = u32x4{h0, h1, h2, h3};
+      *reinterpret_cast<u32x4*>(Xs + XPL + row * ROWX + pc * 16) = u32x4{l0, l1, l2, l3};
+    }
+  }
+  __syncthreads();
+
+  const float unscale = 1.f / (FFN_SA * FFN_SW);
+
+  // 32 rows x (TN * 32) columns, K = E: A fragments at `As` (plane stride `apl`), B fragments = ring tiles t0 .. t0 + KT - 1
+  auto product = [&](f32x16 (&acc)[TN], const unsigned char* As, int apl, int t0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      request(t0 + kt + NS - 1, ring[(kt + NS - 1) % NS]);
+      const bf16x8 (&b)[2][TN][2] = ring[kt % NS];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        bf16x8 af[2];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) af[pl] = *reinterpret_cast<const bf16x8*>(As + pl * apl + r * ROWX + kt * 64 + c * 32 + h * 16);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0]), __builtin_bit_cast(f16x8, b[c][j][1]), acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[1]), __builtin_bit_cast(f16x8, b[c][j][0]), acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0]), __builtin_bit_cast(f16x8, b[c][j][0]), acc[j], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  // step st = 0 .. NU: producers work on unit st (st < NU), consumers on unit st - 1 (st >= 1); one barrier per step.
+  // The two roles are separate code paths (separate register budgets) that execute the same number of barriers.
+  if (producer) {
+    bool bad = false;
+    const int rr = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll 1
+    for (int st = 0; st <= NU; ++st) {
+      if (st < NU) {
+        const int c = st >> 1, hf = st & 1;
+        f32x16 acc1[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc1[j][e] = 0.f;
+        product(acc1, Xs + hf * 32 * ROWX, XPL, st * KT);
+        unsigned char* Hw = Hb + hf * 2 * HPL;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int colb = (wn * TN + j) * 32 + c4;
+          const f32x4 bias = *reinterpret_cast<const f32x4*>(a.b1 + c * E + colb);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float v = acc1[j][e] * unscale;
+            bad |= !(__builtin_fabsf(v) <= 3.4028234664e38f);
+            tile[((e & 3) + 8 * (e >> 2) + 4 * h) * EPI_PITCH + r] = v;
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(tile + (rr + 8 * q) * EPI_PITCH + c4) + bias;
+            v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+            unsigned h0, h1, l0, l1;
+            ffn_split2(v.x, v.y, h0, l0); ffn_split2(v.z, v.w, h1, l1);
+            const int row = rr + 8 * q;
+            *reinterpret_cast<u32x2*>(Hw + row * ROWX + colb * 2) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(Hw + HPL + row * ROWX + colb * 2) = u32x2{l0, l1};
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (bad && p.status) atomicOr(p.status, 1u);
+  } else {
+    bool bad = false;
+    f32x16 acc2[2][TN];                                 // [row half][tile]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[i][j][e] = 0.f;
+    __syncthreads();                                    // step 0: nothing to consume yet
+#pragma unroll 1
+    for (int u = 0; u < NU; u += 2) {                   // units u (row half 0, H buffer 0) and u + 1 (half 1, buffer 1)
+      product(acc2[0], Hb, HPL, u * KT);
+      __syncthreads();
+      product(acc2[1], Hb + 2 * HPL, HPL, (u + 1) * KT);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float v = acc2[i][j][e] * unscale;
+          bad |= !(__builtin_fabsf(v) <= 3.4028234664e38f);
+          acc2[i][j][e] = v;
+        }
+    if (bad && p.status) atomicOr(p.status, 1u);
+    if (gemm_wide_ok(p)) gemm_epilogue_wide<1, 4, 2, TN>(p, acc2, m0, 0, 0, wn, lane, tile);
+    else gemm_epilogue<1, 4, 2, TN>(p, acc2, m0, 0, 0, wn, r, h);
+  }
+}
+
 bool ffn_fused_supported(int E) { return E == 128 || E == 256; }
 
 // p: the proj GEMM as launch_gemm_split would take it (A = the fc input X, K = 4E, N = E, Ws = proj image, bias = proj bias);
@@ -230,6 +396,20 @@ int launch_ffn_f16(const GemmArgs& p, const unsigned short* W1s, const float* b1
     static bool done = false; \
     if (!done) { DCF_HIP(hipFuncSetAttribute((const void*)ffn_f16_kernel<TN_, TM_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; } \
     hipLaunchKernelGGL((ffn_f16_kernel<TN_, TM_>), grid, dim3(256), lds, st, a); } while (0)
+  if (tm == 3) {                                          // warp-specialised: 64 rows, eight waves
+    const size_t lds_ws = (size_t)2 * 64 * rowx + (size_t)4 * 32 * rowx + (size_t)4 * EPI_WAVE_FLOATS * sizeof(float);
+    dim3 grid_ws((p.M + 63) / 64);
+    static bool done_ws[2] = {false, false};
+    if (E == 256) {
+      if (!done_ws[1]) { DCF_HIP(hipFuncSetAttribute((const void*)ffn_f16_ws_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws)); done_ws[1] = true; }
+      hipLaunchKernelGGL(ffn_f16_ws_kernel<2>, grid_ws, dim3(512), lds_ws, st, a);
+    } else {
+      if (!done_ws[0]) { DCF_HIP(hipFuncSetAttribute((const void*)ffn_f16_ws_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws)); done_ws[0] = true; }
+      hipLaunchKernelGGL(ffn_f16_ws_kernel<1>, grid_ws, dim3(512), lds_ws, st, a);
+    }
+    DCF_HIP(hipGetLastError());
+    return 0;
+  }
   if (E == 256) { if (tm == 2) FFN_LAUNCH(2, 2); else FFN_LAUNCH(2, 1); }
   else { if (tm == 2) FFN_LAUNCH(1, 2); else FFN_LAUNCH(1, 1); }
 #undef FFN_LAUNCH
