@@ -1481,9 +1481,9 @@ int dcf_op_linear_split(const float* A, const float* W, const float* bias, float
 }
 
 int dcf_op_ffn(const float* X, const float* W1, const float* b1, const float* W2, const float* b2, const float* R, const float* ls,
-               const uint8_t* rowmask, float* C, int32_t M, int32_t E, void* stream) {
+               const uint8_t* rowmask, float* C, int32_t M, int32_t E, int32_t variant, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  DCF_CHECK(dcf::ffn_fused_supported(E), "dcf_op_ffn: E = %d unsupported (128 or 256)", E);
+  DCF_CHECK(dcf::ffn_fused_supported(E) && variant >= 0 && variant <= 3, "dcf_op_ffn: E = %d (128 or 256) / variant %d (0..3) unsupported", E, variant);
   unsigned short *p1 = nullptr, *p2 = nullptr;
   DCF_HIP(hipMallocAsync((void**)&p1, (size_t)3 * 4 * E * E * sizeof(unsigned short), st));
   DCF_HIP(hipMallocAsync((void**)&p2, (size_t)3 * 4 * E * E * sizeof(unsigned short), st));
@@ -1493,7 +1493,7 @@ int dcf_op_ffn(const float* X, const float* W1, const float* b1, const float* W2
     dcf::GemmArgs g = dcf::gemm(X, E, W2, b2, C, E, M, E, 4 * E);
     g.Ws = p2;
     if (R) { g.flags = dcf::G_RES | (rowmask ? dcf::G_OUT_MASK : 0); g.R = R; g.ldr = E; g.ls = ls; g.rowmask = rowmask; }
-    rc = dcf::launch_ffn_f16(g, p1, b1, st);
+    rc = dcf::launch_ffn_f16(g, p1, b1, st, variant);
   }
   DCF_HIP(hipFreeAsync(p1, st));
   DCF_HIP(hipFreeAsync(p2, st));

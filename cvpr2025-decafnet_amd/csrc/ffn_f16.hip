@@ -380,13 +380,14 @@ bool ffn_fused_supported(int E) { return E == 128 || E == 256; }
 
 // p: the proj GEMM as launch_gemm_split would take it (A = the fc input X, K = 4E, N = E, Ws = proj image, bias = proj bias);
 // W1s / b1: fc image and bias.  Both images must be f16x3 images.
-int launch_ffn_f16(const GemmArgs& p, const unsigned short* W1s, const float* b1, hipStream_t st) {
+int launch_ffn_f16(const GemmArgs& p, const unsigned short* W1s, const float* b1, hipStream_t st, int variant) {
   const int E = p.N;
   DCF_CHECK(ffn_fused_supported(E) && p.K == 4 * E, "launch_ffn_f16: E=%d K=%d unsupported", E, p.K);
   DCF_CHECK(p.A && p.Ws && W1s && b1 && p.bias && p.C && p.lda % 4 == 0, "launch_ffn_f16: null / misaligned operand");
   if (p.M <= 0) return 0;
   FfnArgs a{p, W1s, b1};
-  static const int tm = getenv("DCF_FFN_TM") ? atoi(getenv("DCF_FFN_TM")) : 2;
+  static const int tm_env = getenv("DCF_FFN_TM") ? atoi(getenv("DCF_FFN_TM")) : 2;
+  const int tm = variant ? variant : tm_env;          // 1: 32-row tiles, 2: 64-row tiles, 3: warp-specialised
   const int bm = tm == 2 ? 64 : 32;
   const int rowx = E * 2 + 16;
   const size_t lds = (size_t)4 * bm * rowx + (size_t)4 * EPI_WAVE_FLOATS * sizeof(float);

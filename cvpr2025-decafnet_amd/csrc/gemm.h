@@ -69,7 +69,7 @@ int launch_split_planes(const float* W, unsigned short* out, int N, int K, int64
                         unsigned* overflow = nullptr);
 // fc + GELU + proj of an FFN in one kernel (ffn_f16.hip, f16x3 images): p = the proj GEMM with A = the fc INPUT
 bool ffn_fused_supported(int E);
-int launch_ffn_f16(const GemmArgs& p, const unsigned short* W1s, const float* b1, hipStream_t st);
+int launch_ffn_f16(const GemmArgs& p, const unsigned short* W1s, const float* b1, hipStream_t st, int variant = 0);
 // true if launch_gemm_split can run g with its LayerNorm fused (one tile spans all N columns and the grid still
 // fills the chip); otherwise the caller launches the LayerNorm kernel itself
 bool gemm_can_fuse_ln(int M, int N, int K, GemmAMode mode);

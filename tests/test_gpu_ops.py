@@ -392,8 +392,9 @@ def test_collect_with_ext_scores(L):
         torch.testing.assert_close(segs[q, :n].cpu(), ws, rtol=1e-6, atol=1e-4)
 
 
+@pytest.mark.parametrize('variant', [1, 2, 3])
 @pytest.mark.parametrize('M,E,res', [(64, 128, False), (1000, 256, True), (16500, 256, True), (333, 128, True)])
-def test_fused_ffn(L, M, E, res):
+def test_fused_ffn(L, M, E, res, variant):
     """fc + GELU + proj in one kernel (ffn_f16.hip, f16x3) vs fp64: C = R + ls * (GELU(X W1^T + b1) W2^T + b2) * mask"""
     pkg, lib = L
     g = torch.Generator().manual_seed(M + E)
@@ -413,5 +414,5 @@ def test_fused_ffn(L, M, E, res):
     dev = lambda t: None if t is None else t.cuda()
     Rd, lsd, md = dev(R), dev(ls), dev(mask)
     pkg._lib.check(lib.dcf_op_ffn(P(X.cuda()), P(W1.cuda()), P(b1.cuda()), P(W2.cuda()), P(b2.cuda()), P(Rd) if res else None,
-                                  P(lsd) if res else None, P(md) if res else None, P(C), M, E, st()), 'dcf_op_ffn')
+                                  P(lsd) if res else None, P(md) if res else None, P(C), M, E, variant, st()), 'dcf_op_ffn')
     torch.testing.assert_close(C.cpu().double(), ref, rtol=3e-5, atol=3e-5)
