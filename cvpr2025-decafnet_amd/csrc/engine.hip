@@ -1483,7 +1483,7 @@ int dcf_op_linear_split(const float* A, const float* W, const float* bias, float
 int dcf_op_ffn(const float* X, const float* W1, const float* b1, const float* W2, const float* b2, const float* R, const float* ls,
                const uint8_t* rowmask, float* C, int32_t M, int32_t E, int32_t variant, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  DCF_CHECK(dcf::ffn_fused_supported(E) && variant >= 0 && variant <= 4, "dcf_op_ffn: E = %d (128 or 256) / variant %d (0..4) unsupported", E, variant);
+  DCF_CHECK(dcf::ffn_fused_supported(E) && variant >= 0 && variant <= 6, "dcf_op_ffn: E = %d (128 or 256) / variant %d (0..6) unsupported", E, variant);
   unsigned short *p1 = nullptr, *p2 = nullptr;
   DCF_HIP(hipMallocAsync((void**)&p1, (size_t)3 * 4 * E * E * sizeof(unsigned short), st));
   DCF_HIP(hipMallocAsync((void**)&p2, (size_t)3 * 4 * E * E * sizeof(unsigned short), st));

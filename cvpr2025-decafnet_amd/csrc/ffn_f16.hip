@@ -24,7 +24,8 @@
 // the chip, which is where that path saturates in practice.  Variant 4 (column-block units, every fragment fetched once
 // per 64-row tile) reaches 223 us and ties the default bench (13.73 vs 13.65 M clips/s): its producer waves -- MFMA + the
 // A-fragment LDS reads + GELU + transposes, ~10 k cycles per unit against 3-4 k for the consumers -- are the critical path;
-// rebalancing the roles (more, narrower producer waves) is the next step.
+// variants 5 / 6 rebalance the roles (eight producers of one 32x32 fragment; four or eight consumers; 12 / 16 waves) and
+// reach 203 us = 253 TFLOP/s -- still behind the pair alone, a tie in the bench.
 #include <cstdio>
 #include <cstdlib>
 
@@ -557,6 +558,347 @@ __global__ __launch_bounds__(512, 2) void ffn_f16_ws2_kernel(FfnArgs a) {
   }
 }
 
+// ---- variant 5: twelve waves (eight producers of one 32x32 fragment each: column block wave & 3, row half wave >> 2; four
+// consumers), three waves per SIMD: per unit a SIMD carries 2 x 1.5 k producer + 3 k consumer MFMA cycles and the producers'
+// GELU / LDS work is spread over twice the waves.  Transposes go through 16-row half tiles (LDS: 155.6 KiB at E = 256).
+template <int TN>
+__global__ __launch_bounds__(768, 1) void ffn_f16_ws3_kernel(FfnArgs a) {
+  constexpr int E = TN * 128, KT = E / 32, KT2 = 4 * KT, HB = 128, NU = 4 * E / HB, KTC = HB / 32;
+  constexpr int ROWX = E * 2 + 16, ROWH = HB * 2 + 16;
+  constexpr int XPL = 64 * ROWX, HPL = 64 * ROWH;
+  constexpr int NS = 4;
+  static_assert(KT % NS == 0 && KTC % NS == 0, "ring index static per unit");
+  extern __shared__ unsigned char smem_f[];
+  unsigned char* Xs = smem_f;                           // [2][64][ROWX]
+  unsigned char* Hb = smem_f + 2 * XPL;                 // [2 buffers][2 planes][64][ROWH]
+  const GemmArgs& p = a.p;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool producer = wave < 8;                     // waves 0-7: (column block wave & 3, row half wave >> 2); 8-11: consumers
+  const int wn = wave & 3, ph = (wave >> 2) & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * 64;
+  const int M = p.M;
+  if (m0 >= M) return;
+  float* tbase = reinterpret_cast<float*>(smem_f + 2 * XPL + 4 * HPL);
+  float* tile = tbase + wn * EPI_WAVE_FLOATS;          // consumers' epilogue tiles ...
+  float* tile16 = tbase + wave * (16 * EPI_PITCH);     // ... alias the producers' half tiles (16 rows each), which are dead by then
+
+  if (tid < 512) {  // X tile -> planes, the first 512 threads
+    const int row = tid >> 3;
+    const bool ok = m0 + row < M;
+    const float* src = p.A + (int64_t)(ok ? m0 + row : 0) * p.lda;
+#pragma unroll
+    for (int j = 0; j < E / 64; ++j) {
+      const int pc = j * 8 + (tid & 7);
+      f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        v0 = *reinterpret_cast<const f32x4*>(src + pc * 8);
+        v1 = *reinterpret_cast<const f32x4*>(src + pc * 8 + 4);
+      }
+      unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+      ffn_split2(v0.x, v0.y, h0, l0); ffn_split2(v0.z, v0.w, h1, l1);
+      ffn_split2(v1.x, v1.y, h2, l2); ffn_split2(v1.z, v1.w, h3, l3);
+      *reinterpret_cast<u32x4*>(Xs + row * ROWX + pc * 16) = u32x4{h0, h1, h2, h3};
+      *reinterpret_cast<u32x4*>(Xs + XPL + row * ROWX + pc * 16) = u32x4{l0, l1, l2, l3};
+    }
+  }
+  const float unscale = 1.f / (FFN_SA * FFN_SW);
+
+  if (producer) {
+    // stream: W1 blocks (n32 = u * 4 + wn, kt) of KT, t = u * KT + kt
+    const bf16x8* wimg = reinterpret_cast<const bf16x8*>(a.W1s) + lane;
+    bf16x8 ring[NS][2][2];                              // [slot][16-k chunk][plane]
+    auto request = [&](int t, bf16x8 (&b)[2][2]) __attribute__((always_inline)) {
+      if (t >= NU * KT) t = NU * KT - 1;
+      const int u = t / KT, kt = t - u * KT;
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) b[cc][pl] = wimg[((int64_t)(u * 4 + wn) * KT + kt) * (FFN_BLK / 8) + (cc * 3 + pl) * 64];
+    };
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) request(s, ring[s]);
+    __syncthreads();                                    // X planes complete
+    bool bad = false;
+    const int rr = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll 1
+    for (int u = 0; u <= NU; ++u) {
+      if (u < NU) {
+        f32x16 acc1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc1[e] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          request(u * KT + kt + NS - 1, ring[(kt + NS - 1) % NS]);
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(Xs + (ph * 32 + r) * ROWX + kt * 64 + c * 32 + h * 16);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(Xs + XPL + (ph * 32 + r) * ROWX + kt * 64 + c * 32 + h * 16);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, ring[kt % NS][c][1]), acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, ring[kt % NS][c][0]), acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, ring[kt % NS][c][0]), acc1, 0, 0, 0);
+          }
+        }
+        unsigned char* Hw = Hb + (u & 1) * 2 * HPL;
+        const int colb = wn * 32 + c4;                  // column inside the block
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.b1 + u * HB + colb);
+        // the 32x32 fragment goes through a 16-row transpose tile in two halves: elements e with (e >> 3) == hh are rows
+        // 16 hh .. 16 hh + 15 of the fragment (row = (e & 3) + 8 (e >> 2) + 4 h)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+          for (int e8 = 0; e8 < 8; ++e8) {
+            const int e = hh * 8 + e8;
+            const float v = acc1[e] * unscale;
+            bad |= !(__builtin_fabsf(v) <= 3.4028234664e38f);
+            tile16[((e & 3) + 8 * ((e >> 2) & 1) + 4 * h) * EPI_PITCH + r] = v;
+          }
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(tile16 + (rr + 8 * q) * EPI_PITCH + c4) + bias;
+            v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+            unsigned h0, h1, l0, l1;
+            ffn_split2(v.x, v.y, h0, l0); ffn_split2(v.z, v.w, h1, l1);
+            const int row = ph * 32 + hh * 16 + rr + 8 * q;
+            *reinterpret_cast<u32x2*>(Hw + row * ROWH + colb * 2) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(Hw + HPL + row * ROWH + colb * 2) = u32x2{l0, l1};
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (bad && p.status) atomicOr(p.status, 1u);
+  } else {
+    // stream: W2 blocks (n32 = wn * TN + j, kt = u * KTC + k) of KT2, t = u * KTC + k
+    const bf16x8* wimg = reinterpret_cast<const bf16x8*>(p.Ws) + lane;
+    constexpr int NS = 2;                               // three waves per SIMD: 168 registers, the output accumulators take 64
+    bf16x8 ring[NS][2][TN][2];
+    auto request = [&](int t, bf16x8 (&b)[2][TN][2]) __attribute__((always_inline)) {
+      if (t >= KT2) t = KT2 - 1;
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) b[cc][j][pl] = wimg[((int64_t)(wn * TN + j) * KT2 + t) * (FFN_BLK / 8) + (cc * 3 + pl) * 64];
+    };
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) request(s, ring[s]);
+    bool bad = false;
+    f32x16 acc2[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[i][j][e] = 0.f;
+    __syncthreads();                                    // X planes complete (not used here)
+    __syncthreads();                                    // producers' unit 0
+#pragma unroll 1
+    for (int u = 0; u < NU; ++u) {
+      const unsigned char* Hr = Hb + (u & 1) * 2 * HPL;
+#pragma unroll
+      for (int k = 0; k < KTC; ++k) {
+        request(u * KTC + k + NS - 1, ring[(k + NS - 1) % NS]);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          bf16x8 af[2][2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) af[i][pl] = *reinterpret_cast<const bf16x8*>(Hr + pl * HPL + (i * 32 + r) * ROWH + k * 64 + c * 32 + h * 16);
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][0]), __builtin_bit_cast(f16x8, ring[k % NS][c][j][1]), acc2[i][j], 0, 0, 0);
+              acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][1]), __builtin_bit_cast(f16x8, ring[k % NS][c][j][0]), acc2[i][j], 0, 0, 0);
+              acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][0]), __builtin_bit_cast(f16x8, ring[k % NS][c][j][0]), acc2[i][j], 0, 0, 0);
+            }
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float v = acc2[i][j][e] * unscale;
+          bad |= !(__builtin_fabsf(v) <= 3.4028234664e38f);
+          acc2[i][j][e] = v;
+        }
+    if (bad && p.status) atomicOr(p.status, 1u);
+    if (gemm_wide_ok(p)) gemm_epilogue_wide<1, 4, 2, TN>(p, acc2, m0, 0, 0, wn, lane, tile);
+    else gemm_epilogue<1, 4, 2, TN>(p, acc2, m0, 0, 0, wn, r, h);
+  }
+}
+
+// ---- variant 6 (E = 256): sixteen waves -- the eight producers of variant 5 and EIGHT consumers of 64 rows x 32 output columns
+// (each W2 fragment still fetched once), four waves per SIMD at <= 128 registers, four-deep rings on both sides.
+template <int TN>
+__global__ __launch_bounds__(1024, 1) void ffn_f16_ws4_kernel(FfnArgs a) {
+  static_assert(TN == 2, "sixteen-wave variant: E = 256 only");
+  constexpr int E = TN * 128, KT = E / 32, KT2 = 4 * KT, HB = 128, NU = 4 * E / HB, KTC = HB / 32;
+  constexpr int ROWX = E * 2 + 16, ROWH = HB * 2 + 16;
+  constexpr int XPL = 64 * ROWX, HPL = 64 * ROWH;
+  constexpr int NS = 4;
+  static_assert(KT % NS == 0 && KTC % NS == 0, "ring index static per unit");
+  extern __shared__ unsigned char smem_f[];
+  unsigned char* Xs = smem_f;                           // [2][64][ROWX]
+  unsigned char* Hb = smem_f + 2 * XPL;                 // [2 buffers][2 planes][64][ROWH]
+  const GemmArgs& p = a.p;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool producer = wave < 8;                     // waves 0-7: (column block wave & 3, row half wave >> 2); 8-15: consumers, 32 output columns each
+  const int cw = wave - 8;
+  const int wn = wave & 3, ph = (wave >> 2) & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * 64;
+  const int M = p.M;
+  if (m0 >= M) return;
+  float* tbase = reinterpret_cast<float*>(smem_f + 2 * XPL + 4 * HPL);
+  float* tile16 = tbase + (wave & 7) * (16 * EPI_PITCH);   // producers' half tiles (16 rows each)
+
+  if (tid < 512) {  // X tile -> planes, the first 512 threads
+    const int row = tid >> 3;
+    const bool ok = m0 + row < M;
+    const float* src = p.A + (int64_t)(ok ? m0 + row : 0) * p.lda;
+#pragma unroll
+    for (int j = 0; j < E / 64; ++j) {
+      const int pc = j * 8 + (tid & 7);
+      f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        v0 = *reinterpret_cast<const f32x4*>(src + pc * 8);
+        v1 = *reinterpret_cast<const f32x4*>(src + pc * 8 + 4);
+      }
+      unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+      ffn_split2(v0.x, v0.y, h0, l0); ffn_split2(v0.z, v0.w, h1, l1);
+      ffn_split2(v1.x, v1.y, h2, l2); ffn_split2(v1.z, v1.w, h3, l3);
+      *reinterpret_cast<u32x4*>(Xs + row * ROWX + pc * 16) = u32x4{h0, h1, h2, h3};
+      *reinterpret_cast<u32x4*>(Xs + XPL + row * ROWX + pc * 16) = u32x4{l0, l1, l2, l3};
+    }
+  }
+  const float unscale = 1.f / (FFN_SA * FFN_SW);
+
+  if (producer) {
+    // stream: W1 blocks (n32 = u * 4 + wn, kt) of KT, t = u * KT + kt
+    const bf16x8* wimg = reinterpret_cast<const bf16x8*>(a.W1s) + lane;
+    bf16x8 ring[NS][2][2];                              // [slot][16-k chunk][plane]
+    auto request = [&](int t, bf16x8 (&b)[2][2]) __attribute__((always_inline)) {
+      if (t >= NU * KT) t = NU * KT - 1;
+      const int u = t / KT, kt = t - u * KT;
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) b[cc][pl] = wimg[((int64_t)(u * 4 + wn) * KT + kt) * (FFN_BLK / 8) + (cc * 3 + pl) * 64];
+    };
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) request(s, ring[s]);
+    __syncthreads();                                    // X planes complete
+    bool bad = false;
+    const int rr = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll 1
+    for (int u = 0; u <= NU; ++u) {
+      if (u < NU) {
+        f32x16 acc1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc1[e] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          request(u * KT + kt + NS - 1, ring[(kt + NS - 1) % NS]);
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(Xs + (ph * 32 + r) * ROWX + kt * 64 + c * 32 + h * 16);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(Xs + XPL + (ph * 32 + r) * ROWX + kt * 64 + c * 32 + h * 16);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, ring[kt % NS][c][1]), acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, ring[kt % NS][c][0]), acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, ring[kt % NS][c][0]), acc1, 0, 0, 0);
+          }
+        }
+        unsigned char* Hw = Hb + (u & 1) * 2 * HPL;
+        const int colb = wn * 32 + c4;                  // column inside the block
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.b1 + u * HB + colb);
+        // the 32x32 fragment goes through a 16-row transpose tile in two halves: elements e with (e >> 3) == hh are rows
+        // 16 hh .. 16 hh + 15 of the fragment (row = (e & 3) + 8 (e >> 2) + 4 h)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+          for (int e8 = 0; e8 < 8; ++e8) {
+            const int e = hh * 8 + e8;
+            const float v = acc1[e] * unscale;
+            bad |= !(__builtin_fabsf(v) <= 3.4028234664e38f);
+            tile16[((e & 3) + 8 * ((e >> 2) & 1) + 4 * h) * EPI_PITCH + r] = v;
+          }
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(tile16 + (rr + 8 * q) * EPI_PITCH + c4) + bias;
+            v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+            unsigned h0, h1, l0, l1;
+            ffn_split2(v.x, v.y, h0, l0); ffn_split2(v.z, v.w, h1, l1);
+            const int row = ph * 32 + hh * 16 + rr + 8 * q;
+            *reinterpret_cast<u32x2*>(Hw + row * ROWH + colb * 2) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(Hw + HPL + row * ROWH + colb * 2) = u32x2{l0, l1};
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (bad && p.status) atomicOr(p.status, 1u);
+  } else {
+    // stream: W2 blocks (n32 = cw, kt = u * KTC + k) of KT2, t = u * KTC + k
+    const bf16x8* wimg = reinterpret_cast<const bf16x8*>(p.Ws) + lane;
+    bf16x8 ring[NS][2][2];                              // [slot][16-k chunk][plane]
+    auto request = [&](int t, bf16x8 (&b)[2][2]) __attribute__((always_inline)) {
+      if (t >= KT2) t = KT2 - 1;
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) b[cc][pl] = wimg[((int64_t)cw * KT2 + t) * (FFN_BLK / 8) + (cc * 3 + pl) * 64];
+    };
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) request(s, ring[s]);
+    bool bad = false;
+    f32x16 acc2[2][1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc2[i][0][e] = 0.f;
+    __syncthreads();                                    // X planes complete (not used here)
+    __syncthreads();                                    // producers' unit 0
+#pragma unroll 1
+    for (int u = 0; u < NU; ++u) {
+      const unsigned char* Hr = Hb + (u & 1) * 2 * HPL;
+#pragma unroll
+      for (int k = 0; k < KTC; ++k) {
+        request(u * KTC + k + NS - 1, ring[(k + NS - 1) % NS]);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(Hr + (i * 32 + r) * ROWH + k * 64 + c * 32 + h * 16);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(Hr + HPL + (i * 32 + r) * ROWH + k * 64 + c * 32 + h * 16);
+            acc2[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, ring[k % NS][c][1]), acc2[i][0], 0, 0, 0);
+            acc2[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, ring[k % NS][c][0]), acc2[i][0], 0, 0, 0);
+            acc2[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, ring[k % NS][c][0]), acc2[i][0], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float v = acc2[i][0][e] * unscale;
+        bad |= !(__builtin_fabsf(v) <= 3.4028234664e38f);
+        acc2[i][0][e] = v;
+      }
+    if (bad && p.status) atomicOr(p.status, 1u);
+    gemm_epilogue<1, 8, 2, 1>(p, acc2, m0, 0, 0, cw, r, h);
+  }
+}
+
 bool ffn_fused_supported(int E) { return E == 128 || E == 256; }
 
 // p: the proj GEMM as launch_gemm_split would take it (A = the fc input X, K = 4E, N = E, Ws = proj image, bias = proj bias);
@@ -578,6 +920,28 @@ int launch_ffn_f16(const GemmArgs& p, const unsigned short* W1s, const float* b1
     static bool done = false; \
     if (!done) { DCF_HIP(hipFuncSetAttribute((const void*)ffn_f16_kernel<TN_, TM_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; } \
     hipLaunchKernelGGL((ffn_f16_kernel<TN_, TM_>), grid, dim3(256), lds, st, a); } while (0)
+  if (tm == 6 && E == 256) {                              // sixteen waves: eight producers, eight consumers
+    const size_t lds6 = (size_t)2 * 64 * rowx + (size_t)4 * 64 * (128 * 2 + 16) + (size_t)4 * EPI_WAVE_FLOATS * sizeof(float);
+    static bool done6 = false;
+    if (!done6) { DCF_HIP(hipFuncSetAttribute((const void*)ffn_f16_ws4_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6)); done6 = true; }
+    hipLaunchKernelGGL(ffn_f16_ws4_kernel<2>, dim3((p.M + 63) / 64), dim3(1024), lds6, st, a);
+    DCF_HIP(hipGetLastError());
+    return 0;
+  }
+  if (tm == 5 || tm == 6) {                               // twelve waves: eight narrow producers, four consumers
+    const size_t lds5 = (size_t)2 * 64 * rowx + (size_t)4 * 64 * (128 * 2 + 16) + (size_t)4 * EPI_WAVE_FLOATS * sizeof(float);
+    dim3 grid5((p.M + 63) / 64);
+    static bool done5[2] = {false, false};
+    if (E == 256) {
+      if (!done5[1]) { DCF_HIP(hipFuncSetAttribute((const void*)ffn_f16_ws3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5)); done5[1] = true; }
+      hipLaunchKernelGGL(ffn_f16_ws3_kernel<2>, grid5, dim3(768), lds5, st, a);
+    } else {
+      if (!done5[0]) { DCF_HIP(hipFuncSetAttribute((const void*)ffn_f16_ws3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5)); done5[0] = true; }
+      hipLaunchKernelGGL(ffn_f16_ws3_kernel<1>, grid5, dim3(768), lds5, st, a);
+    }
+    DCF_HIP(hipGetLastError());
+    return 0;
+  }
   if (tm == 4) {                                          // warp-specialised, column-block units
     const size_t lds4 = (size_t)2 * 64 * rowx + (size_t)4 * 64 * (128 * 2 + 16) + (size_t)4 * EPI_WAVE_FLOATS * sizeof(float);
     dim3 grid4((p.M + 63) / 64);

@@ -392,7 +392,7 @@ def test_collect_with_ext_scores(L):
         torch.testing.assert_close(segs[q, :n].cpu(), ws, rtol=1e-6, atol=1e-4)
 
 
-@pytest.mark.parametrize('variant', [1, 2, 3, 4])
+@pytest.mark.parametrize('variant', [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize('M,E,res', [(64, 128, False), (1000, 256, True), (16500, 256, True), (333, 128, True)])
 def test_fused_ffn(L, M, E, res, variant):
     """fc + GELU + proj in one kernel (ffn_f16.hip, f16x3) vs fp64: C = R + ls * (GELU(X W1^T + b1) W2^T + b2) * mask"""
