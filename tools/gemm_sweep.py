@@ -5,8 +5,8 @@ import ctypes, importlib, json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 SHAPES = [(16384, 256, 256), (16384, 1024, 256), (16384, 256, 1024), (16384, 512, 256), (8192, 256, 256), (8192, 1024, 256),
-          (8192, 256, 1024), (4096, 256, 256), (4096, 1024, 256), (4096, 256, 1024), (32640, 256, 768), (49152, 256, 256), (49152, 1024, 256), (49152, 256, 1024)]
-TILES = ['f16:auto', 'f16:64x256', 'f16:64x128', 'f16:64x64', 'f16:128x128', 'f16:128x256']
+          (8192, 256, 1024), (4096, 256, 256), (4096, 1024, 256), (4096, 256, 1024), (32640, 256, 768), (49152, 256, 256), (49152, 1024, 256), (49152, 256, 1024), (81920, 256, 256), (81920, 1024, 256), (81920, 256, 1024)]
+TILES = ['f16:auto', 'f16:64x256', 'f16:64x128', 'f16:128x256']
 
 def child():
     import torch
