@@ -3,26 +3,30 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--nq NQ] [--T 16384]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    ... bench.py --gpus N --shard-T 65536        # BASELINE configs[3]: ONE long video sharded over the N ranks (RCCL)
 
-A "step" is one eval forward of PtTransformerEarlyFusionIterative over one synthetic video of
-T=16384 clips (D=1024) for NQ text queries, inputs already resident in HBM, timed from
-model.forward entry to logits/offsets/masks on the device.  Workload =
-BASELINE.json configs[2] with the survey's probe hyper-parameters.
-With N > 1 every rank runs its own (video, queries) replica -- the path shards over independent
-(video, query) units with no data-path collective (weak scaling); value = all clips of all ranks
-divided by the slowest rank's time.
+Default workload = BASELINE.json configs[2] with the survey's probe hyper-parameters: a "step" is
+one pass of the eval forward of PtTransformerEarlyFusionIterative over a batch of synthetic videos of T = 16384 clips
+(D = 1024), NQ text queries each, inputs already resident in HBM, timed from model.forward entry to logits / offsets /
+masks on the device.  With N > 1 every rank runs its own replica -- the path shards over independent
+(video, query) units with no data-path collective (weak scaling); value = all clips of all ranks divided by the slowest
+rank's time.  With --shard-T one video of that length is cut into N clip chunks (+ halo), two RCCL all-gathers per
+forward (cvpr2025-decafnet_amd/dist.py), strong scaling; rank 0 checks the result against the unsharded forward.
 
 Rank 0 prints ONE JSON line: the driver contract fields plus
-  roofline     : dominant kernel (fp32 MFMA GEMM), live HIP-event timing of every launch
-  cpu_baseline : the CPU oracle (a port of the reference algorithm) timed on this host's cores
+  roofline     : dominant kernel family (dense-conv GEMM), live HIP-event timing of every launch
+  parity       : max |delta| of logits / offsets of one timed video against the CPU oracle (the checker)
+  cpu_baseline : the CPU oracle (a port of the reference algorithm) timed on this host's cores (N = 1 only)
   stages       : per-kernel-family time of one step (same event timing)
   post         : proposal decode + NMS latency and the NMS index match against the oracle
 """
 import argparse
 import ctypes
+import hashlib
 import importlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -32,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: bf16 dense MFMA peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: bf16 / fp16 dense MFMA peak
 PEAK_HBM_GBS = 8000.0            # HBM3E spec
 
 
@@ -50,6 +54,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=5,
                     help='videos per forward (forward_videos: same-length videos batched through every kernel); a step then '
                          'holds --videos x --batch videos')
+    ap.add_argument('--shard-T', type=int, default=0,
+                    help='BASELINE configs[3]: one video of this many clips, clip-chunk sharded over the ranks (0 = replicas)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--debug-gloo-one-gpu', action='store_true',
                     help='flow check of the multi-rank path on a one-GPU box: gloo rendezvous, every rank on cuda:0 (timings meaningless)')
@@ -59,9 +65,156 @@ def parse():
 
 
 def probe_kwargs(T):
-    # BASELINE.md section 2 probe hyper-parameters; max_seq_len*10 >= T so PtGenerator covers the video
+    # BASELINE.md section 2 probe hyper-parameters; the position encoding (max_seq_len 2304) is resampled to T (video_net.py:147-150)
     return dict(D=1024, E=256, TE=256, text_in=512, n_levels=8, win=9, n_heads=4, sn=60, sratio=0.3, msf=True,
                 norm=True, max_seq_len=2304, text_layers=5, text_max_len=48, fusion_layers=2)
+
+
+def csrc_hash():
+    """sha256 over the kernel sources and the C ABI header: profiles/ artefacts that depend on the build carry it"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'cvpr2025-decafnet_amd', 'csrc')
+    for f in sorted(os.listdir(d)) + ['../../include/decafnet_hip.h']:
+        with open(os.path.join(d, f), 'rb') as fh:
+            h.update(f.encode() + b'\0' + fh.read())
+    return h.hexdigest()[:16]
+
+
+def cpu_model():
+    try:
+        for line in subprocess.run(['lscpu'], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            if line.startswith('Model name'):
+                return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return 'unknown'
+
+
+def physical_cores():
+    try:
+        out = subprocess.run(['lscpu', '-p=core,socket'], capture_output=True, text=True, timeout=10).stdout
+        cores = {l for l in out.splitlines() if l and not l.startswith('#')}
+        avail = len(os.sched_getaffinity(0))
+        return max(1, min(len(cores), avail))
+    except Exception:
+        return max(1, len(os.sched_getaffinity(0)))
+
+
+def max_deltas(got, want, nq, L):
+    dl = max(float((got[0][q][l].float().cpu() - want[0][q][l]).abs().max()) for q in range(nq) for l in range(L))
+    do = max(float((got[1][q][l].float().cpu() - want[1][q][l]).abs().max()) for q in range(nq) for l in range(L))
+    mk = all(bool(torch.equal(got[2][q][l].cpu(), want[2][q][l])) for q in range(nq) for l in range(L))
+    return dl, do, mk
+
+
+class Marks:
+    """HIP-event marks on the current stream between the phases of dist.sharded_forward"""
+
+    def __init__(self):
+        self.rows = []
+        self.cur = None
+
+    def begin(self):
+        self.cur = []
+
+    def mark(self, name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.cur.append((name, e))
+
+    def end(self):
+        self.rows.append(self.cur)
+
+    def summary(self):
+        acc = {}
+        for row in self.rows:
+            for (n0, e0), (_, e1) in zip(row, row[1:]):
+                acc.setdefault(n0, []).append(e0.elapsed_time(e1) * 1e3)
+        return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+def run_sharded(args, pkg, dist, rank, world, dev):
+    """BASELINE configs[3]: one long video, clip-chunk sharded over the ranks; two RCCL all-gathers per forward."""
+    T, nq = args.shard_T, args.nq
+    vid_len = args.vid_len or T
+    kw = probe_kwargs(T)
+    opt = pkg.config.make_opt(**kw)
+    opt.model['max_batch'] = args.max_batch
+    model = pkg.modeling.create_model(opt)
+    sd = pkg.synth.make_state_dict({k: list(v.shape) for k, v in model.state_dict().items()}, 2025)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval().requires_grad_(False)
+    inp = pkg.synth.make_inputs(kw['D'], T, vid_len, nq, kw['text_in'], 32, 2025 + 4)      # the same video on every rank
+    texts, tmasks = zip(*[model.encode_text(tok[None].to(dev), torch.ones(1, 1, tok.size(-1), dtype=torch.bool, device=dev))
+                          for tok in inp['tokens']])
+    d = pkg.dist
+    L, win = kw['n_levels'], kw['win']
+    halo = d.receptive_field(L, win, kw['fusion_layers'])
+    plan = d.shard_plan(T, world, L, win, halo)
+    lo, hi, w_lo, w_hi = plan[rank]
+    vid_w = inp['vid'][0][:, w_lo:w_hi].contiguous().to(dev)
+    sh_w = inp['shallow_vid'][0][:, w_lo:w_hi].contiguous().to(dev)
+    mask_full = inp['vid_masks'][0].to(dev)
+    cls = inp['text_cls'].to(dev)
+    be = d.HipBackend(model)
+    marks = Marks()
+
+    def step(timed=False):
+        if timed:
+            marks.begin()
+        out = d.sharded_forward(be, vid_w, sh_w, mask_full, plan, rank, T, L, texts, cls, tmasks, timings=marks if timed else None)
+        if timed:
+            marks.end()
+        return out
+
+    for _ in range(3 + args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device='cpu' if args.debug_gloo_one_gpu else dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert model.numerics_status() & 1 == 0, 'f16x3 GEMM range overflow flagged'
+    for _ in range(min(args.steps, 5)):
+        step(timed=True)
+    torch.cuda.synchronize()
+    phases = marks.summary()
+    result = {
+        'metric': 'clips/sec (grounding fwd, T=16384 D=1024)', 'value': vid_len * nq * args.steps / elapsed, 'unit': 'clips/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+        'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'BASELINE configs[3]: ONE video of T={T} clips (D=1024, probe hyper-parameters, NQ={nq}) clip-chunk sharded over '
+                               f'{world} rank(s): owned chunk + {halo}-clip recompute halo per side, RCCL all-gather of the sidekick scores '
+                               f'(AG-1) and of the packed per-level outputs (AG-2)',
+                   'T': T, 'vid_len': vid_len, 'nq': nq, 'window_clips_rank0': plan[0][3] - plan[0][2], 'window_clips_max': max(p[3] - p[2] for p in plan),
+                   'owned_clips': plan[0][1] - plan[0][0], 'halo': halo, 'parallelism': f'T-shard x{world}',
+                   'backend': 'gloo (flow check)' if args.debug_gloo_one_gpu else ('nccl = RCCL' if world > 1 else 'single rank')},
+        'phases_us_rank0': phases,
+        'collectives_us_rank0': {'ag1_scores': phases.get('ag1'), 'ag2_outputs': phases.get('ag2')},
+    }
+    # the sharded result against the unsharded forward of the same video on rank 0
+    if rank == 0:
+        full = model(inp['vid'].to(dev), inp['shallow_vid'].to(dev), inp['vid_masks'].to(dev), texts, cls, tmasks, eval=True)
+        dl, do, mk = max_deltas(out, [[[x.cpu() for x in lv] for lv in part] for part in full], nq, L)
+        result['parity'] = {'against': 'unsharded forward of the same video on rank 0 (itself checked against the CPU oracle by '
+                                       'tests/test_gpu_e2e.py::test_config4_unsharded_T65536_vs_oracle)',
+                            'max_abs_logit': dl, 'max_abs_offset': do, 'masks_equal': mk}
+        assert mk and dl < 2e-4 and do < 2e-4, f'sharded forward differs from the unsharded one: {dl} {do} {mk}'
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -69,6 +222,11 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if args.gpus != world:
+        sys.stderr.write(f'bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}.  One process per GPU: launch with\n'
+                         f'  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 '
+                         f'--master-port 29511 bench.py --gpus {args.gpus} ...\n')
+        sys.exit(2)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -77,13 +235,15 @@ def main():
         if args.debug_gloo_one_gpu:
             dist.init_process_group('gloo')
             local_rank = 0
-        else:
+        else:                                            # before any other GPU call
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     pkg = importlib.import_module('cvpr2025-decafnet_amd')
     lib = pkg._lib.lib()
+    if args.shard_T:
+        return run_sharded(args, pkg, dist, rank, world, dev)
 
     T = args.T
     vid_len = args.vid_len or T
@@ -120,15 +280,13 @@ def main():
     batch0 = [first] + lane_inputs(model, 2025 + 3 + rank)
 
     def step1():
+        """one forward on the current stream; returns the outputs of its FIRST video in forward()'s structure"""
         if args.batch > 1:
-            return model.forward_videos(batch0)
+            return model.forward_videos(batch0)[0]
         return model(vid, shallow, vmask, texts, text_cls, tmasks, eval=True)
 
-    # A step = one batch of `--videos` different synthetic videos, each an independent forward (own model instance =
-    # own workspace + HIP graph) on its own stream.  One forward is a chain of ~110 dependent kernels, about half of
-    # them single-round GEMMs that leave CUs idle in their prologue / epilogue; independent videos fill those holes
-    # (NQ = 1: 7.1 / 8.6 / 9.2 / 8.6-9.4 M clips/s with 1 / 2 / 3 / 4 videos in flight, tools/streams_probe.py; the fourth
-    # stream shares a hardware queue on some runs, so three is the default).
+    # A step = one batch of `--videos` x `--batch` different synthetic videos: `--videos` independent forwards (own model
+    # instance = own workspace + HIP graph) on their own streams, each carrying `--batch` videos.
     others = []
     for k in range(1, max(1, args.videos)):
         mk = model.replica()                        # same parameters, own engine / workspace / graph
@@ -159,6 +317,7 @@ def main():
     for _ in range(6):
         step()
     torch.cuda.synchronize()
+    launch_modes = sorted({m_.graph_active() for m_ in [model] + [o[0] for o in others]})
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -180,10 +339,12 @@ def main():
     # the f16x3 GEMMs flag any accumulator that left the finite range (operands beyond the fp16 range): must be clean
     for mk in [model] + [o[0] for o in others]:
         assert mk.numerics_status() & 1 == 0, 'f16x3 GEMM range overflow flagged: the timed outputs are not valid'
+    timed_out = [[[x.clone() for x in lv] for lv in part] for part in out]      # first video of the LAST timed step (rank-local)
     n_lanes = 1 + len(others)
     n_videos = n_lanes * max(1, args.batch)
     clips_per_step = n_videos * vid_len * args.nq
     value = world * clips_per_step * args.steps / elapsed
+    launch_note = {0: 'eager kernel launches', 1: 'HIP graph replay', 2: 'HIP graph (just captured)'}
 
     result = {
         'metric': 'clips/sec (grounding fwd, T=16384 D=1024)', 'value': value, 'unit': 'clips/s', 'n_gpus': world,
@@ -195,14 +356,15 @@ def main():
                    'T': T, 'vid_len': vid_len, 'D': 1024, 'E': 256, 'TE': 256, 'levels': 8, 'win': 9, 'heads': 4,
                    'fusion_layers': 2, 'sn': 60, 'sratio': 0.3, 'msf': True, 'norm': True, 'Lq': 32, 'nq': args.nq,
                    'max_batch': args.max_batch, 'videos_per_step': n_videos, 'forwards_in_flight': n_lanes, 'videos_per_forward': max(1, args.batch), 'parallelism': f'replicas x{world}',
-                   'launch': 'HIP graph replay of the forward (captured on the 2nd identical call); DCF_NO_GRAPH=1 = eager'},
+                   'launch': ' / '.join(launch_note[m_] for m_ in launch_modes) + ' (dcf_graph_active after the setup calls; DCF_NO_GRAPH=1 = eager)',
+                   'csrc_sha16': csrc_hash()},
     }
 
     if rank == 0:
         # ---- live per-kernel timing: the same steps again with every launch bracketed by HIP events
         lib.dcf_profile_enable(1)
         for _ in range(args.steps):
-            step1()                                  # one video on the current stream: undisturbed per-kernel times
+            step1()                                  # one forward on the current stream: undisturbed per-kernel times
         torch.cuda.synchronize()
         need = lib.dcf_profile_report(None, 0)
         buf = ctypes.create_string_buffer(int(need) + 16)
@@ -215,11 +377,8 @@ def main():
                       'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['ms'] > 0 else 0.0,
                       'alg_GBps': (v['bytes'] / (v['ms'] * 1e-3) / 1e9) if v['ms'] > 0 else 0.0}
                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}
-        # dominant kernel = the dense-conv GEMM.  Default arithmetic: fp32-accurate bf16x6 operand split on
-        # v_mfma_f32_32x32x16_bf16 (6 bf16 MFMA products per fp32 MAC) => fp32-equivalent peak = 2500 / 6 TFLOP/s;
-        # with DCF_GEMM_MODE=fp32 the native fp32 MFMA (157.3 TFLOP/s) is used instead.
-        # f16x3 (default): two fp16 planes per operand, 3 fp16 MFMA products per fp32 MAC => peak 2500 / 3 TFLOP/s; the two
-        # vid_map GEMMs on the raw features stay on bf16x6 and are listed under `stages`
+        # dominant kernel = the dense-conv GEMM family.  f16x3 (default): two fp16 planes per operand, 3 fp16 MFMA products
+        # per fp32 multiply-add => fp32-equivalent peak 2500 / 3 TFLOP/s; bf16x6: 2500 / 6; DCF_GEMM_MODE=fp32: native 157.3.
         fam = 'gemm_f16x3' if any(k.startswith('gemm_f16x3') for k in prof) else \
               ('gemm_bf16x6' if any(k.startswith('gemm_bf16x6') for k in prof) else 'gemm_f32')
         gk = [k for k in prof if k.startswith(fam)]
@@ -228,34 +387,35 @@ def main():
         peak = PEAK_BF16_MFMA_TFLOPS / terms if terms else PEAK_F32_MFMA_TFLOPS
         ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
         result['roofline'] = {
-            'kernel': '%s_kernel<*> (all %d tile/operand instantiations, %.0f%% of the step)' % (
-                'gemm_bf16s' if terms else 'gemm_f32', len(gk), 100 * d['ms'] / tot_ms),
+            'kernel': '%s family (all %d tile/operand instantiations, %.0f%% of the step)' % (fam, len(gk), 100 * d['ms'] / tot_ms),
             'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
             'launches': d['count'], 'avg_launch_us': 1e3 * d['ms'] / d['count'],
-            'alg_flops_per_launch': d['flops'] / d['count'],
+            'alg_flops_per_launch': d['flops'] / d['count'], 'alg_bytes_per_launch': d['bytes'] / d['count'],
             'peak_note': ('fp16 / bf16 dense MFMA peak 2500 TFLOP/s / %d 16-bit MFMA products per fp32 multiply-add (fp32-accurate operand split)' % terms)
                          if terms else 'native fp32 MFMA dense peak',
             'frac_of_native_f32_mfma_peak': ach / PEAK_F32_MFMA_TFLOPS,
-            'note': 'HIP events around every launch of this kernel, same K steps re-run right after the timed region; '
+            'non_gemm_share': 1.0 - d['ms'] / tot_ms, 'launches_per_forward': sum(v['count'] for v in prof.values()) / args.steps,
+            'note': 'HIP events around every launch of this kernel family, same K steps re-run right after the timed region; '
                     'achieved = algorithmic 2*M*N*K flops / event time',
         }
         # HBM-side bytes per launch of this kernel family: rocprofv3 PMC passes cannot run inside this process, so the
-        # figure comes from the committed summary of tools/pmc_traffic.sh (same command, same build); null if absent
+        # figure comes from the committed summary of tools/pmc_traffic.sh -- valid only for the SAME kernel sources (hash) and
+        # the default workload; null otherwise
         try:
-            # the committed summary was collected on the DEFAULT workload: only a default run may quote it
             if (args.T, args.nq, args.videos, args.batch, args.vid_len) != (16384, 1, 3, 5, 0):
                 raise KeyError('non-default workload')
-            with open(os.path.join(ROOT, 'profiles', 'r01_pmc_gemm_traffic.json')) as fh:
-                pmc = json.load(fh).get({6: 'gemm_bf16s', 3: 'gemm_f16x3', 0: 'gemm_f32'}[terms])
+            with open(os.path.join(ROOT, 'profiles', 'r02_pmc_gemm_traffic.json')) as fh:
+                summ = json.load(fh)
+            if summ.get('csrc_sha16') != csrc_hash():
+                raise KeyError('the PMC summary was collected on other kernel sources')
+            pmc = summ.get({6: 'gemm_bf16s', 3: 'gemm_f16x3', 0: 'gemm_f32'}[terms])
             if pmc:
                 result['roofline']['traffic'] = pmc['hbm_bytes_per_launch']
-                # the other roofline of the same kernels: with f16x3 the fp32 activations are the larger cost
                 gbps = pmc['hbm_bytes_per_launch'] / (1e-6 * result['roofline']['avg_launch_us']) / 1e9
                 result['roofline']['hbm_view'] = {'achieved': gbps, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbps / PEAK_HBM_GBS,
                                                   'note': 'HBM-side bytes per launch (PMC) / average launch time of the GEMM family'}
                 result['roofline']['traffic_note'] = ('bytes per launch, FETCH_SIZE x2 + WRITE_SIZE from two rocprofv3 --pmc passes '
-                                                      '(profiles/r01_pmc_gemm_traffic.json, tools/pmc_traffic.sh); algorithmic '
-                                                      'operand bytes per launch: %.3e' % (d['bytes'] / d['count']))
+                                                      '(profiles/r02_pmc_gemm_traffic.json, tools/pmc_traffic.sh, same csrc hash)')
         except (OSError, ValueError, KeyError):
             pass
         result['config']['gemm_mode'] = {6: 'bf16x6 split MFMA (fp32 accurate)', 3: 'f16x3 split MFMA (fp32 accurate)', 0: 'native fp32 MFMA'}[terms]
@@ -263,8 +423,7 @@ def main():
         if xa:
             result['xattn_in_forward'] = {'bound': 'hbm', 'achieved': xa['bytes'] / (xa['ms'] * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS,
                                           'unit': 'GB/s', 'frac': xa['bytes'] / (xa['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                                          'avg_launch_us': 1e3 * xa['ms'] / xa['count'],
-                                          'note': 'warm: the 16 MiB q/ctx tensors of one query live in L2/Infinity Cache'}
+                                          'avg_launch_us': 1e3 * xa['ms'] / xa['count']}
         # BASELINE config 2 (T=4096, E=1024, Lk=33 cross-attention core), measured as SURVEY 8d prescribes: 100
         # back-to-back launches over rotating buffers > 512 MB, 8 queries per launch (268 MB of q/ctx traffic)
         extras = not args.no_post and world == 1          # single-GPU run only: the other ranks would wait at the barrier
@@ -272,7 +431,6 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, 'tools'))
             import xattn_bench
             # run twice, keep the second: the first call works on ~800 MB of freshly hipMalloc'ed buffers and is 20 % slower
-            # for all of its 140 launches (73 vs 61 us, tools/xattn_bench.py run back to back), the second reuses the cached blocks
             xattn_bench.run(4096, 1024, 16, Lk=33, B=8, reps=100)
             x = xattn_bench.run(4096, 1024, 16, Lk=33, B=8, reps=100)
             result['xattn_config2'] = {'bound': 'hbm', 'achieved': x['cold']['GBps'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
@@ -296,12 +454,12 @@ def main():
                 model(vid, shallow, vmask, t8, cls8, m8, eval=True)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t1) / 5
-            result['nq8'] = {'value': vid_len * 8 / dt, 'unit': 'clips/s', 'ms_per_step': 1e3 * dt,
+            result['nq8'] = {'value': vid_len * 8 / dt, 'unit': 'clips/s', 'ms_per_step': 1e3 * dt, 'launch': launch_note[model.graph_active()],
                              'note': 'one forward over the same video with 8 queries (batched through every kernel), rank 0 only'}
-            model(vid, shallow, vmask, texts, text_cls, tmasks, eval=True)      # restore _last_flat for the post-processing leg
 
-        # ---- the same workload with ONE video in flight (latency view of the headline)
-        if extras and others:
+        # ---- the same workload with ONE forward in flight, and the reference's calling pattern: one video per call on
+        # torch's default stream (the engine hops off the uncapturable NULL stream, so this replays a graph too)
+        if extras:
             for _ in range(3):
                 step1()
             torch.cuda.synchronize()
@@ -310,13 +468,25 @@ def main():
                 step1()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t1) / args.steps
-            result['one_video_in_flight'] = {'value': max(1, args.batch) * vid_len * args.nq / dt, 'unit': 'clips/s', 'ms_per_forward': 1e3 * dt,
-                                             'note': 'a single forward at a time on one stream (HIP-graph replay), rank 0 only'
-                                                     + (f'; {args.batch} videos per forward' if args.batch > 1 else '')}
+            result['one_forward_in_flight'] = {'value': max(1, args.batch) * vid_len * args.nq / dt, 'unit': 'clips/s', 'ms_per_forward': 1e3 * dt,
+                                               'launch': launch_note[model.graph_active()],
+                                               'note': f'a single forward at a time on the default stream, {max(1, args.batch)} video(s) per forward, rank 0 only'}
+            for _ in range(4):
+                model(vid, shallow, vmask, texts, text_cls, tmasks, eval=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                model(vid, shallow, vmask, texts, text_cls, tmasks, eval=True)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / args.steps
+            result['one_video_per_call'] = {'value': vid_len * args.nq / dt, 'unit': 'clips/s', 'ms_per_forward': 1e3 * dt,
+                                            'launch': launch_note[model.graph_active()],
+                                            'note': 'the reference\'s calling pattern (model.py:496: one video per call), default stream, rank 0 only'}
 
         # ---- proposal decode + NMS (reported separately) and the NMS index match
         if extras:
             from oracle import nms_oracle
+            model(vid, shallow, vmask, texts, text_cls, tmasks, eval=True)      # _last_flat of the first video
             fl, fo, fm = model._last_flat
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -345,27 +515,74 @@ def main():
             t1 = time.perf_counter()
             nms_oracle.nms(s_cpu, c_cpu, 0.5)
             t_cpu_nms = time.perf_counter() - t1
+            # forward + decode + the Evaluator's default NMS (soft-NMS, 5 segments kept, voting) for one video, end to end
+            ev = pkg.evaluator.GroundingEvaluator(opt, model)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                lg_, of_, mk_ = model(vid, shallow, vmask, texts, text_cls, tmasks, eval=True)
+                ev.generate_proposals(model._last_flat, T, dict(fps=30.0, clip_stride=16, clip_size=32, duration=1e9))
+            torch.cuda.synchronize()
+            t_e2e = (time.perf_counter() - t1) / reps
             result['post'] = {
                 'candidates': n, 'collect_ms_per_video': 1e3 * t_collect, 'nms_ms': 1e3 * t_nms, 'softnms_full_ms': 1e3 * t_soft,
                 'cpu_oracle_nms_ms': 1e3 * t_cpu_nms,
                 'nms_index_match': bool(torch.equal(keep[0, :int(kc)].cpu(), ref_keep)),
                 'softnms_index_match': bool(torch.equal(inds[0, :int(oc)].cpu(), ref_soft)),
+                'forward_collect_nms': {'value': vid_len * args.nq / t_e2e, 'unit': 'clips/s', 'ms_per_video': 1e3 * t_e2e,
+                                        'note': 'one video per call: forward + _collect_segments + batched_nms (soft-NMS, max_num_segs 5, voting 0.95) '
+                                                '+ D2H of the kept segments, SURVEY 8d'},
             }
 
-        # ---- CPU baseline: the oracle (port of the reference algorithm) on this host, bounded sample
+        # ---- parity of the TIMED outputs and the CPU baseline: the oracle (port of the reference algorithm) on this host
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
             from oracle import decafnet_ref as R
-            cpu_T = args.cpu_T or T
-            cinp = pkg.synth.make_inputs(kw['D'], cpu_T, min(vid_len, cpu_T), 1, kw['text_in'], 32, 2025 + 3)
-            t_cpu, m_cpu = R.encode_text(sd, opt.model, cinp['tokens'][0][None], torch.ones(1, 1, 32, dtype=torch.bool))
-            with torch.no_grad():
-                t1 = time.perf_counter()
-                R.forward_eval(sd, opt.model, cinp['vid'], cinp['shallow_vid'], cinp['vid_masks'], [t_cpu], cinp['text_cls'], [m_cpu])
-                cpu_s = time.perf_counter() - t1
+            texts_cpu, tm_cpu = zip(*[R.encode_text(sd, opt.model, tok[None], torch.ones(1, 1, tok.size(-1), dtype=torch.bool))
+                                      for tok in inp['tokens']])
+
+            def oracle_forward(cinp, tc, mc):
+                with torch.no_grad():
+                    return R.forward_eval(sd, opt.model, cinp['vid'], cinp['shallow_vid'], cinp['vid_masks'], list(tc), cinp['text_cls'], list(mc))
+
+            ncores = physical_cores()
+            torch.set_num_threads(ncores)
+            want = oracle_forward(inp, texts_cpu, tm_cpu)                           # also the warm-up of the timed runs
+            dl, do, mk = max_deltas(timed_out, want, args.nq, 8)
+            result['parity'] = {'against': 'CPU oracle (oracle/decafnet_ref.py, fp32) on the first video of the last timed step',
+                                'max_abs_logit': dl, 'max_abs_offset': do, 'masks_equal': mk,
+                                'max_logit_magnitude': max(float(x.abs().max()) for x in want[0][0]), 'bound': 1e-3}
+            assert mk and dl < 1e-3 and do < 1e-3, f'timed outputs differ from the oracle: {dl} {do} {mk}'
+
+            def best_of(n, fn):
+                best = 1e30
+                for _ in range(n):
+                    t1 = time.perf_counter()
+                    fn()
+                    best = min(best, time.perf_counter() - t1)
+                return best
+
+            cpu_s = best_of(3, lambda: oracle_forward(inp, texts_cpu, tm_cpu))
             result['cpu_baseline'] = {
-                'value': min(vid_len, cpu_T) / cpu_s, 'unit': 'clips/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-                'sample': f'1 video x 1 query, T={cpu_T}, oracle/decafnet_ref.py forward_eval (torch {torch.__version__} CPU fp32), {cpu_s:.2f} s',
+                'value': vid_len * args.nq / cpu_s, 'unit': 'clips/s', 'cores': ncores, 'kind': 'port',
+                'sample': f'1 video x {args.nq} query, T={T}: oracle/decafnet_ref.py forward_eval (torch {torch.__version__} CPU fp32, MKLDNN), '
+                          f'one warm-up then best of 3, {cpu_s:.2f} s, torch.set_num_threads({ncores}) = physical cores available',
+                'cpu': cpu_model(),
             }
+            # thread sweep on a bounded sample (T = 4096: a quarter of the video)
+            sT = min(T, args.cpu_T or 4096)
+            sinp = pkg.synth.make_inputs(kw['D'], sT, sT, 1, kw['text_in'], 32, 2025 + 3)
+            st_, sm_ = R.encode_text(sd, opt.model, sinp['tokens'][0][None], torch.ones(1, 1, 32, dtype=torch.bool))
+            sweep = {}
+            for nt in sorted({1, 8, ncores}):
+                if nt > ncores:
+                    continue
+                torch.set_num_threads(nt)
+                oracle_forward(sinp, [st_], [sm_])
+                s_ = best_of(2, lambda: oracle_forward(sinp, [st_], [sm_]))
+                sweep[str(nt)] = {'clips_per_s': sT / s_, 's': s_}
+            result['cpu_baseline']['thread_sweep'] = {'sample': f'1 video x 1 query, T={sT}, one warm-up then best of 2', 'threads': sweep}
+            result['cpu_baseline']['crosscheck'] = ('build container, 8 threads, T=16384, warm best of 3 (profiles/r02_cpu_crosscheck.json, tools/cpu_crosscheck.py): '
+                                                    'the real reference 19.9 k clips/s, this oracle 15.2 k (0.76x; outputs agree to 1.3e-6)')
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

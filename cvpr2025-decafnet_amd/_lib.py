@@ -47,6 +47,7 @@ SIGNATURES = {
     'dcf_forward_eval_gated': (i32, [vp, c_f32p, c_f32p, c_u8p, i64, i32, ctypes.POINTER(vp), ctypes.POINTER(vp),
                                      ctypes.POINTER(i32), c_f32p, c_f32p, c_f32p, c_u8p, vp]),
     'dcf_debug_copy': (i32, [vp, i32, c_f32p, i64, vp]),
+    'dcf_graph_active': (i32, [vp]),
     'dcf_profile_enable': (i32, [i32]),
     'dcf_profile_report': (i64, [ctypes.c_char_p, i64]),
     'dcf_collect_segments': (i32, [c_f32p, c_f32p, c_u8p, i32, i64, i32, f32, i32, f32, c_f32p, c_f32p, c_i32p, vp]),
@@ -66,6 +67,10 @@ SIGNATURES = {
     'dcf_op_local_attn': (i32, [c_f32p, c_f32p, c_f32p, c_u8p, c_f32p, i32, i32, i32, i32, i32, vp]),
     'dcf_op_sidekick': (i32, [c_f32p, c_f32p, c_f32p, i32, i32, i32, i32, vp]),
     'dcf_op_gate': (i32, [c_f32p, c_u8p, c_f32p, c_u8p, i32, i32, i32, f64, i32, vp]),
+    'dcf_op_encoder': (i32, [vp, ctypes.c_char_p, c_f32p, c_u8p, i32, i32, i32, c_f32p, c_u8p, vp]),
+    'dcf_op_enc_pre': (i32, [vp, ctypes.c_char_p, c_f32p, c_u8p, i32, i32, i32, c_f32p, c_f32p, c_f32p, c_f32p, vp]),
+    'dcf_op_decoder': (i32, [vp, ctypes.c_char_p, c_f32p, c_u8p, i32, i32, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(i32), vp]),
+    'dcf_op_tcn': (i32, [vp, ctypes.c_char_p, c_f32p, c_u8p, i32, i32, i32, i32, c_f32p, vp]),
 }
 
 

@@ -189,6 +189,13 @@ struct dcf_model {
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   bool capturing = false;
+  std::vector<uint64_t> nocapture_key;       // argument set whose capture failed: run it eagerly, do not retry every call
+  int last_launch = 0;                       // how the last forward was issued: 0 eager, 1 graph replay, 2 graph capture + launch
+  // The legacy default stream (NULL: what torch's default stream is) cannot be captured.  A forward called on it hops to
+  // this engine-owned non-blocking stream, ordered after / before the caller's stream by two events, so that the
+  // reference's calling pattern (one stream, one video per call) replays a graph too.
+  hipStream_t own = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
   // second stream for the two independent branches of the forward (fork_side / join_side)
   hipStream_t side = nullptr;
   hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
@@ -199,6 +206,7 @@ struct dcf_model {
   } dbg;
   float* dbg_vidmap = nullptr;
   float* dbg_fused = nullptr;
+  int64_t dbg_cap = 0;                        // capacity (floats) of the armed tap destinations
   bool keep_debug = false;
 };
 
@@ -231,6 +239,9 @@ static int free_model(dcf_model* m) {
     if (m->ev_join[i]) (void)hipEventDestroy(m->ev_join[i]);
   }
   if (m->side) (void)hipStreamDestroy(m->side);
+  if (m->ev_in) (void)hipEventDestroy(m->ev_in);
+  if (m->ev_out) (void)hipEventDestroy(m->ev_out);
+  if (m->own) (void)hipStreamDestroy(m->own);
   return 0;
 }
 
@@ -300,6 +311,66 @@ static int resolve_encoder(dcf_model* m, const std::string& p, int E, hipStream_
   return 0;
 }
 
+// TransformerDecoder parameters (blocks.py:594-630) under prefix p
+static int resolve_decoder(dcf_model* m, const std::string& p, int E, int TE, hipStream_t st, DecW& w) {
+  const float* t;
+  GET(p + ".ln_xattn_q.weight", SH(E), w.ln_q_w); GET(p + ".ln_xattn_q.bias", SH(E), w.ln_q_b);
+  GET(p + ".ln_xattn_kv.weight", SH(TE), w.ln_kv_w); GET(p + ".ln_xattn_kv.bias", SH(TE), w.ln_kv_b);
+  GET(p + ".xattn.q_conv.conv.weight", SH(E, 3), t); if (pack3(m, t, 1, E, 3, 0, 2, 1, st, &w.dw)) return -1;
+  GET(p + ".xattn.q_norm.weight", SH(E), w.qn_w); GET(p + ".xattn.q_norm.bias", SH(E), w.qn_b);
+  GET(p + ".xattn.xattn.query.weight", SH(E, E), w.wq); GET(p + ".xattn.xattn.query.bias", SH(E), w.bq);
+  GET(p + ".xattn.xattn.key.weight", SH(E, TE), w.wk); GET(p + ".xattn.xattn.key.bias", SH(E), w.bk);
+  GET(p + ".xattn.xattn.value.weight", SH(E, TE), w.wv); GET(p + ".xattn.xattn.value.bias", SH(E), w.bv);
+  GET(p + ".xattn.xattn.proj.weight", SH(2 * E, E), w.wp); GET(p + ".xattn.xattn.proj.bias", SH(2 * E), w.bp);
+  GET(p + ".ln_ffn.weight", SH(E), w.ln_ffn_w); GET(p + ".ln_ffn.bias", SH(E), w.ln_ffn_b);
+  GET(p + ".ffn.fc.weight", SH(4 * E, E), w.fc_w); GET(p + ".ffn.fc.bias", SH(4 * E), w.fc_b);
+  GET(p + ".ffn.proj.weight", SH(E, 4 * E), w.pj_w); GET(p + ".ffn.proj.bias", SH(E), w.pj_b);
+  GET(p + ".drop_path_ffn.scale", SH(E), w.ls_ffn);
+  SPLIT(w.wq, E, E); SPLIT(w.wk, E, TE); SPLIT(w.wv, E, TE); SPLIT(w.wp, 2 * E, E);
+  SPLIT(w.fc_w, 4 * E, E); SPLIT(w.pj_w, E, 4 * E);
+  return 0;
+}
+
+// TCN parameters (tcn.py:40-64) under prefix p: in (32, n_in, 1) -> [n_in][32]; dilated (32,32,3) -> [3][ci][co];
+// 1x1 (32,32,1) -> [ci][co]
+static int resolve_tcn(dcf_model* m, const std::string& pre, int n_in, int n_layers, hipStream_t st) {
+  const float* t;
+  m->tcn_wd.clear(); m->tcn_bd.clear(); m->tcn_wp.clear(); m->tcn_bp.clear(); m->tcn_lnw.clear(); m->tcn_lnb.clear();
+  GET(pre + ".conv_1x1.weight", SH(TCN_HID, n_in), t); if (pack3(m, t, 1, TCN_HID, n_in, 0, 2, 1, st, &m->tcn_in_w)) return -1;
+  GET(pre + ".conv_1x1.bias", SH(TCN_HID), m->tcn_in_b);
+  for (int i = 0; i < n_layers; ++i) {
+    const std::string p = pre + ".layers." + std::to_string(i);
+    const float* pk;
+    GET(p + ".conv_dilated.weight", SH(TCN_HID, TCN_HID, 3), t);
+    if (pack3(m, t, TCN_HID, TCN_HID, 3, 2, 1, 0, st, &pk)) return -1;
+    m->tcn_wd.push_back(pk);
+    GET(p + ".conv_dilated.bias", SH(TCN_HID), t); m->tcn_bd.push_back(t);
+    GET(p + ".conv_1x1.weight", SH(TCN_HID, TCN_HID), t);
+    if (pack3(m, t, 1, TCN_HID, TCN_HID, 0, 2, 1, st, &pk)) return -1;
+    m->tcn_wp.push_back(pk);
+    GET(p + ".conv_1x1.bias", SH(TCN_HID), t); m->tcn_bp.push_back(t);
+    GET(p + ".norm.weight", SH(TCN_HID), t); m->tcn_lnw.push_back(t);
+    GET(p + ".norm.bias", SH(TCN_HID), t); m->tcn_lnb.push_back(t);
+  }
+  GET(pre + ".conv_out.weight", SH(TCN_HID, TCN_HID), t);
+  if (pack3(m, t, 1, TCN_HID, TCN_HID, 0, 2, 1, st, &m->tcn_out_w)) return -1;
+  GET(pre + ".conv_out.bias", SH(TCN_HID), m->tcn_out_b);
+  return 0;
+}
+
+// dense-conv arithmetic of the model (dcf_config.gemm_mode) and its status words
+static int init_gemm_mode(dcf_model* m, hipStream_t st) {
+  const int gm = m->cfg.gemm_mode;
+  DCF_CHECK(gm == 0 || gm == 1 || gm == 6 || gm == 16, "gemm_mode %d: use 0 / 16 (f16x3), 6 (bf16x6) or 1 (fp32); the bf16x3 mode was replaced by f16x3", gm);
+  m->gemm_terms = gm == 1 ? 0 : (gm == 6 ? GEMM_BF16X6 : GEMM_F16X3);
+  if (const char* ev = getenv("DCF_GEMM_MODE"))
+    m->gemm_terms = !strcmp(ev, "fp32") ? 0 : (!strcmp(ev, "x6") || !strcmp(ev, "bf16x6") ? GEMM_BF16X6 : GEMM_F16X3);
+  if (m->force_x6 && m->gemm_terms == GEMM_F16X3) m->gemm_terms = GEMM_BF16X6;
+  if (!m->status) DCF_HIP(hipMalloc(&m->status, 2 * sizeof(unsigned)));
+  DCF_HIP(hipMemsetAsync(m->status, 0, 2 * sizeof(unsigned), st));
+  return 0;
+}
+
 static int resolve_head(dcf_model* m, const std::string& p, const std::string& out_name, int C, int NO, int layers,
                         hipStream_t st, HeadW& h) {
   const float* t;
@@ -337,16 +408,7 @@ static int finalize(dcf_model* m, hipStream_t st) {
   m->wsplit.clear();
   m->wsplit_ldw.clear();
   m->wsplit_terms.clear();
-  {
-    const int gm = c.gemm_mode;
-    DCF_CHECK(gm == 0 || gm == 1 || gm == 6 || gm == 16, "gemm_mode %d: use 0 / 16 (f16x3), 6 (bf16x6) or 1 (fp32); the bf16x3 mode was replaced by f16x3", gm);
-    m->gemm_terms = gm == 1 ? 0 : (gm == 6 ? GEMM_BF16X6 : GEMM_F16X3);
-    if (const char* ev = getenv("DCF_GEMM_MODE"))
-      m->gemm_terms = !strcmp(ev, "fp32") ? 0 : (!strcmp(ev, "x6") || !strcmp(ev, "bf16x6") ? GEMM_BF16X6 : GEMM_F16X3);
-    if (m->force_x6 && m->gemm_terms == GEMM_F16X3) m->gemm_terms = GEMM_BF16X6;
-    if (!m->status) DCF_HIP(hipMalloc(&m->status, 2 * sizeof(unsigned)));
-    DCF_HIP(hipMemsetAsync(m->status, 0, 2 * sizeof(unsigned), st));
-  }
+  if (init_gemm_mode(m, st)) return -1;
   m->dec.clear(); m->stem.clear(); m->branch.clear();
   m->embd_conv.clear(); m->embd_ln_w.clear(); m->embd_ln_b.clear();
   m->cls1 = HeadW(); m->cls2 = HeadW(); m->reg = HeadW();
@@ -431,22 +493,8 @@ static int finalize(dcf_model* m, hipStream_t st) {
     if (m->vid_w2 && split_weight(m, m->vid_w2, E, D, st, m->vid_ldw, vidmap_x6 ? GEMM_BF16X6 : 0)) return -1;
   }
   for (int i = 0; i < c.fusion_layers; ++i) {
-    const std::string p = "fusion.layers." + std::to_string(i);
     DecW w{};
-    GET(p + ".ln_xattn_q.weight", SH(E), w.ln_q_w); GET(p + ".ln_xattn_q.bias", SH(E), w.ln_q_b);
-    GET(p + ".ln_xattn_kv.weight", SH(TE), w.ln_kv_w); GET(p + ".ln_xattn_kv.bias", SH(TE), w.ln_kv_b);
-    GET(p + ".xattn.q_conv.conv.weight", SH(E, 3), t); if (pack3(m, t, 1, E, 3, 0, 2, 1, st, &w.dw)) return -1;
-    GET(p + ".xattn.q_norm.weight", SH(E), w.qn_w); GET(p + ".xattn.q_norm.bias", SH(E), w.qn_b);
-    GET(p + ".xattn.xattn.query.weight", SH(E, E), w.wq); GET(p + ".xattn.xattn.query.bias", SH(E), w.bq);
-    GET(p + ".xattn.xattn.key.weight", SH(E, TE), w.wk); GET(p + ".xattn.xattn.key.bias", SH(E), w.bk);
-    GET(p + ".xattn.xattn.value.weight", SH(E, TE), w.wv); GET(p + ".xattn.xattn.value.bias", SH(E), w.bv);
-    GET(p + ".xattn.xattn.proj.weight", SH(2 * E, E), w.wp); GET(p + ".xattn.xattn.proj.bias", SH(2 * E), w.bp);
-    GET(p + ".ln_ffn.weight", SH(E), w.ln_ffn_w); GET(p + ".ln_ffn.bias", SH(E), w.ln_ffn_b);
-    GET(p + ".ffn.fc.weight", SH(4 * E, E), w.fc_w); GET(p + ".ffn.fc.bias", SH(4 * E), w.fc_b);
-    GET(p + ".ffn.proj.weight", SH(E, 4 * E), w.pj_w); GET(p + ".ffn.proj.bias", SH(E), w.pj_b);
-    GET(p + ".drop_path_ffn.scale", SH(E), w.ls_ffn);
-    SPLIT(w.wq, E, E); SPLIT(w.wk, E, TE); SPLIT(w.wv, E, TE); SPLIT(w.wp, 2 * E, E);
-    SPLIT(w.fc_w, 4 * E, E); SPLIT(w.pj_w, E, 4 * E);
+    if (resolve_decoder(m, "fusion.layers." + std::to_string(i), E, TE, st, w)) return -1;
     m->dec.push_back(w);
   }
   GET("fusion.ln_out.weight", SH(E), m->fus_out_w); GET("fusion.ln_out.bias", SH(E), m->fus_out_b);
@@ -484,28 +532,7 @@ static int finalize(dcf_model* m, hipStream_t st) {
     GET("reg_head.scales." + std::to_string(l) + ".scale", SH(1), t);
     DCF_HIP(hipMemcpyAsync(&m->reg_scales[l], t, sizeof(float), hipMemcpyDeviceToHost, st));
   }
-  if (c.model_kind == 0) {
-  // TCN (refine): in (32, L, 1) -> [L][32]; dilated (32,32,3) -> [3][ci][co]; 1x1 (32,32,1) -> [ci][co]
-  GET("refine.conv_1x1.weight", SH(TCN_HID, L), t); if (pack3(m, t, 1, TCN_HID, L, 0, 2, 1, st, &m->tcn_in_w)) return -1;
-  GET("refine.conv_1x1.bias", SH(TCN_HID), m->tcn_in_b);
-  for (int i = 0; i < L; ++i) {
-    const std::string p = "refine.layers." + std::to_string(i);
-    const float* pk;
-    GET(p + ".conv_dilated.weight", SH(TCN_HID, TCN_HID, 3), t);
-    if (pack3(m, t, TCN_HID, TCN_HID, 3, 2, 1, 0, st, &pk)) return -1;
-    m->tcn_wd.push_back(pk);
-    GET(p + ".conv_dilated.bias", SH(TCN_HID), t); m->tcn_bd.push_back(t);
-    GET(p + ".conv_1x1.weight", SH(TCN_HID, TCN_HID), t);
-    if (pack3(m, t, 1, TCN_HID, TCN_HID, 0, 2, 1, st, &pk)) return -1;
-    m->tcn_wp.push_back(pk);
-    GET(p + ".conv_1x1.bias", SH(TCN_HID), t); m->tcn_bp.push_back(t);
-    GET(p + ".norm.weight", SH(TCN_HID), t); m->tcn_lnw.push_back(t);
-    GET(p + ".norm.bias", SH(TCN_HID), t); m->tcn_lnb.push_back(t);
-  }
-  GET("refine.conv_out.weight", SH(TCN_HID, TCN_HID), t);
-  if (pack3(m, t, 1, TCN_HID, TCN_HID, 0, 2, 1, st, &m->tcn_out_w)) return -1;
-  GET("refine.conv_out.bias", SH(TCN_HID), m->tcn_out_b);
-  }
+  if (c.model_kind == 0 && resolve_tcn(m, "refine", L, L, st)) return -1;
   DCF_HIP(hipStreamSynchronize(st));
   for (auto& pl : m->plans) if (pl.d_lt) (void)hipFree(pl.d_lt);
   m->plans.clear();                           // reg scales live in the level tables
@@ -829,7 +856,7 @@ static int run_fusion(dcf_model* m, Buffers& b, float* X, int64_t ldx, int B, in
     GemmArgs go = gemm(b.HID, 4 * E, w.pj_w, w.pj_b, X, ldx, rows, E, 4 * E);
     go.flags = G_RES | G_OUT_MASK; go.rowmask = mask; go.ls = w.ls_ffn; go.R = b.R[2]; go.ldr = E;
     static const bool ffn_first = getenv("DCF_FFN_FUSE_MIN_ROWS") != nullptr;   // the fused FFN has no LayerNorm epilogue
-    if (li + 1 == m->dec.size() && !ffn_first && can_fuse_ln(m, w.pj_w, rows, E, 4 * E, A_ROWS)) {
+    if (li + 1 == m->dec.size() && !ffn_first && m->fus_out_w && can_fuse_ln(m, w.pj_w, rows, E, 4 * E, A_ROWS)) {
       // last layer: only ln_out(x) is consumed afterwards (fusion.py:64-66), the raw stream is not written
       GemmArgs gf = gemm(b.R[0], E, w.fc_w, w.fc_b, b.HID, 4 * E, rows, 4 * E, E);
       gf.flags = G_GELU;
@@ -840,6 +867,7 @@ static int run_fusion(dcf_model* m, Buffers& b, float* X, int64_t ldx, int B, in
     }
     TRY(run_ffn(m, b.R[0], w.fc_w, w.fc_b, go, b.HID, rows, E, st));
   }
+  if (!m->fus_out_w) return 0;          // dcf_op_decoder: the bare layer stack, result left in X
   LnArgs ln{}; ln.X = X; ln.ldx = ldx; ln.Y = out; ln.ldy = ld_out; ln.w = m->fus_out_w; ln.b = m->fus_out_b; ln.rows = rows; ln.C = E;
   TRY(launch_ln(ln, st));
   return 0;
@@ -963,6 +991,7 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
     // ---- vid_map (model.py:543-555)
     TRY(launch_vidmap_combine(m->vid_w1 ? b.P1 : nullptr, m->vid_w2 ? b.P2 : nullptr, m->vid_map_b, b.gate, mask0,
                               m->vid_w3, m->vid_w3 ? b.correl + (int64_t)q0 * T0 : nullptr, b.X, T0, rows0, E, vmap, st));
+    if (m->keep_debug) DCF_CHECK((int64_t)rows0 * E <= m->dbg_cap, "dcf_debug_copy: armed destination holds %lld floats, the tap needs %lld", (long long)m->dbg_cap, (long long)rows0 * E);
     if (m->keep_debug && m->dbg_vidmap) DCF_HIP(hipMemcpyAsync(m->dbg_vidmap, b.X, (size_t)rows0 * E * 4, hipMemcpyDeviceToDevice, st));
 
     // ---- text side: pointers of this chunk
@@ -1074,6 +1103,8 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
     m->dbg.correl = b.correl; m->dbg.gate = b.gate; m->dbg.F = b.F;
     m->dbg.nq = nq; m->dbg.T0 = T0; m->dbg.B = B; m->dbg.S = S;
   }
+  m->keep_debug = false;                      // the taps of dcf_debug_copy(2 / 3) fill once
+  m->dbg_vidmap = m->dbg_fused = nullptr;
   return 0;
 }
 
@@ -1152,7 +1183,7 @@ static int text_encode(dcf_model* m, const float* tokens, const uint8_t* token_m
 extern "C" {
 
 const char* dcf_last_error(void) { return dcf::g_err.c_str(); }
-int dcf_abi_version(void) { return 3; }
+int dcf_abi_version(void) { return 4; }
 
 int dcf_model_create(const dcf_config* cfg, dcf_model** out) {
   DCF_CHECK(cfg && out, "dcf_model_create: null argument");
@@ -1191,12 +1222,9 @@ int dcf_model_bind(dcf_model* m, const char* name, const float* data, const int6
 
 namespace dcf {
 // eager on the first call with a given argument set, capture + replay from the second identical call on
-static int forward_maybe_graph(dcf_model* m, const VideoSet& vs, int T0, int nq,
-                               const float* const* text, const uint8_t* const* text_mask, const int32_t* text_len,
-                               const float* gate, float* lo, float* oo, uint8_t* mo, hipStream_t st) {
-  static const bool no_graph = getenv("DCF_NO_GRAPH") != nullptr;
-  const bool eligible = !no_graph && !g_prof_on && !m->keep_debug && nq > 0;
-  if (!eligible) return forward(m, vs, T0, nq, text, text_mask, text_len, gate, lo, oo, mo, st);
+static int forward_graph_on(dcf_model* m, const VideoSet& vs, int T0, int nq,
+                            const float* const* text, const uint8_t* const* text_mask, const int32_t* text_len,
+                            const float* gate, float* lo, float* oo, uint8_t* mo, hipStream_t st) {
   std::vector<uint64_t> key = {(uint64_t)vs.nvid, (uint64_t)T0, (uint64_t)nq,
                                (uint64_t)gate, (uint64_t)lo, (uint64_t)oo, (uint64_t)mo, (uint64_t)st, (uint64_t)m->pe, (uint64_t)m->pe_T};
   for (int v = 0; v < vs.nvid; ++v) {
@@ -1208,11 +1236,13 @@ static int forward_maybe_graph(dcf_model* m, const VideoSet& vs, int T0, int nq,
     key.push_back(text_mask ? (uint64_t)text_mask[q] : 0);
     key.push_back((uint64_t)text_len[q]);
   }
+  m->last_launch = 0;
   if (m->graph_exec && key == m->graph_key) {
     DCF_HIP(hipGraphLaunch(m->graph_exec, st));
+    m->last_launch = 1;
     return 0;
   }
-  if (key != m->last_key) {                          // first sighting: run eagerly (allocates workspace / plans)
+  if (key != m->last_key || key == m->nocapture_key) {   // first sighting (allocates workspace / plans), or known not to capture
     m->last_key = key;
     return forward(m, vs, T0, nq, text, text_mask, text_len, gate, lo, oo, mo, st);
   }
@@ -1221,6 +1251,7 @@ static int forward_maybe_graph(dcf_model* m, const VideoSet& vs, int T0, int nq,
   m->last_key = key;
   if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
     (void)hipGetLastError();
+    m->nocapture_key = key;
     return forward(m, vs, T0, nq, text, text_mask, text_len, gate, lo, oo, mo, st);
   }
   m->capturing = true;
@@ -1231,6 +1262,7 @@ static int forward_maybe_graph(dcf_model* m, const VideoSet& vs, int T0, int nq,
   if (rc != 0 || ec != hipSuccess || !g) {           // capture failed: nothing ran; fall back to an eager forward
     (void)hipGetLastError();
     if (g) (void)hipGraphDestroy(g);
+    m->nocapture_key = key;
     const std::string err = g_err;
     const int rc2 = forward(m, vs, T0, nq, text, text_mask, text_len, gate, lo, oo, mo, st);
     if (rc2 != 0 && !err.empty()) g_err = err;
@@ -1240,13 +1272,39 @@ static int forward_maybe_graph(dcf_model* m, const VideoSet& vs, int T0, int nq,
   if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) {
     (void)hipGetLastError();
     (void)hipGraphDestroy(g);
+    m->nocapture_key = key;
     return forward(m, vs, T0, nq, text, text_mask, text_len, gate, lo, oo, mo, st);
   }
   m->graph = g;
   m->graph_exec = ge;
   m->graph_key = key;
   DCF_HIP(hipGraphLaunch(ge, st));
+  m->last_launch = 2;
   return 0;
+}
+
+static int forward_maybe_graph(dcf_model* m, const VideoSet& vs, int T0, int nq,
+                               const float* const* text, const uint8_t* const* text_mask, const int32_t* text_len,
+                               const float* gate, float* lo, float* oo, uint8_t* mo, hipStream_t st) {
+  static const bool no_graph = getenv("DCF_NO_GRAPH") != nullptr;
+  const bool eligible = !no_graph && !g_prof_on && !m->keep_debug && nq > 0;
+  if (!eligible) {
+    m->last_launch = 0;
+    return forward(m, vs, T0, nq, text, text_mask, text_len, gate, lo, oo, mo, st);
+  }
+  if (st != nullptr) return forward_graph_on(m, vs, T0, nq, text, text_mask, text_len, gate, lo, oo, mo, st);
+  // legacy default stream: hop to the engine's own stream (see dcf_model::own)
+  if (!m->own) {
+    DCF_HIP(hipStreamCreateWithFlags(&m->own, hipStreamNonBlocking));
+    DCF_HIP(hipEventCreateWithFlags(&m->ev_in, hipEventDisableTiming));
+    DCF_HIP(hipEventCreateWithFlags(&m->ev_out, hipEventDisableTiming));
+  }
+  DCF_HIP(hipEventRecord(m->ev_in, st));
+  DCF_HIP(hipStreamWaitEvent(m->own, m->ev_in, 0));
+  const int rc = forward_graph_on(m, vs, T0, nq, text, text_mask, text_len, gate, lo, oo, mo, m->own);
+  DCF_HIP(hipEventRecord(m->ev_out, m->own));
+  DCF_HIP(hipStreamWaitEvent(st, m->ev_out, 0));
+  return rc;
 }
 }  // namespace dcf
 
@@ -1340,6 +1398,8 @@ int dcf_forward_eval_gated(dcf_model* m, const float* vid, const float* shallow_
                                   logits_out, offsets_out, masks_out, (hipStream_t)stream);
 }
 
+int dcf_graph_active(const dcf_model* m) { return m ? m->last_launch : 0; }
+
 int dcf_debug_copy(dcf_model* m, int32_t what, float* dst, int64_t max_floats, void* stream) {
   DCF_CHECK(m && dst, "dcf_debug_copy: null argument");
   hipStream_t st = (hipStream_t)stream;
@@ -1351,8 +1411,10 @@ int dcf_debug_copy(dcf_model* m, int32_t what, float* dst, int64_t max_floats, v
     case 1: src = m->dbg.gate; n = (int64_t)m->dbg.B * m->dbg.T0; break;
     case 4: src = m->dbg.F; n = (int64_t)m->dbg.B * m->dbg.S * (E + dcf::TCN_HID); break;
     case 2: case 3: {
-      // these buffers are overwritten during the forward: arm the capture, the NEXT forward fills dst
+      // these buffers are overwritten during the forward: arm the tap, the NEXT forward fills dst (rows0 * E floats of its
+      // last query chunk) and disarms it again
       m->keep_debug = true;
+      m->dbg_cap = max_floats;
       if (what == 2) m->dbg_vidmap = dst; else m->dbg_fused = dst;
       return 0;
     }
@@ -1595,6 +1657,135 @@ int dcf_op_gate(const float* correl, const uint8_t* vid_mask, float* gate, uint8
                 int32_t sn, double sratio, int32_t msf, void* stream) {
   dcf::GateArgs a{correl, vid_mask, gate, mask_out, T, nq, 0, sn, msf, sratio};
   return dcf::launch_gate(a, (hipStream_t)stream);
+}
+
+// ---- composite blocks on a scratch model (parity tests against the reference's operator fixtures) ----------------
+namespace dcf {
+// a scratch model holds only the bound parameters of one block: never finalized, its packed images are dropped after every call
+static int scratch_begin(dcf_model* m, const char* what, hipStream_t st) {
+  DCF_CHECK(m && !m->finalized, "%s: needs a scratch model (dcf_model_create + dcf_model_bind of the block's parameters, not finalized)", what);
+  return init_gemm_mode(m, st);
+}
+static int scratch_end(dcf_model* m, hipStream_t st, int rc) {
+  (void)hipStreamSynchronize(st);
+  for (float* p : m->owned) (void)hipFree(p);
+  m->owned.clear();
+  m->wsplit.clear(); m->wsplit_ldw.clear(); m->wsplit_terms.clear();
+  m->dec.clear();
+  m->fus_out_w = m->fus_out_b = nullptr;
+  return rc;
+}
+struct ScratchArena {
+  char* base = nullptr;
+  ~ScratchArena() { if (base) (void)hipFree(base); }
+};
+}  // namespace dcf
+
+int dcf_op_encoder(dcf_model* m, const char* prefix, const float* X, const uint8_t* mask, int32_t B, int32_t T, int32_t stride,
+                   float* Y, uint8_t* mask_out, void* stream) {
+  using namespace dcf;
+  hipStream_t st = (hipStream_t)stream;
+  DCF_CHECK(prefix && X && mask && Y && mask_out && B >= 1 && T >= 1 && (stride == 1 || stride == 2) && T % stride == 0, "dcf_op_encoder: bad arguments");
+  if (scratch_begin(m, "dcf_op_encoder", st)) return -1;
+  const dcf_config& c = m->cfg;
+  const int half = c.win / 2;
+  DCF_CHECK(half == 0 || (T / stride) % half == 0, "dcf_op_encoder: T / stride = %d must be a multiple of win//2 = %d (blocks.py:216)", T / stride, half);
+  EncW w{};
+  int rc = resolve_encoder(m, prefix, c.E, st, w);
+  ScratchArena sa;
+  if (rc == 0) {
+    Buffers b{};
+    Arena dry{nullptr, 0, 0, true};
+    carve(dry, c, T, B, B, T, 1, 1, b);
+    if (hipMalloc(&sa.base, dry.off) != hipSuccess) { set_error("dcf_op_encoder: out of memory"); rc = -1; }
+    if (rc == 0) {
+      Arena real{sa.base, 0, dry.off, false};
+      carve(real, c, T, B, B, T, 1, 1, b);
+      if (stride == 2) rc = launch_mask_down(mask, mask_out, B * T / 2, st);
+      else if (hipMemcpyAsync(mask_out, mask, (size_t)B * T, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = -1;
+      if (rc == 0) rc = run_encoder(m, w, b, X, c.E, mask, mask_out, B, T, stride, Y, c.E, st);
+    }
+  }
+  return scratch_end(m, st, rc);
+}
+
+int dcf_op_enc_pre(dcf_model* m, const char* prefix, const float* X, const uint8_t* mask, int32_t B, int32_t T, int32_t stride,
+                   float* Qc, float* Kc, float* Vc, float* Skip, void* stream) {
+  using namespace dcf;
+  hipStream_t st = (hipStream_t)stream;
+  DCF_CHECK(prefix && X && mask && Qc && Kc && Vc && B >= 1 && T >= 1 && (stride == 1 || (stride == 2 && Skip)) && T % stride == 0, "dcf_op_enc_pre: bad arguments");
+  if (scratch_begin(m, "dcf_op_enc_pre", st)) return -1;
+  EncW w{};
+  int rc = resolve_encoder(m, prefix, m->cfg.E, st, w);
+  if (rc == 0) {
+    EncPreArgs ep{};
+    ep.X = X; ep.ldx = m->cfg.E; ep.mask_in = mask; ep.ln_w = w.ln_attn_w; ep.ln_b = w.ln_attn_b;
+    ep.dw_q = w.dw_q; ep.dw_k = w.dw_k; ep.dw_v = w.dw_v;
+    ep.qn_w = w.qn_w; ep.qn_b = w.qn_b; ep.kn_w = w.kn_w; ep.kn_b = w.kn_b; ep.vn_w = w.vn_w; ep.vn_b = w.vn_b;
+    ep.Qc = Qc; ep.Kc = Kc; ep.Vc = Vc; ep.Skip = stride == 2 ? Skip : nullptr;
+    ep.B = B; ep.T_in = T; ep.C = m->cfg.E;
+    rc = launch_enc_pre(ep, stride, st);
+  }
+  return scratch_end(m, st, rc);
+}
+
+int dcf_op_decoder(dcf_model* m, const char* prefix, float* X, const uint8_t* mask, int32_t B, int32_t T,
+                   const float* const* text, const uint8_t* const* text_mask, const int32_t* text_len, void* stream) {
+  using namespace dcf;
+  hipStream_t st = (hipStream_t)stream;
+  DCF_CHECK(prefix && X && mask && text && text_len && B >= 1 && B <= DCF_MAX_BATCH && T >= 1, "dcf_op_decoder: bad arguments");
+  if (scratch_begin(m, "dcf_op_decoder", st)) return -1;
+  const dcf_config& c = m->cfg;
+  DecW w{};
+  int rc = resolve_decoder(m, prefix, c.E, c.TE, st, w);
+  ScratchArena sa;
+  if (rc == 0) {
+    m->dec.assign(1, w);
+    m->fus_out_w = m->fus_out_b = nullptr;
+    int Lk = 1;
+    TextMeta tm{};
+    for (int i = 0; i < B; ++i) {
+      tm.text[i] = text[i]; tm.text_mask[i] = text_mask ? text_mask[i] : nullptr; tm.len[i] = text_len[i];
+      Lk = std::max(Lk, (int)text_len[i]);
+    }
+    Buffers b{};
+    Arena dry{nullptr, 0, 0, true};
+    carve(dry, c, T, B, B, T, Lk, 1, b);
+    if (hipMalloc(&sa.base, dry.off) != hipSuccess) { set_error("dcf_op_decoder: out of memory"); rc = -1; }
+    if (rc == 0) {
+      Arena real{sa.base, 0, dry.off, false};
+      carve(real, c, T, B, B, T, Lk, 1, b);
+      rc = run_fusion(m, b, X, c.E, B, T, nullptr, mask, nullptr, &tm, Lk, X, c.E, st);
+    }
+  }
+  return scratch_end(m, st, rc);
+}
+
+int dcf_op_tcn(dcf_model* m, const char* prefix, const float* x, const uint8_t* mask, int32_t B, int32_t T, int32_t n_in,
+               int32_t n_layers, float* Y, void* stream) {
+  using namespace dcf;
+  hipStream_t st = (hipStream_t)stream;
+  DCF_CHECK(prefix && x && mask && Y && B >= 1 && T >= 1 && n_in >= 1 && n_in <= DCF_MAX_LEVELS && n_layers >= 0, "dcf_op_tcn: bad arguments");
+  if (scratch_begin(m, "dcf_op_tcn", st)) return -1;
+  int rc = resolve_tcn(m, prefix, n_in, n_layers, st);
+  float* buf = nullptr;
+  if (rc == 0 && hipMalloc(&buf, (size_t)2 * B * T * TCN_HID * sizeof(float)) != hipSuccess) { set_error("dcf_op_tcn: out of memory"); rc = -1; }
+  if (rc == 0) {
+    LevelTable lt{};
+    lt.n_levels = n_in; lt.B = B; lt.T[0] = T; lt.S = T;
+    RefineArgs ra{};
+    ra.stacked = x; ra.mask_all = mask;
+    ra.w_in = m->tcn_in_w; ra.b_in = m->tcn_in_b;
+    ra.host_w_dil = m->tcn_wd.data(); ra.host_b_dil = m->tcn_bd.data(); ra.host_w_pw = m->tcn_wp.data();
+    ra.host_b_pw = m->tcn_bp.data(); ra.host_ln_w = m->tcn_lnw.data(); ra.host_ln_b = m->tcn_lnb.data();
+    ra.w_out = m->tcn_out_w; ra.b_out = m->tcn_out_b;
+    ra.bufA = buf; ra.bufB = buf + (size_t)B * T * TCN_HID; ra.F = Y; ra.ldf = TCN_HID; ra.E = 0;
+    ra.B = B; ra.T0 = T; ra.n_levels = n_in; ra.n_layers = n_layers;
+    rc = launch_refine(ra, lt, st);
+  }
+  rc = scratch_end(m, st, rc);
+  if (buf) (void)hipFree(buf);
+  return rc;
 }
 
 }  // extern "C"

@@ -46,6 +46,8 @@ struct RefineArgs {
   float* bufA; float* bufB;           // [B*T0][32] ping-pong
   float* F; int64_t ldf; int E;       // pyramid feature buffer; refined logits go to columns [E, E+32)
   int B, T0, n_levels, n_layers;
+  const float* stacked;               // optional [B*T0][n_levels] TCN input given directly (dcf_op_tcn); then logits1 / lt are
+                                      // not read and nothing is pooled down a pyramid
 };
 int launch_refine(const RefineArgs& a, const LevelTable& host_lt, hipStream_t st);
 

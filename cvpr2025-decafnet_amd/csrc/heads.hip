@@ -128,8 +128,13 @@ __global__ __launch_bounds__(64) void k_refine_in(RefineArgs p) {
   for (int c = 0; c < TCN_HID; ++c) h[c] = p.b_in[c];
   for (int l = 0; l < p.n_levels; ++l) {
     // nearest source index floor(t * T_l / T_0) = t >> l  (T_0 = T_l * 2^l exactly)
-    float u = p.logits1[lt->start[l] + b * lt->T[l] + (t >> l)];
-    if (l > 0) u *= m0;
+    float u;
+    if (p.stacked) {
+      u = p.stacked[(int64_t)r * p.n_levels + l];
+    } else {
+      u = p.logits1[lt->start[l] + b * lt->T[l] + (t >> l)];
+      if (l > 0) u *= m0;
+    }
 #pragma unroll
     for (int c = 0; c < TCN_HID; ++c) h[c] += p.w_in[l * TCN_HID + c] * u;
   }
@@ -355,7 +360,7 @@ int launch_refine(const RefineArgs& a, const LevelTable& lt, hipStream_t st) {
     float* t = cur; cur = nxt; nxt = t;
   }
   hipLaunchKernelGGL(k_refine_out, g64, b64, 0, st, (const float*)cur, a.w_out, a.b_out, a.mask_all, a.F, a.ldf, a.E, rows0);
-  if (a.n_levels > 1) {
+  if (a.n_levels > 1 && !a.stacked) {
     const int W = 1 << (a.n_levels - 1);
     const size_t lds = (size_t)2 * (2 * W - 1) * TCN_HID * sizeof(float);
     if (lds <= 64 * 1024 && lt.T[0] == lt.T[a.n_levels - 1] * W) {

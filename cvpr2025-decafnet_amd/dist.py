@@ -11,11 +11,11 @@ Two granularities:
    ``[lo_r, hi_r)`` and computes the window ``[lo_r - H, hi_r + H)`` (overlap-recompute, H >=
    the one-sided receptive field of the network, rounded up to the pyramid alignment so that
    stride-2 phases and attention windows coincide with the unsharded run).  Exactly two
-   collectives:
+   collectives, each ONE all-gather whose piece sizes every rank derives from the shard plan:
      AG-1  all-gather of the raw sidekick scores (NQ x T/W fp32 per rank): the block top-k gate
            (model.py:531-541) is the only global reduction of the network; every rank then runs
            the same deterministic selection on identical data.
-     AG-2  all-gather of the owned slice of every pyramid level's logits / offsets / masks.
+     AG-2  all-gather of the owned slice of every pyramid level, packed (logit, offset0, offset1, mask).
    Everything else (per-position LayerNorm, 1x1 convs, cross-attention against the replicated
    text, k3 convs, window attention, stride-2 pooling, the TCN) is position-local, so the owned
    outputs equal the unsharded ones up to fp32 round-off of identical per-position operations.
@@ -57,32 +57,44 @@ def alignment(n_levels: int, win: int) -> int:
 
 def receptive_field(n_levels: int, win: int, fusion_layers: int = 2, n_embd_convs: int = 2, n_stem: int = 0,
                     head_layers: int = 2) -> int:
-    """Conservative one-sided receptive field of a level-0 output, in level-0 clips."""
+    """Exact one-sided receptive field of an output position, in level-0 clips (the larger, LEFT reach; the right reach
+    is 2^(L-1) smaller because nearest upsampling reads the sample at or left of a clip).  Validated against a
+    perturbation probe (tools/receptive_field.py); 2304 for L = 8, w = 9 (right reach 2176).
+
+    Encoder pyramid: fusion / embedding k3 convolutions reach 1 each; level 0 adds its depthwise k3 (1) and window
+    attention (w//2); level l >= 1 works on a grid of 2^l clips: stride-2 depthwise k3 / max-pool reach one input sample
+    (2^(l-1)), attention w//2 samples (2^l * w//2).  Heads: (head_layers + 1) k3 convolutions on the level's grid.
+    Refinement (model.py:442-471) at the coarsest grid W = 2^(L-1): cls_head (hl+1)W, nearest upsampling + dilated TCN
+    (2W - 1) + pooling back down (W - 1) land on a multiple of W after flooring: 3W, then cls_head2 / reg_head (hl+1)W."""
     L, hw = n_levels, win // 2
-    r = fusion_layers + n_embd_convs                       # depthwise k3 per fusion layer, dense k3 embedding convs
-    r += n_stem * (1 + hw)
-    for l in range(L):
-        s = 2 ** l
-        r += s * hw                                        # window attention at level l
-        r += s if l == 0 else s // 2 + s                   # depthwise k3 (input-level units) + max-pool skip
-    r += (head_layers + 1) * 2 ** (L - 1)                  # cls_head trunk + output conv at the coarsest level
-    r += 2 ** (L - 1) + (2 ** L - 1)                       # nearest upsampling granularity + dilated TCN
-    r += 2 ** (L - 1)                                      # pooling the refined logits down the pyramid
-    r += (head_layers + 1) * 2 ** (L - 1)                  # cls_head2 / reg_head
-    return r
+    r = fusion_layers + n_embd_convs + n_stem * (1 + hw)
+    r += 1 + hw
+    for l in range(1, L):
+        r += 2 ** (l - 1) + hw * 2 ** l
+    W = 2 ** (L - 1)
+    return (2 * head_layers + 5) * W + r
 
 
 def shard_plan(T: int, world: int, n_levels: int, win: int, halo: int) -> List[Tuple[int, int, int, int]]:
-    """(lo, hi, w_lo, w_hi) per rank: owned range and computed window, all multiples of the alignment."""
+    """(lo, hi, w_lo, w_hi) per rank: owned range and computed window.  Owned ranges are multiples of the alignment;
+    a window starts / ends on the stride-2 phase grid (multiples of 2^(L-1)) at least `halo` clips beyond the owned range
+    and is lengthened to a multiple of the alignment (blocks.py:216: T_l % (w//2) == 0 at every level)."""
     a = alignment(n_levels, win)
+    ph = 2 ** (n_levels - 1)
     assert T % a == 0, f'T={T} must be a multiple of {a}'
     units = T // a
-    halo = -(-halo // a) * a
+    halo = -(-halo // ph) * ph
     plan = []
     for r in range(world):
         lo = (units * r // world) * a
         hi = (units * (r + 1) // world) * a
-        plan.append((lo, hi, max(0, lo - halo), min(T, hi + halo)))
+        w_lo, w_hi = max(0, lo - halo), min(T, hi + halo)
+        extra = (-(w_hi - w_lo)) % a
+        grow = min(extra, T - w_hi)                      # lengthen to the right first, then to the left
+        w_hi += grow
+        w_lo -= extra - grow
+        assert w_lo >= 0 and (w_hi - w_lo) % a == 0 and w_lo % ph == 0
+        plan.append((lo, hi, w_lo, w_hi))
     return plan
 
 
@@ -122,52 +134,90 @@ class HipBackend:
         return self.model._last_flat          # (nq, S_w), (nq, S_w, 2), (nq, S_w)
 
 
-def _all_gather_cat(x: torch.Tensor, dim: int, group=None) -> torch.Tensor:
+def _gather_static(x: torch.Tensor, sizes: Sequence[int], group=None) -> List[torch.Tensor]:
+    """ONE all-gather of per-rank pieces whose lengths along the LAST-but-k layout are known to every rank from the shard
+    plan (no size exchange): ``x`` is this rank's piece flattened to (n_r, ...) rows with n_r = sizes[rank]; pieces are
+    padded to max(sizes) rows.  Returns the list of the ranks' pieces (views, unpadded)."""
     import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        assert len(sizes) == 1 and x.shape[0] == sizes[0]
+        return [x]
     world = dist.get_world_size(group)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=x.device) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([x.shape[dim]], dtype=torch.int64, device=x.device), group=group)
-    sizes = [int(s) for s in sizes]
+    assert len(sizes) == world and x.shape[0] == sizes[dist.get_rank(group)]
     mx = max(sizes)
-    pad_shape = list(x.shape)
-    pad_shape[dim] = mx
-    buf = x.new_zeros(pad_shape)
-    buf.narrow(dim, 0, x.shape[dim]).copy_(x)
-    outs = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(outs, buf.contiguous(), group=group)
-    return torch.cat([o.narrow(dim, 0, s) for o, s in zip(outs, sizes)], dim=dim)
+    dev = x.device
+    if dev.type == 'cuda' and dist.get_backend(group) == 'gloo':       # flow checks on a one-GPU box: gloo moves host memory
+        x = x.cpu()
+    buf = x.new_zeros((mx,) + tuple(x.shape[1:]))
+    buf[:x.shape[0]].copy_(x)
+    out = x.new_empty((world * mx,) + tuple(x.shape[1:]))
+    dist.all_gather_into_tensor(out, buf, group=group)
+    out = out.view((world, mx) + tuple(x.shape[1:])).to(dev)
+    return [out[r, :sizes[r]] for r in range(world)]
 
 
-def sharded_forward(backend, vid_w, shallow_w, mask_full, plan_r, T, n_levels, texts, text_cls, tmasks, group=None):
+def sharded_forward(backend, vid_w, shallow_w, mask_full, plan, rank, T, n_levels, texts, text_cls, tmasks, group=None,
+                    timings=None):
     """Eval forward of ONE video sharded over the ranks of ``group``.
 
     vid_w, shallow_w : (D, w_hi - w_lo) this rank's window of the (zero padded) features
     mask_full        : (T,) bool validity of every clip of the whole video (cheap, replicated)
-    plan_r           : this rank's (lo, hi, w_lo, w_hi) from ``shard_plan``
+    plan             : ``shard_plan`` of ALL ranks (static: every rank derives every piece size from it); ``rank`` = ours
+    timings          : optional dict; receives callables' wall-clock free event pairs (see bench.py --shard-T)
     Returns the whole video's outputs on every rank, exactly like ``model(..., eval=True)``:
     three lists (NQ) of L-tuples  logits (1, T_l), offsets (1, T_l, 2), masks (1, T_l).
+
+    Exactly two collectives, both a single all-gather with plan-derived static sizes:
+      AG-1  raw sidekick scores of the owned clips, (own, NQ) fp32;
+      AG-2  the owned slice of every level packed as rows (logit, offset0, offset1, mask) fp32, (S_own, NQ, 4).
     """
-    lo, hi, w_lo, w_hi = plan_r
+    lo, hi, w_lo, w_hi = plan[rank]
     nq = text_cls.shape[0]
+    mark = timings.mark if timings is not None else (lambda name: None)
     # AG-1: raw sidekick scores of the owned clips -> whole video on every rank
     own = shallow_w[:, lo - w_lo:hi - w_lo]
-    correl = _all_gather_cat(backend.scores(own, text_cls), dim=1, group=group)            # (nq, T)
+    mark('scores')
+    sc = backend.scores(own, text_cls)                                                     # (nq, own)
+    mark('ag1')
+    pieces = _gather_static(sc.t().contiguous(), [p[1] - p[0] for p in plan], group)       # rank-major pieces (own_r, nq)
+    correl = torch.cat(pieces, 0).t().contiguous()                                         # (nq, T)
+    mark('gate')
     assert correl.shape == (nq, T)
     gate_full = backend.gate(correl, mask_full)                                            # identical on every rank
     gate_w = gate_full[:, w_lo:w_hi].contiguous()
+    mark('forward')
     logits, offsets, masks = backend.forward_window(vid_w, shallow_w, mask_full[w_lo:w_hi].contiguous(), texts, tmasks,
                                                     gate_w, T, w_lo)
-    # AG-2: owned slice of every level
+    mark('pack')
+    # AG-2: owned slice of every level, packed
     Tw = w_hi - w_lo
+
+    def owned_rows(x):                                  # (nq, S_w, ...) -> (S_own, nq, ...): levels concatenated
+        parts, off = [], 0
+        for l in range(n_levels):
+            a, b = (lo - w_lo) >> l, (hi - w_lo) >> l
+            parts.append(x[:, off + a:off + b])
+            off += Tw >> l
+        return torch.cat(parts, 1).transpose(0, 1)
+
+    packed = torch.cat((owned_rows(logits).unsqueeze(-1), owned_rows(offsets), owned_rows(masks).unsqueeze(-1).to(logits.dtype)), -1)
+    s_own = [sum((p[1] - p[0]) >> l for l in range(n_levels)) for p in plan]
+    mark('ag2')
+    pieces = _gather_static(packed.contiguous(), s_own, group)                             # (S_own_r, nq, 4) per rank
+    mark('unpack')
     out_l, out_o, out_m = [], [], []
-    off = 0
+    offs = [0] * len(plan)
     for l in range(n_levels):
-        Tl = Tw >> l
-        a, b = (lo - w_lo) >> l, (hi - w_lo) >> l
-        out_l.append(_all_gather_cat(logits[:, off + a:off + b].contiguous(), 1, group))
-        out_o.append(_all_gather_cat(offsets[:, off + a:off + b].contiguous(), 1, group))
-        out_m.append(_all_gather_cat(masks[:, off + a:off + b].to(torch.uint8).contiguous(), 1, group).bool())
-        off += Tl
+        lv = []
+        for r, p in enumerate(plan):
+            n = (p[1] - p[0]) >> l
+            lv.append(pieces[r][offs[r]:offs[r] + n])
+            offs[r] += n
+        lv = torch.cat(lv, 0).transpose(0, 1)                                              # (nq, T_l, 4)
+        out_l.append(lv[..., 0])
+        out_o.append(lv[..., 1:3])
+        out_m.append(lv[..., 3] != 0)
+    mark('done')
     lg = [tuple(x[q][None] for x in out_l) for q in range(nq)]
     of = [tuple(x[q][None] for x in out_o) for q in range(nq)]
     mk = [tuple(x[q][None] for x in out_m) for q in range(nq)]

@@ -326,6 +326,7 @@ class _Engine:
         self.handle = ctypes.c_void_p()
         _lib.check(self.lib.dcf_model_create(ctypes.byref(cfg), ctypes.byref(self.handle)), 'dcf_model_create')
         self.signature = None
+        self.cached = None
         self.keepalive = []
         self.pe_cache = {}
         self.text_pe_cache = {}
@@ -337,8 +338,17 @@ class _Engine:
         except Exception:
             pass
 
-    def bind(self, named_tensors):
-        sig = tuple((n, t.data_ptr(), t._version) for n, t in named_tensors)
+    def bind(self, model):
+        """(Re)bind the module's parameters if their storage or contents changed.  The walk over the module tree
+        (state_dict) costs about as much host time as a whole T = 16384 forward takes on the GPU, so the tensor list is
+        cached per engine and only a cheap signature -- storage address and in-place version counter of every cached
+        parameter -- is compared on the hot path (``.cuda()`` / ``.to()`` swap ``param.data``, ``load_state_dict`` copies
+        in place and bumps ``_version``; both keep the Parameter objects).  Registering new parameters after the first
+        forward needs ``model._engine = None``."""
+        if self.cached is None:
+            self.cached = model._named_engine_tensors()
+        named_tensors = self.cached
+        sig = tuple((t.data_ptr(), t._version) for _, t in named_tensors)
         if sig == self.signature:
             return
         keep = []
@@ -370,7 +380,7 @@ def _encode_text(model, tokens, token_masks):
     if model._engine is None:
         model._engine = _Engine(model._config())
     eng = model._engine
-    eng.bind(model._named_engine_tensors())
+    eng.bind(model)
     tn = model.text_net
     bs, ct, lq = tokens.shape
     assert ct == tn.in_dim, (ct, tn.in_dim)
@@ -475,6 +485,12 @@ class PtTransformerEarlyFusionIterative(nn.Module):
             _lib.check(rc, 'dcf_numerics_status')
         return rc
 
+    def graph_active(self):
+        """dcf_graph_active: how the last forward was issued (0 eager launches, 1 HIP-graph replay, 2 capture + launch)"""
+        if self._engine is None:
+            return 0
+        return int(self._engine.lib.dcf_graph_active(self._engine.handle))
+
     def replica(self):
         """A second handle on the SAME parameters with its own engine (workspace, repacked weights, HIP graph): run it on
         another HIP stream to keep several videos in flight (throughput mode, see bench.py).  Parameters are shared by
@@ -540,7 +556,7 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         if self._engine is None:
             self._engine = _Engine(self._config())
         eng = self._engine
-        eng.bind(self._named_engine_tensors())
+        eng.bind(self)
         lib = eng.lib
         T = videos[0][0].size(-1)
         nv = len(videos)
@@ -607,7 +623,7 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         if self._engine is None:
             self._engine = _Engine(self._config())
         eng = self._engine
-        eng.bind(self._named_engine_tensors())
+        eng.bind(self)
         lib = eng.lib
         T = vid.size(-1)
         vid_c = vid[0].contiguous().float()

@@ -141,10 +141,17 @@ int dcf_forward_eval_videos(dcf_model* m, int32_t nvid, const float* const* vid,
                             const uint8_t* const* text_mask, const int32_t* text_len, const float* const* text_cls,
                             float* logits_out, float* offsets_out, uint8_t* masks_out, void* stream);
 
-/* Debug taps for parity tests: copy an intermediate of the LAST forward chunk into `dst` (device).
- * what: 0 = sidekick scores (nq, T); 1 = gate (B, T); 2 = vid_map output (B*T, E) token-major;
- *       3 = fusion output (B*T, E); 4 = pyramid features (B*S rows [level][b][t], E+32). */
+/* Debug taps for parity tests.  what 0 / 1 / 4 copy an intermediate of the LAST forward chunk into `dst` (device) now:
+ *   0 = sidekick scores (nq, T); 1 = gate (B, T); 4 = pyramid features (B*S rows [level][b][t], E+32).
+ * what 2 / 3 ARM a one-shot tap: the NEXT forward (run eagerly, no graph) copies 2 = the vid_map output / 3 = the fusion
+ * output (B*T, E) token-major of its last query chunk into `dst` and disarms the tap; `dst` must stay alive until then and
+ * hold max_floats >= B*T*E floats (checked by that forward). */
 int dcf_debug_copy(dcf_model* m, int32_t what, float* dst, int64_t max_floats, void* stream);
+
+/* How the last dcf_forward_eval* call on this model was issued: 0 = eager kernel launches, 1 = replay of the captured HIP
+ * graph, 2 = the call that captured the graph (and launched it).  A forward called on the NULL (legacy default) stream,
+ * which cannot be captured, runs on an engine-owned stream ordered after / before the caller's by events.  ABI version 4. */
+int dcf_graph_active(const dcf_model* m);
 
 /* --------------------------------------------------------------------------------------------
  * Proposal decoding: replaces Evaluator._collect_segments (libs/worker_v2.py:1131-1187).
@@ -237,6 +244,27 @@ int dcf_op_sidekick(const float* shallow, const float* text_cls, float* correl, 
 /* block top-k gate (model.py:531-541) for nq queries: correl (nq, T), vid_mask (T) -> gate (nq, T) fp32 0/1 */
 int dcf_op_gate(const float* correl, const uint8_t* vid_mask, float* gate, uint8_t* mask_out, int32_t T, int32_t nq,
                 int32_t sn, double sratio, int32_t msf, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Composite blocks on a SCRATCH model (ABI version 4): dcf_model_create(cfg) + dcf_model_bind of the block's parameters
+ * under `prefix` (reference state_dict names below it), never finalized.  They exist so that the reference's operator
+ * fixtures (tests/golden/ops.npz) run through the very kernels and launch sequences of the forward.  Token-major rows.
+ *   dcf_op_encoder : TransformerEncoder.forward (libs/modeling/blocks.py:578-591, ConvAttNLayer :462-473), stride 1 or 2;
+ *                    X (B*T, E), mask (B*T) -> Y (B*T/stride, E), mask_out (B*T/stride).  Uses cfg E, vid_heads, win, gemm_mode.
+ *   dcf_op_enc_pre : its front half alone -- ln_attn, the three depthwise k3 convolutions (blocks.py:63-106, groups = E),
+ *                    their LayerNorms and, for stride 2, masked_max_pool1d (blocks.py:31-47) -> Qc, Kc, Vc, Skip (B*T/stride, E).
+ *   dcf_op_decoder : TransformerDecoder.forward (blocks.py:632-650, ConvXAttNLayer :513-520, adaln) in place on X (B*T, E);
+ *                    text[b] (TE, len_b) channel-major, text_mask[b] (len_b) or NULL.  Uses cfg E, TE, fusion_heads, gemm_mode.
+ *   dcf_op_tcn     : TCN.forward (libs/modeling/tcn.py:66-84) on x (B*T, n_in) -> Y (B*T, 32).
+ * ------------------------------------------------------------------------------------------ */
+int dcf_op_encoder(dcf_model* m, const char* prefix, const float* X, const uint8_t* mask, int32_t B, int32_t T, int32_t stride,
+                   float* Y, uint8_t* mask_out, void* stream);
+int dcf_op_enc_pre(dcf_model* m, const char* prefix, const float* X, const uint8_t* mask, int32_t B, int32_t T, int32_t stride,
+                   float* Qc, float* Kc, float* Vc, float* Skip, void* stream);
+int dcf_op_decoder(dcf_model* m, const char* prefix, float* X, const uint8_t* mask, int32_t B, int32_t T,
+                   const float* const* text, const uint8_t* const* text_mask, const int32_t* text_len, void* stream);
+int dcf_op_tcn(dcf_model* m, const char* prefix, const float* x, const uint8_t* mask, int32_t B, int32_t T, int32_t n_in,
+               int32_t n_layers, float* Y, void* stream);
 
 #ifdef __cplusplus
 }

@@ -177,6 +177,36 @@ def gen_ops():
     save('ops.npz', out)
 
 
+@torch.no_grad()
+def gen_ops64():
+    """The blocks of ops.npz whose key / value width (48) the MI355X GEMMs cannot take (K % 32 == 0): cross-attention MHA and
+    the TransformerDecoder with a 64-wide text stream, on 64-channel clips, so that the HIP path runs them too."""
+    from libs.modeling import blocks as B
+    g = torch.Generator().manual_seed(12)
+    out = {}
+    E, T, TEk = 64, 72, 64
+    x = torch.randn(2, E, T, generator=g)
+    mask = torch.ones(2, 1, T, dtype=torch.bool)
+    mask[0, :, 60:] = False
+    mask[1, :, 17:] = False
+    kv = torch.randn(2, TEk, 33, generator=g)
+    kv_mask = torch.ones(2, 1, 33, dtype=torch.bool)
+    kv_mask[1, :, 20:] = False
+    out['x'], out['mask'], out['kv'], out['kv_mask'] = x, mask, kv, kv_mask
+    m = B.MaskedMHA(E, kv_dim=TEk, out_dim=2 * E, n_heads=4).eval()
+    sd = rand_module_(m, 121)
+    for k, v in sd.items():
+        out[f'mha_global/w/{k}'] = v
+    out['mha_global/y'] = m(x, kv, None, kv_mask)
+    m = B.TransformerDecoder(E, TEk, n_heads=4).eval()
+    sd = rand_module_(m, 150)
+    for k, v in sd.items():
+        out[f'dec/w/{k}'] = v
+    y, ym = m(x, mask, kv, kv_mask)
+    out['dec/y'] = y
+    save('ops64.npz', out)
+
+
 # ------------------------------------------------------------------ G2: gate
 @torch.no_grad()
 def gen_gate():
@@ -529,6 +559,8 @@ if __name__ == '__main__':
     which = sys.argv[1:] or ['ops', 'gate', 'e2e', 'postproc', 'nms']
     if 'ops' in which:
         gen_ops()
+    if 'ops64' in which or 'ops' in which:
+        gen_ops64()
     if 'gate' in which:
         gen_gate()
     if 'e2e' in which:

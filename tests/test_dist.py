@@ -67,7 +67,7 @@ def _worker(rank, world, port, outdir):
         backend = OracleBackend(sd, opt.model)
         with torch.no_grad():
             out = d.sharded_forward(backend, inp['vid'][0][:, w_lo:w_hi], inp['shallow_vid'][0][:, w_lo:w_hi], inp['vid_masks'][0],
-                                    plan[rank], T, KW['n_levels'], texts, inp['text_cls'], tmasks)
+                                    plan, rank, T, KW['n_levels'], texts, inp['text_cls'], tmasks)
         torch.save((rank, [list(lv) for lv in out[0]], [list(lv) for lv in out[1]], [list(lv) for lv in out[2]], plan),
                    os.path.join(outdir, f'rank{rank}.pt'))
     finally:
@@ -87,13 +87,15 @@ def test_shard_plan_alignment_and_cover():
     d = load_pkg().dist
     assert d.alignment(8, 9) == 512 and d.alignment(4, 5) == 16
     rf = d.receptive_field(8, 9)
-    assert 2176 <= rf <= 3072          # SURVEY 8e measured 2176 for this configuration
+    assert rf == 2304                  # exact left reach; SURVEY 8e's probe saw the right reach, 2176 = rf - 2^(L-1)
+    assert d.receptive_field(4, 5) == 114 and d.receptive_field(5, 9, 1, 0, 0, 1) == 253    # tools/receptive_field.py probes
     plan = d.shard_plan(65536, 8, 8, 9, rf)
     assert plan[0][0] == 0 and plan[-1][1] == 65536
     for (lo, hi, wl, wh), nxt in zip(plan, plan[1:] + [None]):
-        assert lo % 512 == 0 and hi % 512 == 0 and wl % 512 == 0 and wh % 512 == 0
+        assert lo % 512 == 0 and hi % 512 == 0 and wl % 128 == 0 and wh % 128 == 0 and (wh - wl) % 512 == 0
         assert wl <= lo - rf or wl == 0
         assert wh >= hi + rf or wh == 65536
+        assert wh - wl <= (hi - lo) + 2 * 2304 + 511          # interior ranks: 12 800 clips for 8 192 owned (+56 %)
         if nxt:
             assert hi == nxt[0]
 

@@ -246,6 +246,169 @@ def test_gate_golden(L):
         assert torch.equal(mo[0].cpu(), mask.cpu() & (g.t(f'c{i}/gate') != 0)), c
 
 
+# ---------------------------------------------------------------------------------------------- reference operator fixtures
+# (tests/golden/ops.npz / ops64.npz, generated from the reference's own blocks) through the kernels of the forward
+GEMM_MODES = [('f16x3', 16), ('bf16x6', 6), ('fp32', 1)]
+
+
+def scratch_model(pkg, lib, weights, prefix, **cfg):
+    """dcf_model_create + dcf_model_bind of one block's parameters (never finalized)"""
+    c = pkg._lib.DcfConfig()
+    base = dict(D=32, E=32, TE=32, vid_heads=4, fusion_heads=4, fusion_layers=0, n_embd_convs=0, n_stem=0, n_levels=1, win=9,
+                head_layers=0, sn=60, sratio=0.3, msf=1, norm=1, max_batch=8)
+    base.update(cfg)
+    for k, v in base.items():
+        setattr(c, k, v)
+    h = ctypes.c_void_p()
+    pkg._lib.check(lib.dcf_model_create(ctypes.byref(c), ctypes.byref(h)), 'dcf_model_create')
+    for k, v in weights.items():
+        t = v.contiguous().cuda()
+        shape = (ctypes.c_int64 * max(t.dim(), 1))(*(t.shape if t.dim() else (1,)))
+        pkg._lib.check(lib.dcf_model_bind(h, f'{prefix}.{k}'.encode(), P(t), shape, max(t.dim(), 1)), 'dcf_model_bind')
+    return h
+
+
+@pytest.mark.parametrize('mode,gm', GEMM_MODES)
+@pytest.mark.parametrize('stride', [1, 2])
+def test_encoder_block_golden(L, stride, mode, gm):
+    """TransformerEncoder.forward (blocks.py:578-591) stride 1 / 2, window 9: reference fixture enc_s{1,2}"""
+    pkg, lib = L
+    ops = Golden('ops.npz')
+    x, mask = ops.t('x'), ops.t('mask')
+    bs, E, T = x.shape
+    h = scratch_model(pkg, lib, ops.sub(f'enc_s{stride}/w/'), 'e', E=E, win=9, vid_heads=4, gemm_mode=gm)
+    To = T // stride
+    Y = torch.empty(bs * To, E, device='cuda')
+    mo = torch.empty(bs * To, dtype=torch.bool, device='cuda')
+    pkg._lib.check(lib.dcf_op_encoder(h, b'e', P(tok(x)), P(mask.reshape(-1).contiguous().cuda()), bs, T, stride, P(Y), P(mo), st()),
+                   'dcf_op_encoder')
+    want_m = ops.t(f'enc_s{stride}/ymask')
+    assert torch.equal(mo.cpu().view(bs, 1, To), want_m)
+    torch.testing.assert_close(untok(Y, bs, To), ops.t(f'enc_s{stride}/y'), rtol=2e-5, atol=2e-5)
+    lib.dcf_model_destroy(h)
+
+
+def test_max_pool_and_dwconv_golden(L):
+    """masked_max_pool1d (blocks.py:31-47) as the stride-2 encoder front end computes it: reference fixture maxpool/y; the
+    three depthwise branches against the oracle (LN -> masked depthwise k3 stride 2 -> LN, blocks.py:462-470)"""
+    pkg, lib = L
+    ops = Golden('ops.npz')
+    x, mask = ops.t('x'), ops.t('mask')
+    bs, E, T = x.shape
+    w = ops.sub('enc_s2/w/')
+    h = scratch_model(pkg, lib, w, 'e', E=E)
+    To = T // 2
+    Q, K, V, S = (torch.empty(bs * To, E, device='cuda') for _ in range(4))
+    xm = x * mask                                                         # the encoder masks its input first (blocks.py:581)
+    pkg._lib.check(lib.dcf_op_enc_pre(h, b'e', P(tok(xm)), P(mask.reshape(-1).contiguous().cuda()), bs, T, 2, P(Q), P(K), P(V), P(S), st()),
+                   'dcf_op_enc_pre')
+    torch.testing.assert_close(untok(S, bs, To), ops.t('maxpool/y') * ops.t('maxpool/ymask'), rtol=0, atol=0)
+    xn = R.channel_layer_norm(xm, w['ln_attn.weight'], w['ln_attn.bias'])
+    for buf, n in ((Q, 'q'), (K, 'k'), (V, 'v')):
+        y, _ = R.masked_conv1d(xn, mask, w[f'attn.{n}_conv.conv.weight'], None, 2, 1, E)
+        y = R.channel_layer_norm(y, w[f'attn.{n}_norm.weight'], w[f'attn.{n}_norm.bias'])
+        torch.testing.assert_close(untok(buf, bs, To), y, rtol=1e-5, atol=1e-5)
+    lib.dcf_model_destroy(h)
+
+
+@pytest.mark.parametrize('mode,gm', GEMM_MODES)
+def test_decoder_block_golden(L, mode, gm):
+    """TransformerDecoder.forward (blocks.py:632-650): reference fixture ops64.npz dec (64-wide text stream, 33 keys, the
+    second sequence's keys partially masked)"""
+    pkg, lib = L
+    o = Golden('ops64.npz')
+    x, mask, kv, kvm = o.t('x'), o.t('mask'), o.t('kv'), o.t('kv_mask')
+    bs, E, T = x.shape
+    h = scratch_model(pkg, lib, o.sub('dec/w/'), 'd', E=E, TE=kv.size(1), fusion_heads=4, gemm_mode=gm)
+    X = tok(x)
+    texts = [kv[b].contiguous().cuda() for b in range(bs)]
+    tmasks = [kvm[b, 0].contiguous().cuda() for b in range(bs)]
+    tp = (ctypes.c_void_p * bs)(*[t.data_ptr() for t in texts])
+    mp = (ctypes.c_void_p * bs)(*[t.data_ptr() for t in tmasks])
+    ln = (ctypes.c_int32 * bs)(*[kv.size(2)] * bs)
+    pkg._lib.check(lib.dcf_op_decoder(h, b'd', P(X), P(mask.reshape(-1).contiguous().cuda()), bs, T, tp, mp, ln, st()), 'dcf_op_decoder')
+    torch.testing.assert_close(untok(X, bs, T), o.t('dec/y'), rtol=2e-5, atol=2e-5)
+    lib.dcf_model_destroy(h)
+
+
+def test_tcn_golden(L):
+    """TCN.forward (tcn.py:66-84), 4 dilated residual layers: reference fixture tcn/y"""
+    pkg, lib = L
+    ops = Golden('ops.npz')
+    x, mask = ops.t('tcn/x'), ops.t('mask')
+    bs, n_in, T = x.shape
+    h = scratch_model(pkg, lib, ops.sub('tcn/w/'), 'r')
+    Y = torch.empty(bs * T, 32, device='cuda')
+    pkg._lib.check(lib.dcf_op_tcn(h, b'r', P(tok(x)), P(mask.reshape(-1).contiguous().cuda()), bs, T, n_in, 4, P(Y), st()), 'dcf_op_tcn')
+    torch.testing.assert_close(untok(Y, bs, T), ops.t('tcn/y'), rtol=1e-5, atol=1e-5)
+    lib.dcf_model_destroy(h)
+
+
+def _linear(pkg, lib, x_rows, w, b, nterms):
+    M, K = x_rows.shape
+    N = w.size(0)
+    C = torch.empty(M, N, device='cuda')
+    wv = w.reshape(N, K).contiguous().cuda()
+    if nterms:
+        pkg._lib.check(lib.dcf_op_linear_split(P(x_rows), P(wv), P(b.cuda()), P(C), M, N, K, 0, nterms, st()))
+    else:
+        pkg._lib.check(lib.dcf_op_linear(P(x_rows), P(wv), P(b.cuda()), P(C), M, N, K, 0, st()))
+    return C
+
+
+@pytest.mark.parametrize('nterms', [16, 6, 0])
+def test_mha_global_golden(L, nterms):
+    """MaskedMHA global branch incl. its four 1x1 projections (blocks.py:348-356,374-393): reference fixture ops64.npz
+    mha_global (kv_dim 64, out_dim 2E), core = dcf_op_xattn"""
+    pkg, lib = L
+    o = Golden('ops64.npz')
+    x, kv, kvm = o.t('x'), o.t('kv'), o.t('kv_mask')
+    w = o.sub('mha_global/w/')
+    bs, E, T = x.shape
+    Lk = kv.size(2)
+    q = _linear(pkg, lib, tok(x), w['query.weight'], w['query.bias'], nterms)
+    k = _linear(pkg, lib, tok(kv), w['key.weight'], w['key.bias'], nterms)
+    v = _linear(pkg, lib, tok(kv), w['value.weight'], w['value.bias'], nterms)
+    O = torch.empty(bs * T, E, device='cuda')
+    pkg._lib.check(lib.dcf_op_xattn(P(q), P(k), P(v), P(kvm.reshape(-1).contiguous().cuda()), P(O), bs, T, Lk, E, 4, st()))
+    y = _linear(pkg, lib, O, w['proj.weight'], w['proj.bias'], nterms)
+    torch.testing.assert_close(untok(y, bs, T), o.t('mha_global/y'), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('win', [5, 9, 19])
+def test_mha_local_golden(L, win):
+    """MaskedMHA local branch incl. projections (blocks.py:357-373,391-392): reference fixtures mha_local{5,9,19}"""
+    pkg, lib = L
+    ops = Golden('ops.npz')
+    x, mask = ops.t('x'), ops.t('mask')
+    w = ops.sub(f'mha_local{win}/w/')
+    bs, E, T = x.shape
+    xr = tok(x)
+    q, k, v = (_linear(pkg, lib, xr, w[f'{n}.weight'], w[f'{n}.bias'], 16) for n in ('query', 'key', 'value'))
+    O = torch.empty(bs * T, E, device='cuda')
+    pkg._lib.check(lib.dcf_op_local_attn(P(q), P(k), P(v), P(mask.reshape(-1).contiguous().cuda()), P(O), bs, T, E, 4, win, st()))
+    y = _linear(pkg, lib, O, w['proj.weight'], w['proj.bias'], 16)
+    torch.testing.assert_close(untok(y, bs, T), ops.t(f'mha_local{win}/y'), rtol=1e-5, atol=1e-5)
+
+
+def test_xattn_core_config2_shape(L):
+    """BASELINE configs[1] as bench.py measures it -- 8 queries x T = 4096 clips, E = 1024, 16 heads, 33 keys (one query
+    with half of its keys padded): the grid-stride instantiation of k_xattn_mfma against the oracle's MaskedMHA global
+    core (identity projections, oracle/decafnet_ref.py _mha_global_qkv = blocks.py:374-389)"""
+    pkg, lib = L
+    B, T, Lk, C, heads = 8, 4096, 33, 1024, 16
+    g = torch.Generator().manual_seed(4096)
+    q, k, v = torch.randn(B, T, C, generator=g), torch.randn(B, Lk, C, generator=g), torch.randn(B, Lk, C, generator=g)
+    m = torch.ones(B, Lk, dtype=torch.bool)
+    m[-1, Lk // 2:] = False
+    eye = torch.eye(C)[:, :, None]
+    sd = {f'a.{n}.weight': eye for n in ('query', 'key', 'value', 'proj')}
+    want = R._mha_global_qkv(sd, 'a', q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), m[:, None, :], heads).transpose(1, 2)
+    O = torch.empty(B * T, C, device='cuda')
+    pkg._lib.check(lib.dcf_op_xattn(P(q.cuda()), P(k.cuda()), P(v.cuda()), P(m.cuda()), P(O), B, T, Lk, C, heads, st()))
+    torch.testing.assert_close(O.cpu().view(B, T, C), want, rtol=1e-5, atol=1e-5)
+
+
 # ---------------------------------------------------------------------------------------------- NMS
 def test_nms_known_answers(L):
     pkg, lib = L

@@ -83,6 +83,16 @@ def test_decoder(ops):
     close(y, ops.t('dec/y'))
 
 
+def test_ops64_wide_text_stream():
+    """the same two blocks with a 64-wide key / value stream (the widths the HIP GEMMs take): ops64.npz"""
+    o = Golden('ops64.npz')
+    sd = {'a.' + k: v for k, v in o.sub('mha_global/w/').items()}
+    close(R.mha_global(sd, 'a', o.t('x'), o.t('kv'), o.t('kv_mask'), 4), o.t('mha_global/y'))
+    sd = {'d.' + k: v for k, v in o.sub('dec/w/').items()}
+    y, _ = R.transformer_decoder(sd, 'd', o.t('x'), o.t('mask'), o.t('kv'), o.t('kv_mask'), 4)
+    close(y, o.t('dec/y'))
+
+
 def test_tcn(ops):
     sd = {'r.' + k: v for k, v in ops.sub('tcn/w/').items()}
     y = R.tcn_refine(sd, 'r', ops.t('tcn/x'), ops.t('mask'), 4)

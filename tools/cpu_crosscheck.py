@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Build-container only: time the REAL reference (/root/reference, imported read-only exactly as tests/golden/make_golden.py
+does) beside the CPU oracle (oracle/decafnet_ref.py) on the bench workload, same weights and inputs, and compare outputs.
+SURVEY 8d asks the oracle's clips/s to be cross-checked against the reference before its GPU-box number is trusted.
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/cpu_crosscheck.py [T] [threads] > profiles/r02_cpu_crosscheck.json
+"""
+import importlib.util
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.dont_write_bytecode = True
+spec = importlib.util.spec_from_file_location('make_golden', os.path.join(ROOT, 'tests', 'golden', 'make_golden.py'))
+mg = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(mg)
+mg.install_stubs()
+sys.path.insert(0, ROOT)
+from oracle import decafnet_ref as R  # noqa: E402
+from libs.modeling.model import PtTransformerEarlyFusionIterative  # noqa: E402  (the reference)
+
+
+def stage_times(fn, reps):
+    best = 1e9
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = fn()
+        best = min(best, time.perf_counter() - t0)
+    return best, out
+
+
+@torch.no_grad()
+def main():
+    T = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+    threads = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    torch.set_num_threads(threads)
+    kw = dict(D=1024, E=256, TE=256, text_in=512, n_levels=8, win=9, n_heads=4, sn=60, sratio=0.3, msf=True, norm=True,
+              max_seq_len=2304, text_layers=5, text_max_len=48, fusion_layers=2)      # bench.py probe_kwargs
+    opt = mg.make_opt(**kw)
+    model = PtTransformerEarlyFusionIterative(opt.clone(), second_fusion=False).eval()
+    shapes = {k: list(v.shape) for k, v in model.state_dict().items()}
+    sd = mg.synth.make_state_dict(shapes, 2025)
+    model.load_state_dict(sd)
+    inp = mg.synth.make_inputs(1024, T, T, 1, 512, 32, 2025 + 3)
+    tok = inp['tokens'][0]
+    t_ref, m_ref = model.encode_text(tok[None], torch.ones(1, 1, 32, dtype=torch.bool))
+    t_or, m_or = R.encode_text(sd, opt.model, tok[None], torch.ones(1, 1, 32, dtype=torch.bool))
+
+    def run_ref():
+        return model(inp['vid'], inp['shallow_vid'], inp['vid_masks'], (t_ref,), inp['text_cls'], (m_ref,), eval=True)
+
+    def run_or():
+        return R.forward_eval(sd, opt.model, inp['vid'], inp['shallow_vid'], inp['vid_masks'], [t_or], inp['text_cls'], [m_or])
+
+    run_ref(); run_or()                                     # warm-up (thread pool, MKLDNN primitive cache, page faults)
+    s_ref, o_ref = stage_times(run_ref, 3)
+    s_or, o_or = stage_times(run_or, 3)
+    dl = max(float((a - b).abs().max()) for a, b in zip(o_ref[0][0], o_or[0][0]))
+    do = max(float((a - b).abs().max()) for a, b in zip(o_ref[1][0], o_or[1][0]))
+    # per-op profile of both (one run each) to explain the gap
+    def top_ops(fn):
+        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU]) as p:
+            fn()
+        rows = sorted(p.key_averages(), key=lambda e: -e.self_cpu_time_total)[:12]
+        return [{'op': e.key, 'calls': e.count, 'self_ms': e.self_cpu_time_total / 1e3} for e in rows]
+    print(json.dumps({
+        'where': 'build container (no GPU)', 'threads': threads, 'torch': torch.__version__, 'T': T,
+        'workload': 'bench.py probe config, 1 video x 1 query, warm, best of 3',
+        'reference': {'s': s_ref, 'clips_per_s': T / s_ref}, 'oracle': {'s': s_or, 'clips_per_s': T / s_or},
+        'oracle_over_reference': s_ref / s_or, 'max_abs_logit_diff': dl, 'max_abs_offset_diff': do,
+        'reference_top_ops': top_ops(run_ref), 'oracle_top_ops': top_ops(run_or)}, indent=1))
+
+
+if __name__ == '__main__':
+    main()
