@@ -516,6 +516,7 @@ def main():
             nms_oracle.nms(s_cpu, c_cpu, 0.5)
             t_cpu_nms = time.perf_counter() - t1
             # forward + decode + the Evaluator's default NMS (soft-NMS, 5 segments kept, voting) for one video, end to end
+            opt.model['max_vid_len'] = T                 # the harness pads to max_vid_len (a multiple of the chunk size, worker_v2.py:778)
             ev = pkg.evaluator.GroundingEvaluator(opt, model)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -561,26 +562,24 @@ def main():
                     best = min(best, time.perf_counter() - t1)
                 return best
 
-            cpu_s = best_of(3, lambda: oracle_forward(inp, texts_cpu, tm_cpu))
-            result['cpu_baseline'] = {
-                'value': vid_len * args.nq / cpu_s, 'unit': 'clips/s', 'cores': ncores, 'kind': 'port',
-                'sample': f'1 video x {args.nq} query, T={T}: oracle/decafnet_ref.py forward_eval (torch {torch.__version__} CPU fp32, MKLDNN), '
-                          f'one warm-up then best of 3, {cpu_s:.2f} s, torch.set_num_threads({ncores}) = physical cores available',
-                'cpu': cpu_model(),
-            }
-            # thread sweep on a bounded sample (T = 4096: a quarter of the video)
-            sT = min(T, args.cpu_T or 4096)
-            sinp = pkg.synth.make_inputs(kw['D'], sT, sT, 1, kw['text_in'], 32, 2025 + 3)
-            st_, sm_ = R.encode_text(sd, opt.model, sinp['tokens'][0][None], torch.ones(1, 1, 32, dtype=torch.bool))
+            # thread sweep on the SAME sample (one whole video): MKLDNN convolutions of this size stop scaling long before a
+            # 64-core socket is full, so the reported baseline is the best setting, not "all cores"
             sweep = {}
-            for nt in sorted({1, 8, ncores}):
+            for nt in sorted({1, 8, 16, 32, 64, ncores}):
                 if nt > ncores:
                     continue
                 torch.set_num_threads(nt)
-                oracle_forward(sinp, [st_], [sm_])
-                s_ = best_of(2, lambda: oracle_forward(sinp, [st_], [sm_]))
-                sweep[str(nt)] = {'clips_per_s': sT / s_, 's': s_}
-            result['cpu_baseline']['thread_sweep'] = {'sample': f'1 video x 1 query, T={sT}, one warm-up then best of 2', 'threads': sweep}
+                oracle_forward(inp, texts_cpu, tm_cpu)                               # warm-up at this thread count
+                s_ = best_of(2, lambda: oracle_forward(inp, texts_cpu, tm_cpu))
+                sweep[str(nt)] = {'clips_per_s': vid_len * args.nq / s_, 's': s_}
+            best_nt = max(sweep, key=lambda k: sweep[k]['clips_per_s'])
+            cpu_s = sweep[best_nt]['s']
+            result['cpu_baseline'] = {
+                'value': vid_len * args.nq / cpu_s, 'unit': 'clips/s', 'cores': int(best_nt), 'kind': 'port',
+                'sample': f'1 video x {args.nq} query, T={T} (the bench video): oracle/decafnet_ref.py forward_eval (torch {torch.__version__} CPU fp32, MKLDNN), '
+                          f'per thread count one warm-up then best of 2; value = the fastest setting (torch.set_num_threads({best_nt})), {cpu_s:.2f} s',
+                'cpu': cpu_model(), 'physical_cores_available': ncores, 'thread_sweep': sweep,
+            }
             result['cpu_baseline']['crosscheck'] = ('build container, 8 threads, T=16384, warm best of 3 (profiles/r02_cpu_crosscheck.json, tools/cpu_crosscheck.py): '
                                                     'the real reference 19.9 k clips/s, this oracle 15.2 k (0.76x; outputs agree to 1.3e-6)')
         print(json.dumps(result), flush=True)

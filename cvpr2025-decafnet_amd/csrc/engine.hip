@@ -212,13 +212,13 @@ struct dcf_model {
 
 namespace dcf {
 
-static void drop_graph(dcf_model* m) {
+static void drop_graph(dcf_model* m, bool keep_last_key = false) {
   if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
   if (m->graph) (void)hipGraphDestroy(m->graph);
   m->graph_exec = nullptr;
   m->graph = nullptr;
   m->graph_key.clear();
-  m->last_key.clear();
+  if (!keep_last_key) m->last_key.clear();
 }
 
 static int free_model(dcf_model* m) {
@@ -929,7 +929,7 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
     carve(dry, c, T0, Bmax, nq, S, Lk, nvid, b);
     if (dry.off > m->arena_bytes) {
       DCF_CHECK(!m->capturing, "internal: workspace growth during graph capture");
-      drop_graph(m);
+      drop_graph(m, true);                       // the eager call that grows the workspace still counts as the first sighting
       DCF_HIP(hipStreamSynchronize(st));
       if (m->arena) DCF_HIP(hipFree(m->arena));
       m->arena = nullptr; m->arena_bytes = 0;

@@ -163,18 +163,29 @@ class GroundingEvaluator:
         t0 = time.perf_counter()
         segs, scores, counts = _nms.collect_segments(logits, offsets, masks, T, self.num_fpn_levels, self.pre_nms_thresh,
                                                      self.pre_nms_topk, self.seg_len_thresh, ext_scores=window_ext)
-        counts_h = counts.cpu()
         self.time_dict['post_process'].append(time.perf_counter() - t0)
         t0 = time.perf_counter()
-        results = []
-        for q in range(logits.shape[0]):
-            n = int(counts_h[q])
-            s, c = _nms.batched_nms(segs[q, :n], scores[q, :n], **self.nms_cfg)
-            if len(s) > 0 and data is not None:
-                s = s * self.vid_stride
-                s = (s * data['clip_stride'] + 0.5 * data['clip_size']) / data['fps']          # worker_v2.py:1120-1122
-                s = torch.clamp(s, min=0, max=data['duration'])
-            results.append({'segments': s, 'scores': c})
+        # every query of the video in one pass on the device; ONE device -> host copy of (<= max_num_segs rows + count) per query
+        cfg = self.nms_cfg
+        if cfg.get('max_num_segs', 0) > 0:
+            s_all, c_all, k_all = _nms.batched_nms_queries(segs, scores, counts, **cfg)
+            if data is not None:
+                s_all = s_all * self.vid_stride
+                s_all = (s_all * data['clip_stride'] + 0.5 * data['clip_size']) / data['fps']      # worker_v2.py:1120-1122
+                s_all = torch.clamp(s_all, min=0, max=data['duration'])
+            nq, M = c_all.shape
+            packed = torch.cat((s_all.reshape(nq, 2 * M), c_all, k_all[:, None].to(c_all.dtype)), 1).cpu()   # the only sync
+            results = []
+            for q in range(nq):
+                k = int(packed[q, 3 * M])
+                results.append({'segments': packed[q, :2 * M].view(M, 2)[:k], 'scores': packed[q, 2 * M:3 * M][:k]})
+        else:                                           # max_num_segs <= 0 keeps nothing in the reference either (nms.py:144-146)
+            counts_h = counts.cpu()
+            results = []
+            for q in range(logits.shape[0]):
+                n = int(counts_h[q])
+                s, c = _nms.batched_nms(segs[q, :n], scores[q, :n], **cfg)
+                results.append({'segments': s.cpu(), 'scores': c.cpu()})
         self.time_dict['nms'].append(time.perf_counter() - t0)
         return results
 

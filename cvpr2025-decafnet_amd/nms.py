@@ -176,6 +176,57 @@ def batched_nms(segs, scores, iou_thresh, min_score, max_num_segs, mode='soft_nm
     return nms_segs[idx[:k]].to(in_dev), nms_scores[idx[:k]].to(in_dev)
 
 
+def batched_nms_queries(segs, scores, counts, iou_thresh, min_score, max_num_segs, mode='soft_nms', sigma=0.5, voting_thresh=0.75):
+    """``batched_nms`` (libs/nms/nms.py:106-148) for ALL queries of a video in one pass on the device, without a single
+    host synchronisation: segs (nq, K, 2), scores (nq, K), counts (nq) int32 as ``collect_segments`` returns them (every
+    row sorted by descending score, which is what lets NMSop's ``scores > min_score`` filter, nms.py:13-16, be a count).
+    Returns device tensors out_segs (nq, max_num_segs, 2), out_scores (nq, max_num_segs), out_counts (nq) int32; rows
+    beyond out_counts[q] are padding.  Same values per query as ``batched_nms``."""
+    assert segs.is_cuda and segs.dim() == 3 and max_num_segs > 0
+    nq, K = scores.shape
+    if K > NMS_CAPACITY:
+        raise RuntimeError(f'batched_nms: n={K} exceeds the on-chip capacity {NMS_CAPACITY}')
+    M = int(max_num_segs)
+    dev = segs.device
+    segs = segs.contiguous()
+    scores = scores.contiguous()
+    counts = counts.to(torch.int32).contiguous()
+    if K == 0:
+        return segs.new_zeros(nq, M, 2), scores.new_zeros(nq, M), counts.new_zeros(nq)
+    if mode == 'soft_nms':
+        d, _, oc = softnms_device(segs, scores, counts, K, K, iou_thresh, sigma, min_score, 2, max_iters=M)
+        kc = torch.clamp(oc, max=M)
+        top = d[:, :M].contiguous()                                       # (nq, M', 3) picks in pick order
+        nms_segs, nms_scores = top[..., :2], top[..., 2]
+    elif mode == 'nms':
+        live = torch.arange(K, device=dev)[None] < counts[:, None]
+        c_eff = ((scores > min_score) & live).sum(1).to(torch.int32) if min_score > 0 else counts
+        idx, kc = nms_device(segs, scores, c_eff, K, K, iou_thresh)
+        kc = torch.clamp(kc, max=M)
+        idx = idx[:, :M].clamp_(0, K - 1)                                 # entries beyond kc are undefined: keep the gather in range
+        nms_segs = torch.gather(segs, 1, idx[..., None].expand(-1, -1, 2))
+        nms_scores = torch.gather(scores, 1, idx)
+        top = nms_segs
+    elif mode is None:
+        kc = torch.clamp(counts, max=M)
+        nms_segs, nms_scores, top = segs[:, :M], scores[:, :M], segs[:, :M].contiguous()
+    else:
+        raise NotImplementedError('invalid NMS mode')
+    m_ = nms_scores.shape[1]
+    if m_ < M:                                                            # fewer candidates than max_num_segs
+        pad = M - m_
+        nms_segs = torch.nn.functional.pad(nms_segs, (0, 0, 0, pad))
+        nms_scores = torch.nn.functional.pad(nms_scores, (0, pad))
+        top = torch.nn.functional.pad(top, (0, 0, 0, pad))
+    if mode is not None and voting_thresh > 0:
+        nms_segs = voting_device(top.contiguous(), kc, M, segs, scores, counts, K, voting_thresh)
+    valid = torch.arange(M, device=dev)[None] < kc[:, None]
+    order = torch.where(valid, nms_scores, nms_scores.new_full((), float('-inf'))).sort(dim=1, descending=True, stable=True)[1]
+    out_segs = torch.gather(nms_segs, 1, order[..., None].expand(-1, -1, 2))
+    out_scores = torch.gather(nms_scores, 1, order)
+    return out_segs, out_scores, kc
+
+
 def collect_segments(logits, offsets, masks, T, n_levels, pre_nms_thresh=0.001, pre_nms_topk=2000, seg_len_thresh=0.1,
                      ext_scores=None):
     """Evaluator._collect_segments for all queries: logits (nq,S), offsets (nq,S,2), masks (nq,S) on the GPU ->
