@@ -781,8 +781,7 @@ static int run_head(dcf_model* m, const HeadW& h, Buffers& b, const Plan& pl, in
 static int run_head_pair(dcf_model* m, const HeadW& h1, const HeadW& h2, Buffers& b, const Plan& pl, int Cin, int NO1, int mode1,
                          float* out1, int NO2, int mode2, float* out2, hipStream_t st) {
   const int rowsAll = pl.B * pl.lt.S;
-  static const bool off = getenv("DCF_NO_HEAD_PAIR") != nullptr;
-  bool pair = !off && h1.conv.size() == h2.conv.size() && !h1.conv.empty() && m->gemm_terms != 0;
+  bool pair = h1.conv.size() == h2.conv.size() && !h1.conv.empty() && m->gemm_terms != 0;
   for (size_t i = 0; pair && i < h1.conv.size(); ++i)
     pair = !can_fuse_ln(m, h1.conv[i], rowsAll, Cin, 3 * Cin, A_ROWS_TAP3) && m->wsplit.count(h1.conv[i]) && m->wsplit.count(h2.conv[i]);
   if (!pair) {
@@ -1618,6 +1617,31 @@ int dcf_op_conv3(const float* X, const uint8_t* mask, const float* W_ock, float*
   }
   DCF_HIP(hipFreeAsync(wp, st));
   DCF_HIP(hipFreeAsync(nbr, st));
+  return rc;
+}
+
+int dcf_op_conv3_split(const float* X, const uint8_t* mask, const float* W_ock, float* Y, int32_t B, int32_t T, int32_t Cin,
+                       int32_t N, int32_t nterms, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int rows = B * T;
+  float* wp = nullptr;
+  uint8_t* nbr = nullptr;
+  unsigned short* planes = nullptr;
+  DCF_HIP(hipMallocAsync((void**)&wp, (size_t)N * Cin * 3 * sizeof(float), st));
+  DCF_HIP(hipMallocAsync((void**)&nbr, (size_t)rows, st));
+  DCF_HIP(hipMallocAsync((void**)&planes, (size_t)3 * N * Cin * 3 * sizeof(unsigned short), st));
+  const int n = N * Cin * 3;
+  hipLaunchKernelGGL(dcf::k_permute3, dim3((n + 255) / 256), dim3(256), 0, st, W_ock, wp, N, Cin, 3, 0, 2, 1);
+  int rc = dcf::launch_rowflags(mask, nbr, T, rows, st);
+  if (rc == 0) rc = dcf::launch_split_planes(wp, planes, N, 3 * Cin, 3 * Cin, st, nterms);
+  if (rc == 0) {
+    dcf::GemmArgs g = dcf::gemm(X, Cin, wp, nullptr, Y, N, rows, N, 3 * Cin);
+    g.cin = Cin; g.nbr = nbr; g.Ws = planes;
+    rc = dcf::launch_gemm_split(&g, 1, dcf::A_ROWS_TAP3, nterms, st);
+  }
+  DCF_HIP(hipFreeAsync(wp, st));
+  DCF_HIP(hipFreeAsync(nbr, st));
+  DCF_HIP(hipFreeAsync(planes, st));
   return rc;
 }
 

@@ -229,6 +229,10 @@ int dcf_op_linear_cm_split(const float* A_cm, const float* W, const float* bias,
 /* MaskedConv1D(k=3, pad=1, no bias) on token-major (B*T, Cin) rows; W is the PyTorch (N, Cin, 3) weight. */
 int dcf_op_conv3(const float* X, const uint8_t* mask, const float* W_ock, float* Y, int32_t B, int32_t T, int32_t Cin,
                  int32_t N, void* stream);
+/* the same convolution on the split-operand matrix-core path the forward uses (nterms 16 = f16x3, 6 = bf16x6); Cin % 32 == 0.
+ * ABI version 4. */
+int dcf_op_conv3_split(const float* X, const uint8_t* mask, const float* W_ock, float* Y, int32_t B, int32_t T, int32_t Cin,
+                       int32_t N, int32_t nterms, void* stream);
 /* channel LayerNorm (libs/modeling/blocks.py:125-131) per row; w/b may be NULL. */
 int dcf_op_layernorm(const float* X, const float* w, const float* b, float* Y, int32_t rows, int32_t C, int32_t relu,
                      void* stream);

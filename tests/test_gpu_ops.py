@@ -73,7 +73,8 @@ def test_linear(L, M, N, K, act):
 @pytest.mark.parametrize('nterms,tol', [(6, 2e-5), (16, 2e-5)])
 @pytest.mark.parametrize('M,N,K,act', [(64, 256, 256, 0), (1000, 256, 1024, 1), (333, 1024, 256, 0), (77, 288, 864, 2),
                                          (50, 160, 128, 0), (200, 96, 64, 0), (129, 64, 32, 0), (65, 32, 32, 0), (4096, 512, 256, 0),
-                                         (65600, 256, 256, 1), (32704, 288, 96, 0), (20000, 256, 128, 2)])   # 128x256 / 128x96 / 64x256 tiles
+                                         (65600, 256, 256, 1), (32704, 288, 96, 0), (20000, 256, 128, 2),   # 128x256 / 128x96 / 64x256 tiles
+                                         (33000, 1024, 256, 1), (40001, 288, 864, 2), (70000, 256, 1024, 0), (32768, 512, 64, 0)])
 def test_linear_bf16_split(L, M, N, K, act, nterms, tol):
     """fp32-accurate GEMM on the 16-bit matrix cores (operand splitting, gemm_bf16s.hip: 6 = bf16x6, 16 = f16x3) vs fp64"""
     pkg, lib = L
@@ -97,11 +98,10 @@ def test_linear_bf16_split(L, M, N, K, act, nterms, tol):
         assert e6 <= 2.0 * e32 + 1e-7, (float(e6), float(e32))
 
 
-@pytest.mark.parametrize('M,K,relu,raw', [(28700, 96, 1, False), (32768, 256, 0, True)])
-def test_linear_with_fused_layernorm(L, M, K, relu, raw):
+@pytest.mark.parametrize('M,K,relu,raw,N,nterms', [(28700, 96, 1, False, 256, 6), (32768, 256, 0, True, 256, 6), (28800, 768, 1, False, 256, 16)])
+def test_linear_with_fused_layernorm(L, M, K, relu, raw, N, nterms):
     """GEMM with the channel LayerNorm (+ReLU) of the output row in its epilogue vs fp64 (last row tile partial)"""
     pkg, lib = L
-    N = 256
     g = torch.Generator().manual_seed(M + K)
     A = torch.randn(M, K, generator=g) * 2
     W = torch.randn(N, K, generator=g) / math.sqrt(K)
@@ -114,7 +114,7 @@ def test_linear_with_fused_layernorm(L, M, K, relu, raw):
     C = torch.empty(M, N, device='cuda') if raw else None
     Y = torch.empty(M, N, device='cuda')
     pkg._lib.check(lib.dcf_op_linear_ln(P(A.cuda()), P(W.cuda()), P(b.cuda()), P(lw.cuda()), P(lb.cuda()),
-                                        P(C) if raw else None, P(Y), M, N, K, relu, 6, st()))
+                                        P(C) if raw else None, P(Y), M, N, K, relu, nterms, st()))
     torch.testing.assert_close(Y.cpu().double(), ref, rtol=5e-5, atol=5e-5)
     if raw:
         torch.testing.assert_close(C.cpu().double(), v, rtol=2e-5, atol=2e-5)
@@ -156,6 +156,24 @@ def test_conv3_golden(L):
     Y = torch.empty(bs * T, Cc, device='cuda')
     pkg._lib.check(lib.dcf_op_conv3(P(tok(x)), P(mask.reshape(-1).contiguous().cuda()), P(w.contiguous().cuda()), P(Y), bs, T, Cc, Cc, st()))
     torch.testing.assert_close(untok(Y, bs, T), ops.t('conv_k3/y'), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('nterms', [16, 6])
+@pytest.mark.parametrize('B,T,Cin,N', [(2, 300, 64, 64), (3, 11008, 256, 256), (2, 16400, 288, 288), (1, 33000, 32, 256)])
+def test_conv3_split_vs_fp64(L, B, T, Cin, N, nterms):
+    """MaskedConv1D k3 (blocks.py:63-106) on the split-operand GEMM path (three taps through the neighbour flags: sequence
+    boundaries and padded tails inside the row tiles, 64- and 128-row tile kernels) against an fp64 convolution"""
+    pkg, lib = L
+    g = torch.Generator().manual_seed(B * T + Cin)
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(N, Cin, 3, generator=g) / math.sqrt(3 * Cin)
+    mask = torch.ones(B, 1, T, dtype=torch.bool)
+    mask[0, :, int(T * 0.9):] = False
+    mask[-1, :, T - 3:] = False
+    ref = F.conv1d((x * mask).double(), w.double(), padding=1)
+    Y = torch.empty(B * T, N, device='cuda')
+    pkg._lib.check(lib.dcf_op_conv3_split(P(tok(x)), P(mask.reshape(-1).contiguous().cuda()), P(w.contiguous().cuda()), P(Y), B, T, Cin, N, nterms, st()))
+    torch.testing.assert_close(untok(Y, B, T).double(), ref, rtol=2e-5, atol=2e-5)
 
 
 @pytest.mark.parametrize('C', [32, 128, 256, 288, 1024])
