@@ -10,6 +10,7 @@
 """
 from __future__ import annotations
 
+import os
 import time
 from collections import defaultdict
 
@@ -21,58 +22,66 @@ from . import nms as _nms
 
 
 def iou(pred_segs, gt_segs):
-    """libs/train_utils.py:81-96: 1-D IoU of (..., 2) segments (no epsilon)."""
-    ps, pe = pred_segs[..., 0], pred_segs[..., 1]
-    gs, ge = gt_segs[..., 0], gt_segs[..., 1]
-    overlap = (torch.minimum(pe, ge) - torch.maximum(ps, gs)).clamp(min=0)
-    union = (pe - ps) + (ge - gs) - overlap
-    return overlap / union
+    """Temporal IoU of (..., 2) [start, end] segments, broadcast over the leading dimensions.  Same value as the reference's
+    ``iou`` (libs/train_utils.py:81-96): intersection clamped at 0 over (sum of lengths - intersection), no epsilon, so two
+    empty segments give nan there as here."""
+    lo = torch.maximum(pred_segs[..., 0], gt_segs[..., 0])
+    hi = torch.minimum(pred_segs[..., 1], gt_segs[..., 1])
+    inter = (hi - lo).clamp(min=0)
+    total = (pred_segs[..., 1] - pred_segs[..., 0]) + (gt_segs[..., 1] - gt_segs[..., 0])
+    return inter / (total - inter)
 
 
 class RecallCounter:
-    """Rank@k / IoU@t counting of Evaluator.run (worker_v2.py:857-878) and its report (890-901)."""
+    """Recall@k at temporal-IoU thresholds, the metric ``Evaluator.run`` accumulates (libs/worker_v2.py:857-878) and prints
+    (:890-901).  A query is a hit at (k, t) when any of its k best-scored proposals overlaps the ground truth by IoU >= t;
+    a query without proposals is a miss everywhere."""
 
     def __init__(self, ranks=(1, 5), iou_threshs=(0.3, 0.5)):
-        self.ranks = tuple(ranks)
-        self.topk = max(self.ranks)
-        self.iou_threshs = np.array(iou_threshs)
-        self.counts = np.zeros((len(self.ranks), len(self.iou_threshs)))
-        self.text_cnt = 0
+        self.ranks = tuple(int(k) for k in ranks)
+        self.iou_threshs = np.asarray(iou_threshs, dtype=np.float64)
+        self.hits = np.zeros((len(self.ranks), len(self.iou_threshs)))
+        self.n_queries = 0
+
+    # the reference's attribute names, for code that reads them
+    @property
+    def counts(self):
+        return self.hits
+
+    @property
+    def text_cnt(self):
+        return self.n_queries
 
     def update(self, results, targets):
-        assert len(results) == len(targets)
-        for result, target in zip(results, targets):
-            segs, scores = result['segments'].cpu(), result['scores'].cpu()
-            idx = scores.argsort(descending=True)
-            segs = segs[idx[:self.topk]]
-            target = torch.as_tensor(target, dtype=torch.float).expand(len(segs), -1)
-            iou_topk = iou(segs, target)
-            iou_n = np.array([iou_topk[:k].max().item() if len(iou_topk[:k]) > 0 else 0 for k in self.ranks])
-            self.counts += (iou_n[:, None] >= self.iou_threshs[None])
-        self.text_cnt += len(targets)
+        if len(results) != len(targets):
+            raise ValueError(f'{len(results)} results for {len(targets)} ground-truth segments')
+        for res, gt in zip(results, targets):
+            segs, scores = res['segments'].cpu(), res['scores'].cpu()
+            best_first = segs[torch.argsort(scores, descending=True)[:max(self.ranks)]]
+            overlaps = iou(best_first, torch.as_tensor(gt, dtype=torch.float32)[None])
+            for i, k in enumerate(self.ranks):
+                best = float(overlaps[:k].max()) if len(overlaps[:k]) else 0.0
+                self.hits[i] += best >= self.iou_threshs
+        self.n_queries += len(targets)
 
     def metrics(self):
-        return self.counts / max(self.text_cnt, 1)
+        return self.hits / max(self.n_queries, 1)
 
     def report(self):
-        m = self.metrics()
-        s = "\nFinal:"
-        for i, rank in enumerate(self.ranks):
-            s += "\n-----"
-            for j, thresh in enumerate(self.iou_threshs):
-                s += f"\nRank@{rank}, IoU@{thresh:.1f}: {(m[i, j] * 100):.2f}"
-        return s + "\n-----\n"
+        """the reference's table layout (worker_v2.py:890-901)"""
+        m = self.metrics() * 100
+        lines = ['', 'Final:']
+        for i, k in enumerate(self.ranks):
+            lines.append('-----')
+            lines += [f'Rank@{k}, IoU@{t:.1f}: {m[i, j]:.2f}' for j, t in enumerate(self.iou_threshs)]
+        return '\n'.join(lines + ['-----', ''])
 
 
 def load_features(path_without_ext: str, fmt: str = 'npy'):
-    """Pre-extracted clip features as the reference stores them (libs/data/dataset.py:128-135): (T, C) on disk,
-    returned channel-major (C, T) float32 like ``_load_vid_feats`` (:398-399)."""
-    if fmt == 'npy':
-        a = np.load(path_without_ext + '.npy').astype(np.float32)
-    elif fmt == 'pt':
-        a = torch.load(path_without_ext + '.pt').numpy().astype(np.float32)
-    else:
-        raise NotImplementedError(f'feature format {fmt!r}')
+    """One feature file as the reference stores it ((T, C) on disk: npy / pt / pk0 / pk1 / pk_avg, libs/data/dataset.py:107-135)
+    returned channel-major (C, T) like ``_load_vid_feats`` (:398-399).  Multi-source videos: ``data.load_video_features``."""
+    from . import data as _data
+    a = np.asarray(_data.load_clip_features(path_without_ext, fmt), dtype=np.float32)
     return torch.from_numpy(np.ascontiguousarray(a.transpose()))
 
 
@@ -113,6 +122,24 @@ class GroundingEvaluator:
         self.pre_nms_topk, self.pre_nms_thresh, self.seg_len_thresh = ev['pre_nms_topk'], ev['pre_nms_thresh'], ev['seg_len_thresh']
         self.nms_cfg = dict(opt['nms'])
         self.time_dict = defaultdict(list)
+
+    @classmethod
+    def from_checkpoint(cls, opt, root=None, ckpt=None, device='cuda'):
+        """What ``Evaluator.__init__`` + ``load_model`` do for the model (libs/worker_v2.py:747-749, 806-812): build it with
+        ``create_model(opt)``, load ``<root>/models/<ckpt>.pth``['model_ema'] (a checkpoint written by the reference's
+        ``Trainer``: the state_dict names are the parameter ABI), move it to the GPU, eval mode, no gradients.
+        ``root`` / ``ckpt`` default to ``opt['_root']`` / ``opt['_ckpt']`` like the reference (eval.py:29-36)."""
+        from . import modeling
+        root = root if root is not None else opt['_root']
+        ckpt = ckpt if ckpt is not None else opt['_ckpt']
+        path = os.path.join(root, 'models', f'{ckpt}.pth')
+        state = torch.load(path, map_location='cpu')
+        if 'model_ema' not in state:
+            raise KeyError(f"{path}: no 'model_ema' entry (keys: {sorted(state)})")
+        model = modeling.create_model(opt)
+        model.load_state_dict(state['model_ema'])
+        model = model.to(device).eval().requires_grad_(False)
+        return cls(opt, model)
 
     @torch.no_grad()
     def prepare(self, data, model=None):

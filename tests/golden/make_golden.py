@@ -10,8 +10,8 @@ Modules the reference imports at module level but never touches on the grounding
 (yacs, torchtext, decord, torchvision, wandb, cv2) are absent from this image and are
 replaced by inert stubs.
 
-Fixture families:  G1 ops.npz, G2 gate.npz, G3 e2e_*.npz, G4 postproc.npz,
-G5 nms_kat.npz.
+Fixture families:  G1 ops.npz / ops64.npz, G2 gate.npz, G3 e2e_*.npz, G4 postproc.npz,
+G5 nms_kat.npz, G6 data_io.npz (feature files, annotations, text-CLS table through the reference's loaders).
 """
 import importlib
 import importlib.util
@@ -552,11 +552,93 @@ def gen_nms(ext):
     save('nms_kat.npz', out)
 
 
+# ------------------------------------------------------------------ G6: feature files / annotations / text-CLS table
+def write_data_tree(root, arrays):
+    """materialise the synthetic dataset of data_io.npz under ``root`` (also used by tests/test_data_io.py)"""
+    import pickle
+    for d in ('featA', 'featB', 'shallow', 'text', 'ext'):
+        os.makedirs(os.path.join(root, d), exist_ok=True)
+    for vid in ('v0', 'v1'):
+        a, b, sh = arrays[f'{vid}/featA'], arrays[f'{vid}/featB'], arrays[f'{vid}/shallow']
+        np.save(os.path.join(root, 'featA', vid + '.npy'), a)
+        np.save(os.path.join(root, 'featB', vid + '.npy'), b)
+        np.save(os.path.join(root, 'shallow', vid + '.npy'), sh)
+        torch.save(torch.from_numpy(np.array(a)), os.path.join(root, 'featA', vid + '.pt'))
+        with open(os.path.join(root, 'featA', vid + '.pk'), 'wb') as fh:
+            pickle.dump((np.array(a), np.array(a) * 0.5 + 1.0, np.array(a) * 0), fh)
+    anno = json.loads(bytes(arrays['anno_json']).decode())
+    with open(os.path.join(root, 'anno.json'), 'w') as fh:
+        json.dump(anno, fh)
+    cls = {}
+    for i, sent in enumerate(json.loads(bytes(arrays['sentences']).decode())):
+        cls[sent] = np.array(arrays['cls_rows'][i:i + 1])
+        np.save(os.path.join(root, 'text', f't{i}.npy'), arrays[f'text/t{i}'])
+        np.save(os.path.join(root, 'ext', f't{i}.npy'), arrays[f'ext/t{i}'])
+    np.save(os.path.join(root, 'cls_val.npy'), cls, allow_pickle=True)
+
+
+@torch.no_grad()
+def gen_data_io():
+    """Synthetic feature files pushed through the reference's OWN loaders (VID_LOAD_FUNC, VideoCentricDataset._load_vid_feats /
+    _load_text_feats / _load_ext_scores / _parse_annotations / _load_text_cls_feats, libs/data/dataset.py) bound to a bare
+    namespace instead of a constructed dataset (whose constructor wants the Ego4D metadata)."""
+    import tempfile
+    from types import SimpleNamespace as NS
+    from libs.data import dataset as D
+    g = np.random.default_rng(7)
+    arrays = {}
+    lens = {'v0': (37, 35), 'v1': (20, 20)}
+    for vid, (la, lb) in lens.items():
+        arrays[f'{vid}/featA'] = g.standard_normal((la, 6)).astype(np.float32)
+        arrays[f'{vid}/featB'] = g.standard_normal((lb, 4)).astype(np.float32)
+        arrays[f'{vid}/shallow'] = g.standard_normal(((la + 1) // 2, 10)).astype(np.float32)
+    sentences = ['where is the red cup', 'who opened the door ', 'when did I wash hands', 'what fell down', 'zero length query']
+    anno = {'val': {
+        'v0': {'fps': 30.0, 'num_frames': 1200, 'num_clips': 37, 'annotations': [
+            {'segment': [1.5, 7.25], 'sentence': sentences[0], 'sentence_id': 't0'},
+            {'segment': [-2.0, 3.0], 'sentence': sentences[1], 'sentence_id': 't1'},
+            {'segment': [38.0, 45.0], 'sentence': sentences[2], 'sentence_id': 't2'}]},
+        'v1': {'fps': 25.0, 'num_frames': 500, 'duration': 19.5, 'annotations': [
+            {'segment': [3.0, 9.0], 'sentence': sentences[3], 'sentence_id': 't3'},
+            {'segment': [25.0, 30.0], 'sentence': sentences[4], 'sentence_id': 't4'}]},
+        'no_queries': {'fps': 30.0, 'num_frames': 30}}}
+    arrays['anno_json'] = np.frombuffer(json.dumps(anno).encode(), dtype=np.uint8)
+    arrays['sentences'] = np.frombuffer(json.dumps(sentences).encode(), dtype=np.uint8)
+    arrays['cls_rows'] = g.standard_normal((len(sentences), 10)).astype(np.float32)
+    for i in range(len(sentences)):
+        arrays[f'text/t{i}'] = g.standard_normal((5 + i, 8)).astype(np.float32)
+        arrays[f'ext/t{i}'] = g.standard_normal((37,)).astype(np.float32)
+    out = dict(arrays)
+    with tempfile.TemporaryDirectory() as root:
+        write_data_tree(root, arrays)
+        for fmt in ('npy', 'pt', 'pk0', 'pk1', 'pk_avg'):
+            out[f'clip/{fmt}'] = np.asarray(D.VID_LOAD_FUNC[fmt](os.path.join(root, 'featA', 'v0'), None))
+        for tag, ds, norm in (('ds1', 1, False), ('ds2', 2, False), ('ds2_norm', 2, True)):
+            for vid in lens:
+                ns = NS(vid_feat_dict={}, vid_feat_dir=[os.path.join(root, 'featA'), os.path.join(root, 'featB')],
+                        opt=NS(data=NS(vid_load='npy')), downsample_rate=ds, normalize_vid=norm)
+                out[f'vid/{tag}/{vid}'] = D.VideoCentricDataset._load_vid_feats(ns, vid)
+        ns = NS(text_feat_dict={}, tokenizer=None, text_feat_dir=os.path.join(root, 'text'), is_training=False, normalize_text=True)
+        out['text_out_norm/t1'] = D.VideoCentricDataset._load_text_feats(ns, 't1')
+        ns.normalize_text = False
+        out['text_out/t1'] = D.VideoCentricDataset._load_text_feats(ns, 't1')
+        ns = NS(ext_score_dir=os.path.join(root, 'ext'), downsample_rate=2, normalize_scores=True, temperature=0.7, text_feat_dict={})
+        out['ext_norm/t0'] = D.VideoCentricDataset._load_ext_scores(ns, 't0')
+        ns = NS(anno_file=os.path.join(root, 'anno.json'), split=('val',), opt=NS(data=NS(downsample_rate=2)))
+        vid_dict, _ = D.VideoCentricDataset._parse_annotations(ns)
+        out['parsed'] = {k: dict(fps=v['fps'], num_frames=v['num_frames'], num_clips=v['num_clips'], duration=v['duration'],
+                                 text_ids=list(v['text_ids']), segments=np.asarray(v['segments']).tolist()) for k, v in vid_dict.items()}
+        ns = NS(vid_dict=vid_dict, text_cls_dict=np.load(os.path.join(root, 'cls_val.npy'), allow_pickle=True).item())
+        for vid in vid_dict:
+            out[f'cls/{vid}'] = D.VideoCentricDataset._load_text_cls_feats(ns, vid, tuple(range(len(vid_dict[vid]['segments']))))
+    save('data_io.npz', out)
+
+
 if __name__ == '__main__':
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ext = install_stubs()
-    which = sys.argv[1:] or ['ops', 'gate', 'e2e', 'postproc', 'nms']
+    which = sys.argv[1:] or ['ops', 'gate', 'e2e', 'postproc', 'nms', 'data_io']
     if 'ops' in which:
         gen_ops()
     if 'ops64' in which or 'ops' in which:
@@ -575,3 +657,5 @@ if __name__ == '__main__':
         gen_postproc_ext()
     if 'nms' in which:
         gen_nms(ext)
+    if 'data_io' in which:
+        gen_data_io()
