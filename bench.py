@@ -378,7 +378,7 @@ def main():
                       'alg_GBps': (v['bytes'] / (v['ms'] * 1e-3) / 1e9) if v['ms'] > 0 else 0.0}
                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}
         # dominant kernel = the dense-conv GEMM family.  f16x3 (default): two fp16 planes per operand, 3 fp16 MFMA products
-        # per fp32 multiply-add => fp32-equivalent peak 2500 / 3 TFLOP/s; bf16x6: 2500 / 6; DCF_GEMM_MODE=fp32: native 157.3.
+        # per fp32 multiply-add => fp32-equivalent peak 2500 / 3 TFLOP/s; opt.model.gemm_mode = 'bf16x6': 2500 / 6; 'fp32': native 157.3.
         fam = 'gemm_f16x3' if any(k.startswith('gemm_f16x3') for k in prof) else \
               ('gemm_bf16x6' if any(k.startswith('gemm_bf16x6') for k in prof) else 'gemm_f32')
         gk = [k for k in prof if k.startswith(fam)]

@@ -57,7 +57,6 @@ SIGNATURES = {
     'dcf_segment_voting': (i32, [c_f32p, i32, c_i32p, i32, i32, c_f32p, c_f32p, c_i32p, i32, i32, f32, i32, c_f32p, vp]),
     'dcf_op_linear': (i32, [c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, i32, vp]),
     'dcf_op_linear_split': (i32, [c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, i32, i32, vp]),
-    'dcf_op_ffn': (i32, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, c_f32p, i32, i32, i32, vp]),
     'dcf_op_linear_cm': (i32, [c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, vp]),
     'dcf_op_linear_ln': (i32, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, i32, i32, vp]),
     'dcf_op_linear_cm_split': (i32, [c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, i32, vp]),

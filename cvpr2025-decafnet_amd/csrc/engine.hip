@@ -196,9 +196,6 @@ struct dcf_model {
   // reference's calling pattern (one stream, one video per call) replays a graph too.
   hipStream_t own = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
-  // second stream for the two independent branches of the forward (fork_side / join_side)
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
   // last-forward bookkeeping for dcf_debug_copy
   struct {
     float *correl = nullptr, *gate = nullptr, *vidmap = nullptr, *fused = nullptr, *F = nullptr;
@@ -234,11 +231,6 @@ static int free_model(dcf_model* m) {
   m->plans.clear();
   if (m->arena) (void)hipFree(m->arena);
   if (m->text_ws) (void)hipFree(m->text_ws);
-  for (int i = 0; i < 2; ++i) {
-    if (m->ev_fork[i]) (void)hipEventDestroy(m->ev_fork[i]);
-    if (m->ev_join[i]) (void)hipEventDestroy(m->ev_join[i]);
-  }
-  if (m->side) (void)hipStreamDestroy(m->side);
   if (m->ev_in) (void)hipEventDestroy(m->ev_in);
   if (m->ev_out) (void)hipEventDestroy(m->ev_out);
   if (m->own) (void)hipStreamDestroy(m->own);
@@ -363,8 +355,6 @@ static int init_gemm_mode(dcf_model* m, hipStream_t st) {
   const int gm = m->cfg.gemm_mode;
   DCF_CHECK(gm == 0 || gm == 1 || gm == 6 || gm == 16, "gemm_mode %d: use 0 / 16 (f16x3), 6 (bf16x6) or 1 (fp32); the bf16x3 mode was replaced by f16x3", gm);
   m->gemm_terms = gm == 1 ? 0 : (gm == 6 ? GEMM_BF16X6 : GEMM_F16X3);
-  if (const char* ev = getenv("DCF_GEMM_MODE"))
-    m->gemm_terms = !strcmp(ev, "fp32") ? 0 : (!strcmp(ev, "x6") || !strcmp(ev, "bf16x6") ? GEMM_BF16X6 : GEMM_F16X3);
   if (m->force_x6 && m->gemm_terms == GEMM_F16X3) m->gemm_terms = GEMM_BF16X6;
   if (!m->status) DCF_HIP(hipMalloc(&m->status, 2 * sizeof(unsigned)));
   DCF_HIP(hipMemsetAsync(m->status, 0, 2 * sizeof(unsigned), st));
@@ -486,11 +476,10 @@ static int finalize(dcf_model* m, hipStream_t st) {
   }
   // these two GEMMs read the raw feature files, whose range the model does not control; everything downstream is
   // bounded by LayerNorms.  In f16x3 mode they run without the activation pre-scale (|x| < 65504 instead of 4094; an
-  // absolute representation floor of 2^-25 on the features); DCF_VIDMAP_X6=1 keeps them on the three-plane bf16 split.
-  static const bool vidmap_x6 = getenv("DCF_VIDMAP_X6") != nullptr;
+  // absolute representation floor of 2^-25 on the features).
   if (D % 32 == 0 && E % 32 == 0) {
-    if (m->vid_w1 && split_weight(m, m->vid_w1, E, D, st, m->vid_ldw, vidmap_x6 ? GEMM_BF16X6 : 0)) return -1;
-    if (m->vid_w2 && split_weight(m, m->vid_w2, E, D, st, m->vid_ldw, vidmap_x6 ? GEMM_BF16X6 : 0)) return -1;
+    if (m->vid_w1 && split_weight(m, m->vid_w1, E, D, st, m->vid_ldw)) return -1;
+    if (m->vid_w2 && split_weight(m, m->vid_w2, E, D, st, m->vid_ldw)) return -1;
   }
   for (int i = 0; i < c.fusion_layers; ++i) {
     DecW w{};
@@ -636,35 +625,6 @@ static GemmArgs gemm(const float* A, int64_t lda, const float* W, const float* b
 
 #define TRY(x) do { if ((x) != 0) return -1; } while (0)
 
-// Two places of the forward have a branch that does not depend on the main chain (bit 0: the sidekick scoring
-// next to the vid_map GEMMs; bit 1: the first classification head on the two finest levels next to the
-// latency-bound encoders of the coarse levels).  DCF_FORK=<mask> runs them on a second stream between fork_side and
-// join_side (plain event dependencies, which stream capture turns into parallel graph branches).  OFF by default:
-// measured on MI355X (same box, 3 runs each, ms per step) none 2.63 / bit 0 2.67 / bit 1 2.70 / both 2.71 -- the
-// kernels of two queues slow each other down by more than the overlap gains (rocprofv3: sidekick 34 -> 144 us
-// beside the GEMM, the level-2 GEMMs 18 -> 58 us beside the head convolution).
-static bool fork_enabled(int which) {
-  static const int mask = getenv("DCF_FORK") ? atoi(getenv("DCF_FORK")) : 0;
-  return ((mask >> which) & 1) && !g_prof_on;
-}
-static int fork_side(dcf_model* m, int which, hipStream_t st) {
-  if (!m->side) {
-    DCF_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) {
-      DCF_HIP(hipEventCreateWithFlags(&m->ev_fork[i], hipEventDisableTiming));
-      DCF_HIP(hipEventCreateWithFlags(&m->ev_join[i], hipEventDisableTiming));
-    }
-  }
-  DCF_HIP(hipEventRecord(m->ev_fork[which], st));
-  DCF_HIP(hipStreamWaitEvent(m->side, m->ev_fork[which], 0));
-  return 0;
-}
-static int join_side(dcf_model* m, int which, hipStream_t st) {
-  DCF_HIP(hipEventRecord(m->ev_join[which], m->side));
-  DCF_HIP(hipStreamWaitEvent(st, m->ev_join[which], 0));
-  return 0;
-}
-
 // dense GEMM dispatch: bf16-split MFMA when the weight has split planes, fp32 MFMA otherwise
 static int run_gemm(dcf_model* m, GemmArgs* g, int count, GemmAMode mode, hipStream_t st) {
   bool split = m->gemm_terms != 0;
@@ -682,17 +642,9 @@ static int run_gemm(dcf_model* m, GemmArgs* g, int count, GemmAMode mode, hipStr
   return split ? launch_gemm_split(g, count, mode, terms, st) : launch_gemm(g, count, mode, st);
 }
 
-// fc + GELU + proj as one kernel (ffn_f16.hip): f16x3 images for both weights, E = 128 / 256, enough rows
+// FFN (blocks.py:535-538): fc with the erf GELU in its epilogue, then proj (`go`: residual / LayerScale / mask epilogue)
 static int run_ffn(dcf_model* m, const float* X, const float* fc_w, const float* fc_b, GemmArgs go, float* HID, int rows, int E,
                    hipStream_t st) {
-  static const long min_rows = getenv("DCF_FFN_FUSE_MIN_ROWS") ? atol(getenv("DCF_FFN_FUSE_MIN_ROWS")) : 1000000000L;
-  const bool fused = !go.ln_w && rows >= min_rows && ffn_fused_supported(E) && m->wsplit.count(fc_w) && m->wsplit.count(go.W) &&
-                     m->wsplit_terms[fc_w] == GEMM_F16X3 && m->wsplit_terms[go.W] == GEMM_F16X3 &&
-                     m->wsplit_ldw[fc_w] == E && m->wsplit_ldw[go.W] == 4 * E;
-  if (fused) {
-    go.A = X; go.lda = E; go.Ws = m->wsplit[go.W]; go.status = m->status;
-    return launch_ffn_f16(go, m->wsplit[fc_w], fc_b, st);
-  }
   GemmArgs gf = gemm(X, E, fc_w, fc_b, HID, 4 * E, rows, 4 * E, E);
   gf.flags = G_GELU;
   TRY(run_gemm(m, &gf, 1, A_ROWS, st));
@@ -854,8 +806,7 @@ static int run_fusion(dcf_model* m, Buffers& b, float* X, int64_t ldx, int B, in
     TRY(launch_dec_mid(b.R[1], b.H2, w.ln_ffn_w, w.ln_ffn_b, b.R[2], b.R[0], rows, E, st));
     GemmArgs go = gemm(b.HID, 4 * E, w.pj_w, w.pj_b, X, ldx, rows, E, 4 * E);
     go.flags = G_RES | G_OUT_MASK; go.rowmask = mask; go.ls = w.ls_ffn; go.R = b.R[2]; go.ldr = E;
-    static const bool ffn_first = getenv("DCF_FFN_FUSE_MIN_ROWS") != nullptr;   // the fused FFN has no LayerNorm epilogue
-    if (li + 1 == m->dec.size() && !ffn_first && m->fus_out_w && can_fuse_ln(m, w.pj_w, rows, E, 4 * E, A_ROWS)) {
+    if (li + 1 == m->dec.size() && m->fus_out_w && can_fuse_ln(m, w.pj_w, rows, E, 4 * E, A_ROWS)) {
       // last layer: only ln_out(x) is consumed afterwards (fusion.py:64-66), the raw stream is not written
       GemmArgs gf = gemm(b.R[0], E, w.fc_w, w.fc_b, b.HID, 4 * E, rows, 4 * E, E);
       gf.flags = G_GELU;
@@ -941,17 +892,9 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
   // ---- per video: sidekick scores and the query-independent halves of vid_map
   DCF_CHECK(!(gate_override && c.scat), "opt.model.scat needs the sidekick scores: the externally gated (T-sharded) forward does not take them");
   for (int v = 0, q_off = 0; v < nvid; q_off += vs.nq[v], ++v) {
-    bool forked = false;
     if (!gate_override) {
-      // HBM-bound scoring of the shallow features next to the MFMA-bound vid_map GEMMs
       ScoreArgs sa{vs.shallow[v], vs.text_cls[v], b.tn + (size_t)q_off * D, b.partial, b.correl + (size_t)q_off * T0, D, T0, vs.nq[v], c.norm};
-      if (fork_enabled(0)) {
-        TRY(fork_side(m, 0, st));
-        forked = true;
-        TRY(launch_sidekick(sa, m->side));
-      } else {
-        TRY(launch_sidekick(sa, st));
-      }
+      TRY(launch_sidekick(sa, st));
     }
     // deep and shallow halves of vid_map share one grid (same shape, blockIdx.z selects the operand set)
     GemmArgs g[2];
@@ -960,7 +903,6 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
     if (m->vid_w2) g[ng++] = gemm(vs.shallow[v], T0, m->vid_w2, nullptr, b.P2 + (size_t)v * T0 * E, E, T0, E, D);
     for (int i = 0; i < ng; ++i) { g[i].ldw = m->vid_ldw; g[i].a_scale = 1.f; }
     TRY(run_gemm(m, g, ng, A_CHANMAJOR, st));
-    if (forked) TRY(join_side(m, 0, st));
     if (nvid > 1) DCF_HIP(hipMemcpyAsync(b.maskv + (size_t)v * T0, vs.mask[v], (size_t)T0, hipMemcpyDeviceToDevice, st));
   }
   if (nvid > 1) vid_mask = b.maskv;
@@ -1011,7 +953,6 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
     }
 
     // ---- vid_net: VideoTransformer.forward (video_net.py:123-164)
-    const bool head_split = c.model_kind == 0 && !c.second_fusion && L >= 3 && fork_enabled(1);
     {
       if (c.model_kind == 0) {
         GemmArgs ge = gemm(b.R[0], E, m->embd_fc_w, m->embd_fc_b, b.X, E, rows0, E, E);
@@ -1057,14 +998,7 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
         float* xo = b.F + (int64_t)lt.start[l] * ldf;
         TRY(run_encoder(m, m->branch[l], b, xin, ldx, mi, mo, B, l > 0 ? lt.T[l - 1] : T0, stride, xo, ldf, st));
         xin = xo; ldx = ldf;
-        if (l == 1 && head_split) {
-          // levels 0-1 (3/4 of the pyramid rows) are final: their first classification head runs beside the
-          // encoders of levels 2.. (a few hundred workgroups at most, latency bound)
-          TRY(fork_side(m, 1, st));
-          TRY(run_head(m, m->cls1, b, *pl, E, 1, 0, 0, b.logits1, m->side, 0, lt.start[2]));
-        }
       }
-      if (head_split) TRY(join_side(m, 1, st));
     }
 
     // ---- second / late fusion over the whole pyramid (model.py:443-444, :66-67; fusion.py:68-78), in place on F
@@ -1075,12 +1009,8 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
       // ---- PtTransformer.fuse_and_predict (model.py:65-69): cls_head / reg_head on the fused pyramid
       TRY(run_head_pair(m, m->cls1, m->reg, b, *pl, E, 1, 0, logits_out + (int64_t)q0 * S, 2, 1, offsets_out + (int64_t)q0 * S * 2, st));
     } else {
-    // ---- heads: fuse_and_predict (model.py:442-471).  (Running cls_head level by level on a side stream was
-    // measured slower, 40 small launches instead of 5 big ones; the split above is one extra set of 5 launches.)
-    if (head_split)
-      TRY(run_head(m, m->cls1, b, *pl, E, 1, 0, 0, b.logits1, st, lt.start[2], rowsAll - lt.start[2]));   // levels 0-1: above
-    else
-      TRY(run_head(m, m->cls1, b, *pl, E, 1, 0, 0, b.logits1, st));
+    // ---- heads: fuse_and_predict (model.py:442-471)
+    TRY(run_head(m, m->cls1, b, *pl, E, 1, 0, 0, b.logits1, st));
     {
       RefineArgs ra{};
       ra.logits1 = b.logits1; ra.lt = pl->d_lt; ra.mask_all = b.mask_all;
@@ -1538,26 +1468,6 @@ int dcf_op_linear_split(const float* A, const float* W, const float* bias, float
     rc = dcf::launch_gemm_split(&g, 1, dcf::A_ROWS, nterms, st);
   }
   DCF_HIP(hipFreeAsync(planes, st));
-  return rc;
-}
-
-int dcf_op_ffn(const float* X, const float* W1, const float* b1, const float* W2, const float* b2, const float* R, const float* ls,
-               const uint8_t* rowmask, float* C, int32_t M, int32_t E, int32_t variant, void* stream) {
-  hipStream_t st = (hipStream_t)stream;
-  DCF_CHECK(dcf::ffn_fused_supported(E) && variant >= 0 && variant <= 6, "dcf_op_ffn: E = %d (128 or 256) / variant %d (0..6) unsupported", E, variant);
-  unsigned short *p1 = nullptr, *p2 = nullptr;
-  DCF_HIP(hipMallocAsync((void**)&p1, (size_t)3 * 4 * E * E * sizeof(unsigned short), st));
-  DCF_HIP(hipMallocAsync((void**)&p2, (size_t)3 * 4 * E * E * sizeof(unsigned short), st));
-  int rc = dcf::launch_split_planes(W1, p1, 4 * E, E, E, st, dcf::GEMM_F16X3);
-  if (rc == 0) rc = dcf::launch_split_planes(W2, p2, E, 4 * E, 4 * E, st, dcf::GEMM_F16X3);
-  if (rc == 0) {
-    dcf::GemmArgs g = dcf::gemm(X, E, W2, b2, C, E, M, E, 4 * E);
-    g.Ws = p2;
-    if (R) { g.flags = dcf::G_RES | (rowmask ? dcf::G_OUT_MASK : 0); g.R = R; g.ldr = E; g.ls = ls; g.rowmask = rowmask; }
-    rc = dcf::launch_ffn_f16(g, p1, b1, st, variant);
-  }
-  DCF_HIP(hipFreeAsync(p1, st));
-  DCF_HIP(hipFreeAsync(p2, st));
   return rc;
 }
 

@@ -18,7 +18,6 @@ enum GemmFlags {
   G_RES_MASK = 8,
   G_OUT_MASK = 16,
   G_AMASK = 32,     // A_ROWS: multiply A rows by rowmask on load (MaskedConv1D's x * mask)
-  G_NARROW = 64,    // force the dword-store epilogue (experiments: DCF_NARROW_EPILOGUE=1)
 };
 
 struct GemmArgs {
@@ -67,9 +66,6 @@ int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, 
 // overflow: optional device word, bit 0 set if a weight does not fit the scaled fp16 range (f16x3 only)
 int launch_split_planes(const float* W, unsigned short* out, int N, int K, int64_t ldw, hipStream_t st, int nterms = GEMM_BF16X6,
                         unsigned* overflow = nullptr);
-// fc + GELU + proj of an FFN in one kernel (ffn_f16.hip, f16x3 images): p = the proj GEMM with A = the fc INPUT
-bool ffn_fused_supported(int E);
-int launch_ffn_f16(const GemmArgs& p, const unsigned short* W1s, const float* b1, hipStream_t st, int variant = 0);
 // true if launch_gemm_split can run g with its LayerNorm fused (one tile spans all N columns and the grid still
 // fills the chip); otherwise the caller launches the LayerNorm kernel itself
 bool gemm_can_fuse_ln(int M, int N, int K, GemmAMode mode);

@@ -569,7 +569,7 @@ static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterm
 static int launch_kslice(const GemmBatch& b, int count, int nterms, hipStream_t stream) {
   const GemmArgs& p = b.g[0];
   // 32-row tiles while 64-row tiles would leave most CUs without a workgroup
-  static const long small_max = getenv("DCF_KSLICE_SMALL") ? atol(getenv("DCF_KSLICE_SMALL")) : 128;
+  constexpr long small_max = 128;
   const long tiles64 = (long)((p.M + 63) / 64) * (p.N / 64) * count;
   const bool small = tiles64 <= small_max;
   dim3 grid(small ? tile_grid<32, 64>(p) : tile_grid<64, 64>(p), 1, count);
@@ -592,12 +592,11 @@ static int launch_kslice(const GemmBatch& b, int count, int nterms, hipStream_t 
 }
 
 bool gemm_can_fuse_ln(int M, int N, int K, GemmAMode mode) {
-  static const bool off = getenv("DCF_NO_LN_FUSE") != nullptr;
   // The fused kernel needs a 64 x N tile, i.e. M / 64 workgroups.  Measured at T = 16384 (rocprofv3): with 256
   // workgroups (M = 16384, one per CU) conv + LN fused 64 us vs 40 + 8 us as two kernels on 64x128 tiles; with 510
   // (M = 32640, the heads) 79 vs 74 + 12.5 us.  So: only where the grid still gives two workgroups per CU.
-  static const long min_tiles = getenv("DCF_LN_FUSE_MIN_TILES") ? atol(getenv("DCF_LN_FUSE_MIN_TILES")) : 448;
-  return !off && mode != A_CHANMAJOR && N == 256 && K % SBK == 0 && (M + 63) / 64 >= min_tiles;
+  constexpr long min_tiles = 448;            // (re-swept in f16x3 mode: 448 / 256 / 128 -> 1.892 / 1.973 / 1.988 ms per one-video step)
+  return mode != A_CHANMAJOR && N == 256 && K % SBK == 0 && (M + 63) / 64 >= min_tiles;
 }
 
 // same contract as launch_gemm; every g[i].Ws must hold the pre-tiled bf16 planes of g[i].W (launch_split_planes)
@@ -606,8 +605,6 @@ int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, 
   DCF_CHECK(nterms == T_F16 || nterms == 6, "launch_gemm_split: nterms must be 16 (f16x3) or 6 (bf16x6)");
   GemmBatch b;
   for (int i = 0; i < 3; ++i) b.g[i] = g[i < count ? i : 0];
-  static const bool narrow = getenv("DCF_NARROW_EPILOGUE") != nullptr;
-  if (narrow) for (int i = 0; i < 3; ++i) b.g[i].flags |= G_NARROW;
   const GemmArgs& p = g[0];
   for (int i = 0; i < count; ++i) {
     DCF_CHECK(g[i].M == p.M && g[i].N == p.N && g[i].K == p.K, "launch_gemm_split: grouped shapes differ");
@@ -625,7 +622,7 @@ int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, 
   const int N = p.N;
   auto wgs = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * (N / bn) * count; };
   constexpr long WANT = 448;            // ~2 workgroups per CU (32640x256x768: 64x256 tiles, 510 workgroups, 70.8 us vs 76.9 with 64x128)
-  static const char* forced = getenv("DCF_GEMM_CFG");      // experiments: tools/gemm_sweep.py
+  static const char* forced = getenv("DCF_GEMM_CFG");      // developer switch (tools/gemm_sweep.py): force one tile shape
   if (forced) {
     int bm = 0, bn = 0;
     if (sscanf(forced, "%dx%d", &bm, &bn) == 2 && bn > 0 && N % bn == 0) {
@@ -642,7 +639,7 @@ int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, 
     return launch_cfg_s<1, 4, 2, 2>(b, count, mode, nterms, stream);
   }
   // small grids: split K over the waves instead of the tile (see gemm_bf16s_kslice_kernel)
-  static const long kslice_max = getenv("DCF_KSLICE_MAX") ? atol(getenv("DCF_KSLICE_MAX")) : 512;
+  constexpr long kslice_max = 512;
   // (8192x256x256, 512 tiles: tile kernel 14.9 us vs 18.0 k-sliced; 8192x256x1024: 40 vs 38 -> short K switches at 256 tiles)
   // (f16x3: 8192x256x1024, 512 tiles: tile kernel 22.7 us vs 30.4 k-sliced -> 256 tiles for every K)
   if (mode == A_ROWS && N % 64 == 0 && p.K >= 4 * SBK && wgs(64, 64) <= ((p.K >= 16 * SBK && nterms != T_F16) ? kslice_max : kslice_max / 2))
@@ -654,8 +651,7 @@ int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, 
   }
   // batched queries (M >= 64 K rows): 128x256 tiles, 128x64 per wave = half the weight fetches per MFMA at 2 waves/SIMD
   // (131072x256x1024: 189 vs 180 TFLOP/s; at M = 16384 the same tile is 30 % slower)
-  static const bool big = getenv("DCF_NO_128x256") == nullptr;
-  if (big && N % 256 == 0 && p.M >= 65536 && mode != A_CHANMAJOR) return launch_cfg_s<1, 4, 4, 2>(b, count, mode, nterms, stream);
+  if (N % 256 == 0 && p.M >= 65536 && mode != A_CHANMAJOR) return launch_cfg_s<1, 4, 4, 2>(b, count, mode, nterms, stream);
   if (N % 256 == 0 && wgs(64, 256) >= WANT) return launch_cfg_s<1, 4, 2, 2>(b, count, mode, nterms, stream);   // 64x256, 64x64 per wave
   // N = 288 (heads on E + 32 channels).  Also measured for M = 32640, K = 864: 64x288 tiles of three 64x96 waves
   // with the LayerNorm fused (each weight fragment fetched once, but 252 registers = 2 waves/SIMD) 122 us, 64x96
@@ -665,8 +661,7 @@ int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, 
     // f16x3: three waves side by side, 128x32 each (every weight fragment fetched by exactly one wave, 4 row tiles of
     // A per fragment).  The four-wave stack of 32x96 tiles fetches each fragment four times through the 64 B/clk
     // vector-memory path: ~135 B/clk per CU at full MFMA rate once the MFMA work halved (bf16x6: half that).
-    static const bool stack = getenv("DCF_HEADS_STACK") != nullptr;
-    if (nterms == T_F16 && !stack) return launch_cfg_s<1, 3, 4, 1>(b, count, mode, nterms, stream);
+    if (nterms == T_F16) return launch_cfg_s<1, 3, 4, 1>(b, count, mode, nterms, stream);
     return launch_cfg_s<4, 1, 1, 3>(b, count, mode, nterms, stream);
   }
   if (N % 160 == 0 && N % 64 != 0) return launch_cfg_s<4, 1, 1, 5>(b, count, mode, nterms, stream);             // 128x160

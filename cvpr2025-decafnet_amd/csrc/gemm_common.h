@@ -202,7 +202,7 @@ __device__ __forceinline__ void gemm_epilogue_wide_flags(const GemmArgs& p, f32x
 
 // true if the 16-byte epilogue applies to this operand set (row pitches and base pointers 16-byte aligned)
 __device__ __forceinline__ bool gemm_wide_ok(const GemmArgs& p) {
-  bool ok = !(p.flags & G_NARROW) && (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
+  bool ok = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
   if (p.flags & G_RES) ok = ok && (p.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(p.R) & 15) == 0;
   if (p.bias) ok = ok && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
   if ((p.flags & G_RES) && p.ls) ok = ok && (reinterpret_cast<uintptr_t>(p.ls) & 15) == 0;

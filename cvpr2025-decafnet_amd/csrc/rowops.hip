@@ -14,7 +14,7 @@ namespace dcf {
 // Output rows per wavefront: long strips amortise the window warm-up (2 extra rows), short strips expose
 // more wavefronts when a pyramid level is small.
 static inline int pick_strip(long rows) {
-  static const long want = getenv("DCF_STRIPS") ? atol(getenv("DCF_STRIPS")) : 4096;   // measured 1024: 2.47, 2048: 2.43, 4096: 2.40, 8192: 2.39 ms per step
+  constexpr long want = 4096;                // strips per launch; measured 1024: 2.47, 2048: 2.43, 4096: 2.40, 8192: 2.39 ms per step
   int s = 16;
   while (s > 2 && rows / s < want) s >>= 1;
   return s;

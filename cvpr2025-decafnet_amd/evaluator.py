@@ -218,7 +218,9 @@ class GroundingEvaluator:
 
     def predict(self, data):
         flat, T = self.forward(data)
-        return self.generate_proposals(flat, T, data, self._window_ext)
+        res = self.generate_proposals(flat, T, data, self._window_ext)
+        self._check_numerics([self.model])          # the host has just synchronised for the proposals: 4 more bytes
+        return res
 
     def run(self, dataset, counter: RecallCounter = None, n_streams: int = 1, batch_videos: int = 1):
         """Evaluator.run (worker_v2.py:815-910) over an iterable of per-video dicts (keys as in

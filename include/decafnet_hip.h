@@ -197,13 +197,6 @@ int dcf_segment_voting(const float* nms_segs, int32_t nms_ld, const int32_t* n1_
 int dcf_profile_enable(int32_t on);
 int64_t dcf_profile_report(char* buf, int64_t cap);
 
-/* Fused FFN operator (test hook of ffn_f16.hip): C = [R + ls *] (GELU(X W1^T + b1) W2^T + b2) [* rowmask], X (M, E) token-major,
- * W1 (4E, E), W2 (E, 4E) as in ffn.fc / ffn.proj (blocks.py:535-538); R / ls / rowmask may be NULL together.  E = 128 or 256.
- * variant: 0 = library default, 1 = 32-row tiles, 2 = 64-row tiles, 3 / 4 = warp-specialised (producer / consumer waves; row-half /
- * column-block units), 5 / 6 = column-block units with eight narrow producers and four / eight consumers (6: E = 256 only). */
-int dcf_op_ffn(const float* X, const float* W1, const float* b1, const float* W2, const float* b2, const float* R, const float* ls,
-               const uint8_t* rowmask, float* C, int32_t M, int32_t E, int32_t variant, void* stream);
-
 /* --------------------------------------------------------------------------------------------
  * Single-operator entry points (used by the parity tests and micro-benchmarks).
  * ------------------------------------------------------------------------------------------ */

@@ -608,29 +608,3 @@ def test_collect_with_ext_scores(L):
         assert n == len(wc)
         torch.testing.assert_close(scores[q, :n].cpu(), wc, rtol=1e-6, atol=1e-7)
         torch.testing.assert_close(segs[q, :n].cpu(), ws, rtol=1e-6, atol=1e-4)
-
-
-@pytest.mark.parametrize('variant', [1, 2, 3, 4, 5, 6])
-@pytest.mark.parametrize('M,E,res', [(64, 128, False), (1000, 256, True), (16500, 256, True), (333, 128, True)])
-def test_fused_ffn(L, M, E, res, variant):
-    """fc + GELU + proj in one kernel (ffn_f16.hip, f16x3) vs fp64: C = R + ls * (GELU(X W1^T + b1) W2^T + b2) * mask"""
-    pkg, lib = L
-    g = torch.Generator().manual_seed(M + E)
-    X = torch.randn(M, E, generator=g) * 2
-    W1 = torch.randn(4 * E, E, generator=g) / math.sqrt(E)
-    b1 = torch.randn(4 * E, generator=g) * 0.5
-    W2 = torch.randn(E, 4 * E, generator=g) / math.sqrt(4 * E)
-    b2 = torch.randn(E, generator=g)
-    ref = F.gelu(X.double() @ W1.double().t() + b1.double()) @ W2.double().t() + b2.double()
-    R = ls = mask = None
-    if res:
-        R = torch.randn(M, E, generator=g)
-        ls = torch.rand(E, generator=g) + 0.5
-        mask = torch.rand(M, generator=g) > 0.2
-        ref = R.double() + ls.double() * (ref * mask.double()[:, None])
-    C = torch.empty(M, E, device='cuda')
-    dev = lambda t: None if t is None else t.cuda()
-    Rd, lsd, md = dev(R), dev(ls), dev(mask)
-    pkg._lib.check(lib.dcf_op_ffn(P(X.cuda()), P(W1.cuda()), P(b1.cuda()), P(W2.cuda()), P(b2.cuda()), P(Rd) if res else None,
-                                  P(lsd) if res else None, P(md) if res else None, P(C), M, E, variant, st()), 'dcf_op_ffn')
-    torch.testing.assert_close(C.cpu().double(), ref, rtol=3e-5, atol=3e-5)
