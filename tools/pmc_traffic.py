@@ -1,8 +1,9 @@
 """Summarise the two rocprofv3 --pmc passes of tools/pmc_traffic.sh: HBM-side bytes per launch of the GEMM kernels.
 FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request and is doubled
 (MI355X_MICROARCH.md, HBM section)."""
-import csv, json, sys
+import csv, json, os, sys
 csv.field_size_limit(1 << 30)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def family(name):
@@ -41,4 +42,6 @@ out['note'] = ('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate pass
                '--no-cpu-baseline --no-post`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per '
                '128-B request); counters in KiB; averages over every launch of the kernel family (tile kernel + k-sliced kernel; gemm_f16x3 = the '
                'default two-plane fp16 mode, gemm_bf16s = the bf16x6 instantiations, here the two vid_map products)')
+import bench  # noqa: E402  (csrc_hash: bench.py only quotes this summary for the same kernel sources)
+out['csrc_sha16'] = bench.csrc_hash()
 print(json.dumps(out, indent=1))

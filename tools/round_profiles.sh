@@ -5,6 +5,7 @@ R=$GRAFT_REPO_ROOT
 cd $R
 python3 bench.py --steps 10 --warmup 3 > gpurun_out/${tag}_bench_n1.json 2> gpurun_out/${tag}_bench_n1.err
 python3 bench.py --steps 10 --warmup 3 --nq 8 --no-cpu-baseline > gpurun_out/${tag}_bench_n1_nq8.json 2>/dev/null
+python3 bench.py --steps 10 --warmup 3 --videos 1 --batch 1 --no-cpu-baseline > gpurun_out/${tag}_bench_n1_one_video.json 2>/dev/null
 echo "bench done"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kstats -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-post > /tmp/kstats.log 2>&1
@@ -13,5 +14,5 @@ echo "kernel stats done"
 cd $R
 bash tools/pmc_traffic.sh && cp gpurun_out/pmc_traffic.json gpurun_out/${tag}_pmc_gemm_traffic.json
 echo "pmc traffic done"
-bash tools/run_trace.sh $tag --videos 1 && cp gpurun_out/step_$tag.txt gpurun_out/${tag}_step_timeline.txt
+bash tools/run_trace.sh $tag --videos 1 --batch 1 && cp gpurun_out/step_$tag.txt gpurun_out/${tag}_step_timeline.txt
 echo "timeline done"

@@ -19,7 +19,9 @@ t0 = int(step[0]['Start_Timestamp'])
 prev_end = t0
 tot = 0
 short = lambda n: re.sub(r'\(.*$', '', n.replace('dcf::', '').replace('void ', ''))[:70]
-print(f'{len(step)} kernels, wall {(int(step[-1]["End_Timestamp"]) - t0) / 1e3:.1f} us')
+gaps = sum(max(0, int(n_['Start_Timestamp']) - int(p_['End_Timestamp'])) for p_, n_ in zip(step[:-1], step[1:]))
+print(f'{len(step)} kernel dispatches of one steady-state forward (the fastest of {len(starts) - 1}), wall {(int(step[-1]["End_Timestamp"]) - t0) / 1e3:.1f} us, '
+      f'sum of inter-kernel gaps {gaps / 1e3:.1f} us')
 for r in step:
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
     g = r.get('Grid_Size_X', r.get('Grid_Size', '?'))
