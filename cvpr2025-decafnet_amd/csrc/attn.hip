@@ -1,17 +1,19 @@
-// Attention cores of the grounding path (fp32).
+// Attention cores of the grounding path (fp32 in, fp32 out).
 //
 //  * xattn:  clips attend to <= 64 text tokens (MaskedMHA global branch,
-//            libs/modeling/blocks.py:374-389).  K/V of one query (Lk x C, <= 64 KiB each) are staged
-//            once per workgroup in LDS; every wavefront then streams clip rows: 1 KiB coalesced
-//            read of q, 1 KiB coalesced write of the context -- 8 B/channel/clip of HBM traffic,
-//            which is the algorithmic minimum.
+//            libs/modeling/blocks.py:374-389).  K/V of one (query, head) are staged once per workgroup in
+//            LDS as two fp16 planes (hi + lo, the same split the GEMMs use); a wavefront then streams
+//            16-row groups of clips: q fragments are fetched two groups ahead, Q.K^T and P.V run on
+//            v_mfma_f32_16x16x16_f16 with three products per step (hi.hi + hi.lo + lo.hi, fp32-class
+//            accuracy), the softmax of the <= 64 scores stays in registers.  HBM traffic is one read of q
+//            and one write of the context -- 8 B/channel/clip, the algorithmic minimum.
+//            A VALU variant (lane owns 4 channels, online softmax) serves the shapes the MFMA tiling
+//            does not cover.
 //  * local:  sliding-window self attention |i-j| <= w/2 (MaskedMHA local branch, blocks.py:204-325,
 //            357-373, restated as a band).  A wavefront owns one clip row; its <= w neighbour K/V
-//            rows come from L1/L2.
-//
-// In both kernels a lane owns 4 consecutive channels of the row, a head is a group of d/4 adjacent
-// lanes, the q.k dot product is a 4-FMA partial + log2(d/4) cross-lane adds, and the softmax is
-// carried online (running max / running sum), so no score matrix is ever materialised.
+//            rows come from L1/L2; a lane owns 4 consecutive channels, a head is a group of d/4 adjacent
+//            lanes, the q.k dot product is a 4-FMA partial + log2(d/4) cross-lane adds, and the softmax
+//            is carried online (running max / running sum), so no score matrix is materialised.
 #include "attn.h"
 #include "common.h"
 
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void k_xattn_valu(XAttnArgs p) {
 
 
 // ------------------------------------------------------------------------------------------
-// cross attention on the matrix cores (fp32 MFMA 16x16x4, exact fp32)
+// cross attention on the matrix cores, fp32 accurate (two fp16 planes per operand, three MFMA products)
 // ------------------------------------------------------------------------------------------
 // Workgroup = 4 wavefronts = (64 clip rows, one head); grid = (row groups, heads, B), each workgroup
 // stages K_h and V_h of its (query, head) once in LDS and then strides over row groups.
@@ -96,33 +98,59 @@ __global__ __launch_bounds__(256) void k_xattn_valu(XAttnArgs p) {
 //   S^T = K_h Q^T   "swapped" product: A = K tile (16 keys x d), B = Q^T.  The D fragment then holds,
 //                   per lane (row r = lane & 15, g = lane >> 4), the scores of keys 16*kt + 4*g + j:
 //                   the softmax over keys is in-lane plus two cross-lane steps (xor 16, xor 32).
-//   O^T = V_h^T P^T A = V^T tile (16 channels x keys), B = P^T: the B fragment of k-step j IS the
-//                   lane's score register j -- the probabilities never leave their registers.
+//   O^T = V_h^T P^T A = V^T tile (16 channels x keys), B = P^T: the B fragment of a 16-key step IS the
+//                   lane's score register -- the probabilities never leave their registers.
 //   Q goes global -> registers directly in B-fragment order (every byte of the q slice is read once,
 //   as 64-byte pieces), O goes registers -> global as float4 (4 consecutive channels per lane).
-// The k index of each 16-wide chunk is permuted (lane group g owns d = 16c + 4g + j for step j) for
-// both operands alike, so one ds_read_b128 / global_load_dwordx4 feeds 4 MFMAs.
+// Arithmetic: v_mfma_f32_16x16x16_f16 on x = hi + lo (two fp16 values, 22 significant bits; below |x| = 2^-14 the
+// absolute representation error is <= 2^-25), products hi*lo + lo*hi + hi*hi accumulated in fp32 -- the operand split of
+// the dense convolutions (gemm_bf16s.hip) without its scaling: q, k are O(1) after the d^-1/4 scale, p is in [0, 1].
+// Measured error against the fp32 reference: that of an fp32 FMA chain (tests/test_gpu_ops.py: 1e-5 at E = 1024).
+// Why not the exact fp32 MFMA (v_mfma_f32_16x16x4_f32, the round-1 kernel): it retires 4 k per 32 cycles -- 64 of them per
+// 16 rows x 64 channels x 33 keys = 2 048 cycles for 8 KiB of q / ctx traffic, 30 us of pure MFMA issue per SIMD at
+// BASELINE config 2 against 43 us of HBM time: the core was bound by both.  Three 16-cycle fp16 products replace four
+// 32-cycle fp32 ones (2.7x less matrix time), same lane layout (lane group g owns d = 16c + 4g + j of a 16-wide chunk).
+typedef _Float16 xh4 __attribute__((ext_vector_type(4)));
+typedef _Float16 xh2 __attribute__((ext_vector_type(2)));
+typedef float xf2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split4(const f32x4& x, xh4& hi, xh4& lo) {
+  const xh2 h0 = __builtin_convertvector(xf2{x.x, x.y}, xh2), h1 = __builtin_convertvector(xf2{x.z, x.w}, xh2);
+  const xh2 l0 = __builtin_convertvector(xf2{x.x - (float)h0[0], x.y - (float)h0[1]}, xh2);
+  const xh2 l1 = __builtin_convertvector(xf2{x.z - (float)h1[0], x.w - (float)h1[1]}, xh2);
+  hi = xh4{h0[0], h0[1], h1[0], h1[1]};
+  lo = xh4{l0[0], l0[1], l1[0], l1[1]};
+}
+__device__ __forceinline__ f32x4 mma3(const xh4& ah, const xh4& al, const xh4& bh, const xh4& bl, f32x4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl, c, 0, 0, 0);      // smallest terms first
+  c = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, c, 0, 0, 0);
+}
+
 template <int D16, int NKT, int REM, int QT>
 __global__ __launch_bounds__(256) void k_xattn_mfma(XAttnArgs p) {
   // NKT full 16-key MFMA tiles + REM (0..2) trailing keys on the vector ALU: Lk = 33 (32 words + the
-  // background token) would otherwise pay for 48 keys.  Each wavefront owns QT = 2 tiles of 16 clip rows so
-  // that every K / V fragment read from LDS feeds two MFMAs (QT = 1 for head dims >= 128: registers).
+  // background token) would otherwise pay for 48 keys.  Each wavefront owns QT tiles of 16 clip rows so
+  // that every K / V fragment read from LDS feeds QT MFMA groups.
   constexpr int D = 16 * D16;          // head dim
-  constexpr int PITCH = D + 4;         // LDS row pitch in floats
-  constexpr int LKP = 16 * NKT + REM;  // staged key rows
+  constexpr int KP = D + 4;            // pitch (halves) of a key row: 8-byte reads of 16 rows x 2 lane groups hit distinct banks
+  constexpr int VP = 16 * NKT + 4;     // pitch (halves) of a row of the transposed V image
+  constexpr int KT16 = 16 * NKT;
   extern __shared__ float smem[];
-  float* Ks = smem;                    // [LKP][PITCH], pre-scaled by d^-1/4
-  constexpr int VP = 16 * NKT + 4;     // pitch of the transposed V image (4*odd: conflict-free b128 reads)
-  float* Vt = smem + LKP * PITCH;      // [D][VP]   V^T of the NKT full tiles: Vt[chan][key]
-  float* Vr = Vt + D * VP;             // [REM][D]  trailing keys, row-major
-  float* Ms = Vr + (REM > 0 ? REM : 1) * D;  // [LKP] additive key mask (0 / -inf)
+  _Float16* Kh = reinterpret_cast<_Float16*>(smem);          // [KT16][KP]  hi plane of K (pre-scaled by d^-1/4)
+  _Float16* Kl = Kh + KT16 * KP;                             // lo plane
+  _Float16* Vh = Kl + KT16 * KP;                             // [D][VP]     hi plane of V^T: Vh[chan][key]
+  _Float16* Vl = Vh + D * VP;
+  float* Kr = reinterpret_cast<float*>(Vl + D * VP);         // [REM][D]    trailing keys, fp32 (vector-ALU path), pre-scaled
+  float* Vr = Kr + (REM > 0 ? REM : 1) * D;                  // [REM][D]
+  float* Ms = Vr + (REM > 0 ? REM : 1) * D;                  // [KT16 + REM] additive key mask (0 / -inf)
   const int C = p.C, Lk = p.Lk;
   const int head = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const float scale = 1.0f / sqrtf(sqrtf((float)D));
 
-  for (int i = tid; i < LKP * (D / 4); i += 256) {
+  for (int i = tid; i < (KT16 + REM) * (D / 4); i += 256) {
     const int key = i / (D / 4), c4 = i % (D / 4);
     f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
     if (key < Lk) {
@@ -130,23 +158,29 @@ __global__ __launch_bounds__(256) void k_xattn_mfma(XAttnArgs p) {
       kv = *reinterpret_cast<const f32x4*>(p.K + off) * scale;
       vv = *reinterpret_cast<const f32x4*>(p.V + off);
     }
-    *reinterpret_cast<f32x4*>(Ks + key * PITCH + c4 * 4) = kv;
-    if (key < 16 * NKT) {
-      Vt[(c4 * 4 + 0) * VP + key] = vv.x; Vt[(c4 * 4 + 1) * VP + key] = vv.y;
-      Vt[(c4 * 4 + 2) * VP + key] = vv.z; Vt[(c4 * 4 + 3) * VP + key] = vv.w;
+    if (key < KT16) {
+      xh4 hi, lo;
+      split4(kv, hi, lo);
+      *reinterpret_cast<xh4*>(Kh + key * KP + c4 * 4) = hi;
+      *reinterpret_cast<xh4*>(Kl + key * KP + c4 * 4) = lo;
+      split4(vv, hi, lo);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { Vh[(c4 * 4 + e) * VP + key] = hi[e]; Vl[(c4 * 4 + e) * VP + key] = lo[e]; }
     } else {
-      *reinterpret_cast<f32x4*>(Vr + (key - 16 * NKT) * D + c4 * 4) = vv;
+      *reinterpret_cast<f32x4*>(Kr + (key - KT16) * D + c4 * 4) = kv;
+      *reinterpret_cast<f32x4*>(Vr + (key - KT16) * D + c4 * 4) = vv;
     }
   }
-  for (int i = tid; i < LKP; i += 256) Ms[i] = (i < Lk && p.kvmask[(size_t)b * Lk + i]) ? 0.f : -INFINITY;
+  for (int i = tid; i < KT16 + REM; i += 256) Ms[i] = (i < Lk && p.kvmask[(size_t)b * Lk + i]) ? 0.f : -INFINITY;
   __syncthreads();
 
   constexpr int ROWS = 64 * QT;        // clip rows per workgroup iteration
   const int n_groups = (p.T + ROWS - 1) / ROWS;
-  // Q fragments are fetched one row group ahead: the next group's 1 KiB wave loads stay in flight while
-  // the current group is multiplied (a wave has nothing else to overlap its own HBM latency with).
-  f32x4 qn[QT][D16];
-  auto fetch_q = [&](int grp) __attribute__((always_inline)) {
+  // Q fragments are fetched TWO row groups ahead (two statically indexed register sets, the loop is unrolled by two): a wave
+  // has nothing but its own requests in flight to cover the HBM latency with.
+  f32x4 qn_[2][QT][D16];
+  auto fetch_q = [&](int grp, f32x4 (&qn)[QT][D16]) __attribute__((always_inline)) {
+    if (grp >= n_groups) return;
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
       int tt = grp * ROWS + (wave * QT + t) * 16 + r;
@@ -156,10 +190,10 @@ __global__ __launch_bounds__(256) void k_xattn_mfma(XAttnArgs p) {
       for (int c = 0; c < D16; ++c) qn[t][c] = *reinterpret_cast<const f32x4*>(qp + 16 * c);
     }
   };
-  if ((int)blockIdx.x < n_groups) fetch_q(blockIdx.x);
-  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-    // ---- Q fragments: q[t][c] = Q[row_t][head*D + 16c + 4g .. +3], scaled
+  auto process = [&](int grp, f32x4 (&qn)[QT][D16]) __attribute__((always_inline)) {
+    // ---- Q fragments: q[t][c] = Q[row_t][head*D + 16c + 4g .. +3], scaled, as two fp16 planes
     f32x4 q[QT][D16];
+    xh4 qh[QT][D16], ql[QT][D16];
     bool live[QT];
     int64_t row[QT];
 #pragma unroll
@@ -168,9 +202,12 @@ __global__ __launch_bounds__(256) void k_xattn_mfma(XAttnArgs p) {
       live[t] = tt < p.T;
       row[t] = (int64_t)b * p.T + (live[t] ? tt : p.T - 1);
 #pragma unroll
-      for (int c = 0; c < D16; ++c) q[t][c] = qn[t][c] * scale;
+      for (int c = 0; c < D16; ++c) {
+        q[t][c] = qn[t][c] * scale;
+        split4(q[t][c], qh[t][c], ql[t][c]);
+      }
     }
-    if (grp + (int)gridDim.x < n_groups) fetch_q(grp + gridDim.x);
+    fetch_q(grp + 2 * (int)gridDim.x, qn);           // this set is free again: request the group after next
     // ---- S^T tiles
     f32x4 s[QT][NKT > 0 ? NKT : 1];
 #pragma unroll
@@ -179,17 +216,13 @@ __global__ __launch_bounds__(256) void k_xattn_mfma(XAttnArgs p) {
       for (int t = 0; t < QT; ++t) s[t][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < D16; ++c) {
-        const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + (16 * kt + r) * PITCH + 16 * c + 4 * g);
+        const xh4 kh = *reinterpret_cast<const xh4*>(Kh + (16 * kt + r) * KP + 16 * c + 4 * g);
+        const xh4 kl = *reinterpret_cast<const xh4*>(Kl + (16 * kt + r) * KP + 16 * c + 4 * g);
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-          s[t][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, q[t][c].x, s[t][kt], 0, 0, 0);
-          s[t][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, q[t][c].y, s[t][kt], 0, 0, 0);
-          s[t][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, q[t][c].z, s[t][kt], 0, 0, 0);
-          s[t][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, q[t][c].w, s[t][kt], 0, 0, 0);
-        }
+        for (int t = 0; t < QT; ++t) s[t][kt] = mma3(kh, kl, qh[t][c], ql[t][c], s[t][kt]);
       }
     }
-    // ---- trailing keys: full dot product per row, replicated over the 4 lane groups
+    // ---- trailing keys: full fp32 dot product per row, replicated over the 4 lane groups
     float sr[QT][REM > 0 ? REM : 1];
 #pragma unroll
     for (int j = 0; j < REM; ++j) {
@@ -198,15 +231,16 @@ __global__ __launch_bounds__(256) void k_xattn_mfma(XAttnArgs p) {
       for (int t = 0; t < QT; ++t) part[t] = 0.f;
 #pragma unroll
       for (int c = 0; c < D16; ++c) {
-        const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + (16 * NKT + j) * PITCH + 16 * c + 4 * g);
+        const f32x4 kf = *reinterpret_cast<const f32x4*>(Kr + j * D + 16 * c + 4 * g);
 #pragma unroll
         for (int t = 0; t < QT; ++t) part[t] += dot4(q[t][c], kf);
       }
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
-        sr[t][j] = xor32_sum(xor16_sum(part[t])) + Ms[16 * NKT + j];
+        sr[t][j] = xor32_sum(xor16_sum(part[t])) + Ms[KT16 + j];
       }
     }
+    xh4 ph[QT][NKT > 0 ? NKT : 1], pl[QT][NKT > 0 ? NKT : 1];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
       // ---- softmax over keys (lane holds keys 16kt + 4g + j of its row, plus the replicated trailing keys)
@@ -232,7 +266,7 @@ __global__ __launch_bounds__(256) void k_xattn_mfma(XAttnArgs p) {
       for (int j = 0; j < REM; ++j) { sr[t][j] = fast_exp(sr[t][j] - mx); sum += sr[t][j]; }
       const float inv = 1.0f / sum;        // all keys masked: NaN row, as the reference
 #pragma unroll
-      for (int kt = 0; kt < NKT; ++kt) s[t][kt] *= inv;
+      for (int kt = 0; kt < NKT; ++kt) { s[t][kt] *= inv; split4(s[t][kt], ph[t][kt], pl[t][kt]); }
 #pragma unroll
       for (int j = 0; j < REM; ++j) sr[t][j] *= inv;
     }
@@ -244,15 +278,10 @@ __global__ __launch_bounds__(256) void k_xattn_mfma(XAttnArgs p) {
       for (int t = 0; t < QT; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt) {
-        const f32x4 vf = *reinterpret_cast<const f32x4*>(Vt + (16 * ct + r) * VP + 16 * kt + 4 * g);
-        const float v0 = vf.x, v1 = vf.y, v2 = vf.z, v3 = vf.w;
+        const xh4 vh = *reinterpret_cast<const xh4*>(Vh + (16 * ct + r) * VP + 16 * kt + 4 * g);
+        const xh4 vl = *reinterpret_cast<const xh4*>(Vl + (16 * ct + r) * VP + 16 * kt + 4 * g);
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-          o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v0, s[t][kt].x, o[t], 0, 0, 0);
-          o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v1, s[t][kt].y, o[t], 0, 0, 0);
-          o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v2, s[t][kt].z, o[t], 0, 0, 0);
-          o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v3, s[t][kt].w, o[t], 0, 0, 0);
-        }
+        for (int t = 0; t < QT; ++t) o[t] = mma3(vh, vl, ph[t][kt], pl[t][kt], o[t]);
       }
 #pragma unroll
       for (int j = 0; j < REM; ++j) {
@@ -264,6 +293,12 @@ __global__ __launch_bounds__(256) void k_xattn_mfma(XAttnArgs p) {
       for (int t = 0; t < QT; ++t)
         if (live[t]) *reinterpret_cast<f32x4*>(p.O + row[t] * C + (size_t)head * D + 4 * g + 16 * ct) = o[t];
     }
+  };
+  fetch_q(blockIdx.x, qn_[0]);
+  fetch_q(blockIdx.x + gridDim.x, qn_[1]);
+  for (int grp = blockIdx.x; grp < n_groups; grp += 2 * gridDim.x) {
+    process(grp, qn_[0]);
+    if (grp + (int)gridDim.x < n_groups) process(grp + gridDim.x, qn_[1]);
   }
 }
 
@@ -369,8 +404,11 @@ static int launch_xattn_mfma(const XAttnArgs& a, hipStream_t st) {
   if (gx > cap) gx = cap;
   dim3 grid(gx, a.heads, a.B);
   constexpr int D = 16 * D16;
+  // (measured at BASELINE config 2, d = 64: QT = 2 -> 216 registers, 2 waves per SIMD, 70 us against 60; non-temporal q loads /
+  // context stores 72 us; heads as the fastest grid index 66 us)
   constexpr int QT = D16 <= 2 ? 2 : 1;
-  const size_t lds = (size_t)((16 * nkt + rem) * (D + 4) + D * (16 * nkt + 4) + (rem > 0 ? rem : 1) * D + 16 * nkt + rem) * sizeof(float);
+  // two fp16 planes of K [16 nkt][D + 4] and of V^T [D][16 nkt + 4], fp32 rows of the trailing keys (K and V), the key mask
+  const size_t lds = (size_t)2 * 2 * (16 * nkt * (D + 4) + D * (16 * nkt + 4)) + ((size_t)2 * (rem > 0 ? rem : 1) * D + 16 * nkt + rem) * sizeof(float);
 #define XL(NKT_, REM_) hipLaunchKernelGGL((k_xattn_mfma<D16, NKT_, REM_, QT>), grid, dim3(256), lds, st, a)
   switch (nkt * 4 + rem) {
     case 0 * 4 + 1: XL(0, 1); break;
