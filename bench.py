@@ -436,7 +436,7 @@ def main():
             result['xattn_config2'] = {'bound': 'hbm', 'achieved': x['cold']['GBps'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                        'frac': x['cold']['GBps'] / PEAK_HBM_GBS, 'warm_GBps': x['warm']['GBps'],
                                        'us_per_launch': x['cold']['us'], 'alg_bytes_per_clip': 8 * 1024,
-                                       'workload': 'T=4096 E=1024 heads=16 Lk=33, 8 queries/launch, fp32 MFMA 16x16x4'}
+                                       'workload': 'T=4096 E=1024 heads=16 Lk=33, 8 queries/launch, f16x3 split on MFMA 16x16x16 f16'}
         result['stages'] = stages
         result['event_ms_per_step'] = tot_ms / args.steps
 
