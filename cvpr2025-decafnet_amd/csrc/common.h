@@ -157,6 +157,57 @@ __device__ __forceinline__ void row_layernorm(Row<NCH>& r, int C, int lane, cons
   }
 }
 
+// A per-channel parameter vector (LayerNorm weight / bias, one tap of a depthwise convolution) of a strip kernel: rows of one
+// chunk (C <= 256) keep it in registers for the whole strip, so the strip loop issues no load but its row prefetches --
+// a parameter load inside the loop would make every s_waitcnt on it wait for the older, slower row loads too (a wave's
+// vector-memory results come back in order).  Wider rows read it at the point of use (L1 hits).
+template <int NCH>
+struct RowParam {
+  static constexpr bool CACHED = NCH == 1;
+  Row<NCH> r;
+  const float* p;
+  __device__ __forceinline__ void init(const float* __restrict__ p_, int C, int lane) {
+    p = p_;
+    if constexpr (CACHED) { if (p_) r.load(p_, C, lane); else r.zero(); }
+  }
+  __device__ __forceinline__ f32x4 get(int j, int lane) const {
+    if constexpr (CACHED) return r.v[j];
+    else return *reinterpret_cast<const f32x4*>(p + 256 * j + 4 * lane);
+  }
+};
+
+// row_layernorm with the affine parameters as RowParam (w.p == nullptr: no affine); same operation order, same bits
+template <int NCH>
+__device__ __forceinline__ void row_layernorm(Row<NCH>& r, int C, int lane, const RowParam<NCH>& w, const RowParam<NCH>& b,
+                                              float eps = 1e-5f) {
+  const float inv_c = 1.0f / (float)C;
+  float mean = r.sum() * inv_c;
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    int c = 256 * j + 4 * lane;
+    if (c < C) {
+      r.v[j].x -= mean; r.v[j].y -= mean; r.v[j].z -= mean; r.v[j].w -= mean;
+      sq += (r.v[j].x * r.v[j].x + r.v[j].y * r.v[j].y) + (r.v[j].z * r.v[j].z + r.v[j].w * r.v[j].w);
+    }
+  }
+  float var = wave_sum(sq) * inv_c;
+  float rs = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    int c = 256 * j + 4 * lane;
+    if (c < C) {
+      f32x4 x = r.v[j];
+      x.x *= rs; x.y *= rs; x.z *= rs; x.w *= rs;
+      if (w.p != nullptr) {
+        const f32x4 ww = w.get(j, lane), bb = b.get(j, lane);
+        x.x = x.x * ww.x + bb.x; x.y = x.y * ww.y + bb.y; x.z = x.z * ww.z + bb.z; x.w = x.w * ww.w + bb.w;
+      }
+      r.v[j] = x;
+    }
+  }
+}
+
 __device__ __forceinline__ float gelu_erf(float x) {
   // exact (erf) GELU, nn.GELU default (libs/modeling/blocks.py:531): 0.5 x (1 + erf(x / sqrt 2)).
   // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 rounding level) on one v_exp_f32 and one

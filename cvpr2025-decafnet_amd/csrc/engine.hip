@@ -568,7 +568,7 @@ static void carve(Arena& a, const dcf_config& c, int T0, int B, int nq, int S, i
   b.P2 = a.take<float>((size_t)nvid * T0 * E);
   b.maskv = a.take<uint8_t>(nvid > 1 ? (size_t)nvid * T0 : 0);     // the videos' masks side by side (several videos only)
   b.tn = a.take<float>((size_t)nq * c.D);
-  b.partial = a.take<float>((size_t)SCORE_SLICES * (nq + 1) * T0);
+  b.partial = a.take<float>((size_t)SCORE_SLICES * (nq + nvid) * T0);
   b.correl = a.take<float>((size_t)nq * T0);
   b.gate = a.take<float>(rows0);
   b.mask_all = a.take<uint8_t>(rowsAll);
@@ -891,11 +891,16 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
   }
   // ---- per video: sidekick scores and the query-independent halves of vid_map
   DCF_CHECK(!(gate_override && c.scat), "opt.model.scat needs the sidekick scores: the externally gated (T-sharded) forward does not take them");
-  for (int v = 0, q_off = 0; v < nvid; q_off += vs.nq[v], ++v) {
-    if (!gate_override) {
-      ScoreArgs sa{vs.shallow[v], vs.text_cls[v], b.tn + (size_t)q_off * D, b.partial, b.correl + (size_t)q_off * T0, D, T0, vs.nq[v], c.norm};
-      TRY(launch_sidekick(sa, st));
+  if (!gate_override) {                              // the scores of every video's queries: three launches in all
+    DCF_CHECK(nvid <= SCORE_MAXVID, "%d videos per forward > %d", nvid, SCORE_MAXVID);
+    ScoreArgs sa{};
+    for (int v = 0, q_off = 0; v < nvid; q_off += vs.nq[v], ++v) {
+      sa.shallow[v] = vs.shallow[v]; sa.text_cls[v] = vs.text_cls[v]; sa.nq[v] = vs.nq[v]; sa.qoff[v] = q_off;
     }
+    sa.nvid = nvid; sa.tn = b.tn; sa.partial = b.partial; sa.correl = b.correl; sa.D = D; sa.T = T0; sa.NQ = nq; sa.norm = c.norm;
+    TRY(launch_sidekick(sa, st));
+  }
+  for (int v = 0; v < nvid; ++v) {
     // deep and shallow halves of vid_map share one grid (same shape, blockIdx.z selects the operand set)
     GemmArgs g[2];
     int ng = 0;
@@ -1580,8 +1585,7 @@ int dcf_op_sidekick(const float* shallow, const float* text_cls, float* correl, 
   float *tn = nullptr, *partial = nullptr;
   DCF_HIP(hipMallocAsync((void**)&tn, (size_t)nq * D * sizeof(float), st));
   DCF_HIP(hipMallocAsync((void**)&partial, (size_t)dcf::SCORE_SLICES * (nq + 1) * T * sizeof(float), st));
-  dcf::ScoreArgs a{shallow, text_cls, tn, partial, correl, D, T, nq, norm};
-  int rc = dcf::launch_sidekick(a, st);
+  int rc = dcf::launch_sidekick(dcf::score_args(shallow, text_cls, tn, partial, correl, D, T, nq, norm), st);
   DCF_HIP(hipFreeAsync(tn, st));
   DCF_HIP(hipFreeAsync(partial, st));
   return rc;

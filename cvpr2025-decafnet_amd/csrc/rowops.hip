@@ -143,58 +143,107 @@ __device__ __forceinline__ void axpy3(Row<NCH>& out, const Row<NCH>& a, const Ro
   }
 }
 
+// depthwise k3 taps as RowParams ([3][C] in memory)
+template <int NCH>
+struct Taps3 {
+  RowParam<NCH> t[3];
+  __device__ __forceinline__ void init(const float* __restrict__ w, int C, int lane) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t[k].init(w + k * C, C, lane);
+  }
+};
+template <int NCH>
+__device__ __forceinline__ void axpy3(Row<NCH>& out, const Row<NCH>& a, const Row<NCH>& b, const Row<NCH>& c,
+                                      const Taps3<NCH>& w, int C, int lane) {
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    if (256 * j + 4 * lane < C) out.v[j] = w.t[0].get(j, lane) * a.v[j] + w.t[1].get(j, lane) * b.v[j] + w.t[2].get(j, lane) * c.v[j];
+    else out.v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+// Strip kernels below: a wave walks a strip of consecutive rows.  The validity of every input row of the strip (<= 34 rows)
+// is fetched up front -- one mask byte per lane, one ballot -- and raw rows are requested TWO rows ahead of their use
+// (unconditionally, address clamped into the sequence), so a wave keeps 2 KiB of row loads in flight across the LayerNorm
+// reductions and stores of the current row instead of one dependent round trip per row, mask byte and parameter vector.
 // ------------------------------------------------------------------------------------------
 // TransformerDecoder front half (libs/modeling/blocks.py:632-645, :513-516):
 //   q  = x * m
 //   Qc = q_norm( dwconv3( ln_xattn_q(q) * m ) )          -> input of the query projection
 //   Xa = adaln(q * m)  (LayerNorm without affine)          -> modulated later by the xattn output
 // ------------------------------------------------------------------------------------------
-template <int NCH>
+template <int NCH, bool FULL>
 __global__ __launch_bounds__(256) void k_dec_pre(DecPreArgs p) {
   const int lane = threadIdx.x & 63;
   const int STRIP = p.strip;
   const int strips_per_b = (p.T + STRIP - 1) / STRIP;
-  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int s = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the strip loop is uniform
   if (s >= strips_per_b * p.B) return;
   const int b = s / strips_per_b;
   const int t0 = (s % strips_per_b) * STRIP;
+  const int t1 = min(t0 + STRIP, p.T);
   const int64_t base = (int64_t)b * p.T;
-  const int C = p.C;
+  const int C = FULL ? 256 * NCH : p.C;                  // FULL: every lane chunk exists, no per-lane channel predicate
 
+  RowParam<NCH> lnw, lnb, qnw, qnb, none;
+  Taps3<NCH> dw;
+  lnw.init(p.ln_q_w, C, lane); lnb.init(p.ln_q_b, C, lane);
+  qnw.init(p.qn_w, C, lane); qnb.init(p.qn_b, C, lane);
+  none.init(nullptr, C, lane);
+  dw.init(p.dw, C, lane);
+
+  // rows t0-1 .. t1: lane l looks at row t0 - 1 + l
+  unsigned long long vm, lm = ~0ull, rm = ~0ull;
+  {
+    const int t = t0 - 1 + lane;
+    const bool in = lane < t1 - t0 + 2 && t >= 0 && t < p.T;
+    vm = __ballot(in && p.mask[base + t] != 0);
+    if (p.nbr) {   // pyramid mode: rows of several sequences back to back, the flags of row t say which neighbours belong to it
+      const unsigned f = in ? p.nbr[base + t] : 0u;
+      lm = __ballot((f & 2u) != 0);
+      rm = __ballot((f & 4u) != 0);
+    }
+  }
+  auto fetch = [&](int t, Row<NCH>& raw) __attribute__((always_inline)) {
+    const int tc = t < 0 ? 0 : (t < p.T ? t : p.T - 1);
+    raw.load(p.X + (base + tc) * p.ldx, C, lane);
+  };
   // normalised-and-masked row (conv input), zero outside [0,T) or where the mask is 0
-  auto conv_in = [&](int t, Row<NCH>& raw, Row<NCH>& ln) __attribute__((always_inline)) {
-    if (t >= 0 && t < p.T && p.mask[base + t]) {
-      raw.load(p.X + (base + t) * p.ldx, C, lane);
+  auto norm = [&](int t, Row<NCH>& raw, Row<NCH>& ln) __attribute__((always_inline)) {
+    if ((vm >> (t - t0 + 1)) & 1ull) {
       ln = raw;
-      row_layernorm(ln, C, lane, p.ln_q_w, p.ln_q_b);
+      row_layernorm(ln, C, lane, lnw, lnb);
     } else {
       raw.zero();
       ln.zero();
     }
   };
 
-  Row<NCH> raw_c, raw_n, prev, cur, nxt, tmp;
-  conv_in(t0 - 1, tmp, prev);
-  conv_in(t0, raw_c, cur);
-  const int t1 = min(t0 + STRIP, p.T);
-  for (int t = t0; t < t1; ++t) {
-    conv_in(t + 1, raw_n, nxt);
+  Row<NCH> raw_c, raw_n, prev, cur, nxt, x0, x1;
+  fetch(t0 - 1, raw_n); fetch(t0, raw_c); fetch(t0 + 1, x0); fetch(t0 + 2, x1);
+  norm(t0 - 1, raw_n, prev);
+  norm(t0, raw_c, cur);
+  auto emit = [&](int t, Row<NCH>& buf) __attribute__((always_inline)) {
+    raw_n = buf;                                           // row t + 1, requested two iterations ago
+    if (t + 3 <= t1) fetch(t + 3, buf);
+    norm(t + 1, raw_n, nxt);
     Row<NCH> q;
-    if (p.nbr) {      // pyramid mode: rows of several sequences back to back, the flags of row t say which neighbours belong to it
-      const unsigned f = p.nbr[base + t];
+    {
       Row<NCH> pz = prev, nz = nxt;
-      if (!(f & 2u)) pz.zero();
-      if (!(f & 4u)) nz.zero();
-      axpy3(q, pz, cur, nz, p.dw, C, lane);
-    } else {
-      axpy3(q, prev, cur, nxt, p.dw, C, lane);
+      if (!((lm >> (t - t0 + 1)) & 1ull)) pz.zero();
+      if (!((rm >> (t - t0 + 1)) & 1ull)) nz.zero();
+      axpy3(q, pz, cur, nz, dw, C, lane);
     }
-    row_layernorm(q, C, lane, p.qn_w, p.qn_b);
+    row_layernorm(q, C, lane, qnw, qnb);
     q.store(p.Qc + (base + t) * (int64_t)C, C, lane);
     Row<NCH> xa = raw_c;                       // already zero where masked
-    row_layernorm(xa, C, lane, nullptr, nullptr);
+    row_layernorm(xa, C, lane, none, none);
     xa.store(p.Xa + (base + t) * (int64_t)C, C, lane);
     prev = cur; cur = nxt; raw_c = raw_n;
+  };
+  for (int t = t0; t < t1; t += 2) {
+    emit(t, x0);
+    if (t + 1 < t1) emit(t + 1, x1);
   }
 }
 
@@ -227,50 +276,66 @@ __global__ __launch_bounds__(256) void k_dec_mid(const float* __restrict__ Xa, c
 //   xn   = ln_attn(x);  {q,k,v}c = {q,k,v}_norm( dwconv3_strideS( xn * m ) )
 // Output row i reads input rows S*i-1, S*i, S*i+1.
 // ------------------------------------------------------------------------------------------
-template <int NCH, int S>
+template <int NCH, int S, bool FULL>
 __global__ __launch_bounds__(256) void k_enc_pre(EncPreArgs p) {
   const int lane = threadIdx.x & 63;
   const int To = p.T_in / S;
   const int STRIP = p.strip;
   const int strips_per_b = (To + STRIP - 1) / STRIP;
-  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int s = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the strip loop is uniform
   if (s >= strips_per_b * p.B) return;
   const int b = s / strips_per_b;
   const int i0 = (s % strips_per_b) * STRIP;
+  const int i1 = min(i0 + STRIP, To);
   const int64_t ibase = (int64_t)b * p.T_in;
   const int64_t obase = (int64_t)b * To;
-  const int C = p.C;
+  const int C = FULL ? 256 * NCH : p.C;                  // FULL: every lane chunk exists, no per-lane channel predicate
 
-  auto conv_in = [&](int t, Row<NCH>& raw, Row<NCH>& ln, bool& valid) __attribute__((always_inline)) {
-    valid = (t >= 0 && t < p.T_in && p.mask_in[ibase + t]);
+  RowParam<NCH> lnw, lnb, qnw, qnb, knw, knb, vnw, vnb;
+  Taps3<NCH> dwq, dwk, dwv;
+  lnw.init(p.ln_w, C, lane); lnb.init(p.ln_b, C, lane);
+  qnw.init(p.qn_w, C, lane); qnb.init(p.qn_b, C, lane);
+  knw.init(p.kn_w, C, lane); knb.init(p.kn_b, C, lane);
+  vnw.init(p.vn_w, C, lane); vnb.init(p.vn_b, C, lane);
+  dwq.init(p.dw_q, C, lane); dwk.init(p.dw_k, C, lane); dwv.init(p.dw_v, C, lane);
+
+  // input rows tb .. tl of the strip (<= 2 * 16 + 1): lane l looks at row tb + l
+  const int tb = S * i0 - 1, tl = S * (i1 - 1) + 1;
+  unsigned long long vm;
+  {
+    const int t = tb + lane;
+    vm = __ballot(t <= tl && t >= 0 && t < p.T_in && p.mask_in[ibase + t] != 0);
+  }
+  auto fetch = [&](int t, Row<NCH>& raw) __attribute__((always_inline)) {
+    const int tc = t < 0 ? 0 : (t < p.T_in ? t : p.T_in - 1);
+    raw.load(p.X + (ibase + tc) * p.ldx, C, lane);
+  };
+  auto norm = [&](int t, Row<NCH>& raw, Row<NCH>& ln) __attribute__((always_inline)) -> bool {
+    const bool valid = (vm >> (t - tb)) & 1ull;
     if (valid) {
-      raw.load(p.X + (ibase + t) * p.ldx, C, lane);
       ln = raw;
-      row_layernorm(ln, C, lane, p.ln_w, p.ln_b);
+      row_layernorm(ln, C, lane, lnw, lnb);
     } else {
       raw.zero();
       ln.zero();
     }
+    return valid;
   };
 
   Row<NCH> rp, rc, rn, lp, lc, ln_;
-  bool vp, vc, vn;
-  conv_in(S * i0 - 1, rp, lp, vp);
-  const int i1 = min(i0 + STRIP, To);
-  for (int i = i0; i < i1; ++i) {
-    if (S == 2 || i == i0) conv_in(S * i, rc, lc, vc);
-    conv_in(S * i + 1, rn, ln_, vn);
+  bool vp, vc = false, vn;
+  auto emit = [&](int i) __attribute__((always_inline)) {
     Row<NCH> o;
-    axpy3(o, lp, lc, ln_, p.dw_q, C, lane);
-    row_layernorm(o, C, lane, p.qn_w, p.qn_b);
+    axpy3(o, lp, lc, ln_, dwq, C, lane);
+    row_layernorm(o, C, lane, qnw, qnb);
     o.store(p.Qc + (obase + i) * (int64_t)C, C, lane);
-    axpy3(o, lp, lc, ln_, p.dw_k, C, lane);
-    row_layernorm(o, C, lane, p.kn_w, p.kn_b);
+    axpy3(o, lp, lc, ln_, dwk, C, lane);
+    row_layernorm(o, C, lane, knw, knb);
     o.store(p.Kc + (obase + i) * (int64_t)C, C, lane);
-    axpy3(o, lp, lc, ln_, p.dw_v, C, lane);
-    row_layernorm(o, C, lane, p.vn_w, p.vn_b);
+    axpy3(o, lp, lc, ln_, dwv, C, lane);
+    row_layernorm(o, C, lane, vnw, vnb);
     o.store(p.Vc + (obase + i) * (int64_t)C, C, lane);
-    if (S == 2) {
+    if constexpr (S == 2) {
       // max over the valid window entries; 0 when the output position itself is padded
       // (its mask is mask_in[2i] == vc) -- the global-min filler never wins, see DESIGN.md
 #pragma unroll
@@ -281,10 +346,36 @@ __global__ __launch_bounds__(256) void k_enc_pre(EncPreArgs p) {
         o.v[j] = vc ? m : f32x4{0.f, 0.f, 0.f, 0.f};
       }
       o.store(p.Skip + (obase + i) * (int64_t)C, C, lane);
+    }
+  };
+
+  Row<NCH> x0, x1;
+  if constexpr (S == 2) {
+    fetch(tb, rp); fetch(tb + 1, x0); fetch(tb + 2, x1);
+    vp = norm(tb, rp, lp);
+    for (int i = i0; i < i1; ++i) {
+      rc = x0; rn = x1;                                    // rows 2i, 2i + 1, requested one iteration ago
+      if (i + 1 < i1) { fetch(2 * i + 2, x0); fetch(2 * i + 3, x1); }
+      vc = norm(2 * i, rc, lc);
+      vn = norm(2 * i + 1, rn, ln_);
+      emit(i);
       rp = rn; lp = ln_; vp = vn;
-    } else {
+    }
+  } else {
+    fetch(tb, rp); fetch(tb + 1, rc); fetch(tb + 2, x0); fetch(tb + 3, x1);
+    vp = norm(tb, rp, lp);
+    vc = norm(tb + 1, rc, lc);
+    auto one = [&](int i, Row<NCH>& buf) __attribute__((always_inline)) {
+      rn = buf;                                            // row i + 1, requested two iterations ago
+      if (i + 3 <= tl) fetch(i + 3, buf);
+      vn = norm(i + 1, rn, ln_);
+      emit(i);
       rp = rc; lp = lc; vp = vc;
       rc = rn; lc = ln_; vc = vn;
+    };
+    for (int i = i0; i < i1; i += 2) {
+      one(i, x0);
+      if (i + 1 < i1) one(i + 1, x1);
     }
   }
 }
@@ -379,17 +470,23 @@ __global__ void k_rows_to_chanmajor(const float* __restrict__ X, float* __restri
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-#define DISPATCH_NCH(C, CALL)                                                     \
+#define DISPATCH_NCH(C, ...)                                                      \
   do {                                                                            \
     int _n = ((C) + 255) / 256;                                                   \
     DCF_CHECK((C) % 4 == 0 && _n >= 1 && _n <= 4, "channels=%d unsupported (need C %% 4 == 0, C <= 1024)", (int)(C)); \
     switch (_n) {                                                                 \
-      case 1: { constexpr int NCH = 1; CALL; } break;                             \
-      case 2: { constexpr int NCH = 2; CALL; } break;                             \
-      case 3: { constexpr int NCH = 3; CALL; } break;                             \
-      default: { constexpr int NCH = 4; CALL; } break;                            \
+      case 1: { constexpr int NCH = 1; __VA_ARGS__; } break;                      \
+      case 2: { constexpr int NCH = 2; __VA_ARGS__; } break;                      \
+      case 3: { constexpr int NCH = 3; __VA_ARGS__; } break;                      \
+      default: { constexpr int NCH = 4; __VA_ARGS__; } break;                     \
     }                                                                             \
     DCF_HIP(hipGetLastError());                                                   \
+  } while (0)
+// the same with `constexpr bool FULL` = "C is a whole number of 256-channel chunks" defined for the call
+#define DISPATCH_NCH_FULL(C, ...)                                                 \
+  do {                                                                            \
+    if ((C) % 256 == 0) { constexpr bool FULL = true; DISPATCH_NCH(C, __VA_ARGS__); }    \
+    else { constexpr bool FULL = false; DISPATCH_NCH(C, __VA_ARGS__); }           \
   } while (0)
 
 int launch_rowflags(const uint8_t* mask, uint8_t* nbr, int T, int rows, hipStream_t st) {
@@ -439,7 +536,7 @@ int launch_dec_pre(const DecPreArgs& a_, hipStream_t st) {
   const int STRIP = a.strip;
   int strips = a.B * ((a.T + STRIP - 1) / STRIP);
   ProfScope prof("dec_pre", st, 30.0 * a.B * a.T * a.C, 4.0 * 3.0 * a.B * a.T * a.C);
-  DISPATCH_NCH(a.C, hipLaunchKernelGGL((k_dec_pre<NCH>), dim3((strips + 3) / 4), dim3(256), 0, st, a));
+  DISPATCH_NCH_FULL(a.C, hipLaunchKernelGGL((k_dec_pre<NCH, FULL>), dim3((strips + 3) / 4), dim3(256), 0, st, a));
   return 0;
 }
 
@@ -464,10 +561,10 @@ int launch_enc_pre(const EncPreArgs& a_, int stride, hipStream_t st) {
   ProfScope prof(stride == 1 ? "enc_pre_s1" : "enc_pre_s2", st, 50.0 * a.B * To * a.C,
                  4.0 * a.C * a.B * ((double)a.T_in + (stride == 1 ? 3.0 : 4.0) * To));
   if (stride == 1) {
-    DISPATCH_NCH(a.C, hipLaunchKernelGGL((k_enc_pre<NCH, 1>), dim3((strips + 3) / 4), dim3(256), 0, st, a));
+    DISPATCH_NCH_FULL(a.C, hipLaunchKernelGGL((k_enc_pre<NCH, 1, FULL>), dim3((strips + 3) / 4), dim3(256), 0, st, a));
   } else {
     DCF_CHECK(a.Skip, "enc_pre: stride 2 needs a skip buffer");
-    DISPATCH_NCH(a.C, hipLaunchKernelGGL((k_enc_pre<NCH, 2>), dim3((strips + 3) / 4), dim3(256), 0, st, a));
+    DISPATCH_NCH_FULL(a.C, hipLaunchKernelGGL((k_enc_pre<NCH, 2, FULL>), dim3((strips + 3) / 4), dim3(256), 0, st, a));
   }
   return 0;
 }

@@ -8,15 +8,30 @@ namespace dcf {
 constexpr int SCORE_SLICES = 32;   // channel slices of the partial-sum pass
 constexpr int SCORE_MAXQ = 8;      // queries per scoring launch
 
+constexpr int SCORE_MAXVID = 16;   // videos per scoring launch (= videos per forward)
+
+// Scores of the queries of up to SCORE_MAXVID videos in one pass (three launches in all).  Video v owns rows
+// qoff[v] .. qoff[v] + nq[v] - 1 of tn and correl and rows qoff[v] + v .. (its sum of squares, then its queries) of every
+// slice of partial.
 struct ScoreArgs {
-  const float* shallow;   // (D, T) channel-major -- the reference layout of shallow_vid[0]
-  const float* text_cls;  // (NQ, D)
-  float* tn;              // (NQ, D) scratch: normalised text_cls
-  float* partial;         // [SCORE_SLICES][NQ + 1][T] scratch
+  const float* shallow[SCORE_MAXVID];   // (D, T) channel-major -- the reference layout of shallow_vid[0]
+  const float* text_cls[SCORE_MAXVID];  // (nq[v], D)
+  int nq[SCORE_MAXVID], qoff[SCORE_MAXVID];
+  int nvid;
+  float* tn;              // (NQ, D) scratch: normalised text_cls, NQ = sum of nq[v]
+  float* partial;         // [SCORE_SLICES][NQ + nvid][T] scratch
   float* correl;          // (NQ, T) out
   int D, T, NQ, norm;
 };
 int launch_sidekick(const ScoreArgs& a, hipStream_t st);
+// one video
+inline ScoreArgs score_args(const float* shallow, const float* text_cls, float* tn, float* partial, float* correl, int D, int T,
+                            int nq, int norm) {
+  ScoreArgs a{};
+  a.shallow[0] = shallow; a.text_cls[0] = text_cls; a.nq[0] = nq; a.qoff[0] = 0; a.nvid = 1;
+  a.tn = tn; a.partial = partial; a.correl = correl; a.D = D; a.T = T; a.NQ = nq; a.norm = norm;
+  return a;
+}
 
 struct GateArgs {
   const float* correl;      // (NQ, T), row q0 + b is used for batch element b

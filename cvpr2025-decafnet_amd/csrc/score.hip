@@ -15,25 +15,47 @@
 
 namespace dcf {
 
-__global__ __launch_bounds__(256) void k_text_cls_norm(const float* __restrict__ cls, float* __restrict__ tn, int D, int norm) {
+// entry v of a kernel-argument array for a wave-uniform v: a chain of selects over static indices (a dynamically indexed
+// by-value argument array is copied to scratch memory first)
+template <typename T>
+__device__ __forceinline__ T pick(const T (&a)[SCORE_MAXVID], int v) {
+  T r = a[0];
+#pragma unroll
+  for (int i = 1; i < SCORE_MAXVID; ++i) r = v == i ? a[i] : r;
+  return r;
+}
+
+// grid = total queries; video of query row q: the last v with qoff[v] <= q
+__global__ __launch_bounds__(256) void k_text_cls_norm(ScoreArgs p) {
   __shared__ float red[4];
   const int q = blockIdx.x, tid = threadIdx.x;
+  int v = 0;
+#pragma unroll
+  for (int i = 1; i < SCORE_MAXVID; ++i) v = (i < p.nvid && p.qoff[i] <= q) ? i : v;
+  const float* cls = pick(p.text_cls, v) + (size_t)(q - pick(p.qoff, v)) * p.D;
+  const int D = p.D;
   float s = 0.f;
-  for (int c = tid; c < D; c += 256) { float v = cls[(size_t)q * D + c]; s += v * v; }
+  for (int c = tid; c < D; c += 256) { float x = cls[c]; s += x * x; }
   s = wave_sum(s);
   if ((tid & 63) == 0) red[tid >> 6] = s;
   __syncthreads();
   const float nrm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
-  const float inv = norm ? 1.0f / (nrm + 1e-4f) : 1.0f;
-  for (int c = tid; c < D; c += 256) tn[(size_t)q * D + c] = cls[(size_t)q * D + c] * inv;
+  const float inv = p.norm ? 1.0f / (nrm + 1e-4f) : 1.0f;
+  for (int c = tid; c < D; c += 256) p.tn[(size_t)q * D + c] = cls[c] * inv;
 }
 
-// grid = (ceil(T/256), SCORE_SLICES); block = 64 (one wave, 4 clips per lane)
+// grid = (ceil(T/256), SCORE_SLICES, nvid * query chunks); block = 64 (one wave, 4 clips per lane)
 template <int NQ>
-__global__ __launch_bounds__(64) void k_sidekick_partial(ScoreArgs p, int q0) {
+__global__ __launch_bounds__(64) void k_sidekick_partial(ScoreArgs p) {
   const int lane = threadIdx.x;
   const int t = (blockIdx.x * 64 + lane) * 4;
   const int slice = blockIdx.y;
+  const int vid = blockIdx.z % p.nvid, q0 = (blockIdx.z / p.nvid) * SCORE_MAXQ;
+  const int nqv = pick(p.nq, vid) - q0;                 // queries of this video left for this chunk (may be <= 0 or > NQ)
+  if (nqv <= 0) return;
+  const int qrow = pick(p.qoff, vid) + q0;              // first of them in tn / correl
+  const float* shallow = pick(p.shallow, vid);
+  const float* tn = p.tn + (size_t)qrow * p.D;
   const int cps = (p.D + SCORE_SLICES - 1) / SCORE_SLICES;
   const int c0 = slice * cps, c1 = min(c0 + cps, p.D);
   const bool vec = (p.T & 3) == 0;
@@ -44,71 +66,77 @@ __global__ __launch_bounds__(64) void k_sidekick_partial(ScoreArgs p, int q0) {
   if (t < p.T) {
     int c = c0;
     if (vec) {
-      // eight channel rows requested before the first is used: with one wave per SIMD (1024-2048 waves in all) a
-      // load per iteration left the loop waiting for one round trip per channel (35 us for 64 MiB)
+      // eight channel rows requested before the first is used: a load per iteration left the loop waiting for one round trip
+      // per channel (35 us for 64 MiB)
       for (; c + 8 <= c1; c += 8) {
         f32x4 x[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const f32x4*>(p.shallow + (size_t)(c + u) * p.T + t);
+        for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const f32x4*>(shallow + (size_t)(c + u) * p.T + t);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           ss += x[u] * x[u];
 #pragma unroll
-          for (int q = 0; q < NQ; ++q) dot[q] += x[u] * p.tn[(size_t)(q0 + q) * p.D + c + u];
+          for (int q = 0; q < NQ; ++q) dot[q] += x[u] * tn[(size_t)(q < nqv ? q : 0) * p.D + c + u];
         }
       }
     }
     for (; c < c1; ++c) {
-      const float* src = p.shallow + (size_t)c * p.T + t;
+      const float* src = shallow + (size_t)c * p.T + t;
       f32x4 x = {0.f, 0.f, 0.f, 0.f};
       if (vec) x = *reinterpret_cast<const f32x4*>(src);
       else { x.x = src[0]; if (t + 1 < p.T) x.y = src[1]; if (t + 2 < p.T) x.z = src[2]; if (t + 3 < p.T) x.w = src[3]; }
       ss += x * x;
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) dot[q] += x * p.tn[(size_t)(q0 + q) * p.D + c];   // wave-uniform scalar load
+      for (int q = 0; q < NQ; ++q) dot[q] += x * tn[(size_t)(q < nqv ? q : 0) * p.D + c];   // wave-uniform scalar load
     }
-    float* dst = p.partial + ((size_t)slice * (p.NQ + 1)) * p.T + t;
+    float* dst = p.partial + ((size_t)slice * (p.NQ + p.nvid) + qrow + vid) * p.T + t;      // the video's ss row
     const int n = min(4, p.T - t);
     for (int i = 0; i < n; ++i) {
       if (q0 == 0) dst[i] = ss[i];
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) dst[(size_t)(1 + q0 + q) * p.T + i] = dot[q][i];
+      for (int q = 0; q < NQ; ++q)
+        if (q < nqv) dst[(size_t)(1 + q) * p.T + i] = dot[q][i];
     }
   }
 }
 
+// grid = (ceil(T/256), nvid)
 __global__ __launch_bounds__(256) void k_sidekick_final(ScoreArgs p) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= p.T) return;
+  const int vid = blockIdx.y;
+  const int nq = pick(p.nq, vid), qoff = pick(p.qoff, vid);
+  const size_t rows = p.NQ + p.nvid, row0 = qoff + vid;
   float ss = 0.f;
-  for (int s = 0; s < SCORE_SLICES; ++s) ss += p.partial[((size_t)s * (p.NQ + 1)) * p.T + t];
+  for (int s = 0; s < SCORE_SLICES; ++s) ss += p.partial[((size_t)s * rows + row0) * p.T + t];
   const float inv = p.norm ? 1.0f / (sqrtf(ss) + 1e-4f) : 1.0f;
-  for (int q = 0; q < p.NQ; ++q) {
+  for (int q = 0; q < nq; ++q) {
     float d = 0.f;
-    for (int s = 0; s < SCORE_SLICES; ++s) d += p.partial[((size_t)s * (p.NQ + 1) + 1 + q) * p.T + t];
-    p.correl[(size_t)q * p.T + t] = d * inv;
+    for (int s = 0; s < SCORE_SLICES; ++s) d += p.partial[((size_t)s * rows + row0 + 1 + q) * p.T + t];
+    p.correl[(size_t)(qoff + q) * p.T + t] = d * inv;
   }
 }
 
 int launch_sidekick(const ScoreArgs& a, hipStream_t st) {
-  if (a.NQ <= 0 || a.T <= 0) return 0;
-  ProfScope prof("sidekick_score", st, 2.0 * (a.NQ + 1.0) * a.D * a.T, 4.0 * (double)a.D * a.T * ((a.NQ + SCORE_MAXQ - 1) / SCORE_MAXQ));
-  hipLaunchKernelGGL(k_text_cls_norm, dim3(a.NQ), dim3(256), 0, st, a.text_cls, a.tn, a.D, a.norm);
-  dim3 grid((a.T + 255) / 256, SCORE_SLICES);
-  for (int q0 = 0; q0 < a.NQ; q0 += SCORE_MAXQ) {
-    int n = a.NQ - q0 < SCORE_MAXQ ? a.NQ - q0 : SCORE_MAXQ;
-    switch (n) {
-      case 1: hipLaunchKernelGGL(k_sidekick_partial<1>, grid, dim3(64), 0, st, a, q0); break;
-      case 2: hipLaunchKernelGGL(k_sidekick_partial<2>, grid, dim3(64), 0, st, a, q0); break;
-      case 3: hipLaunchKernelGGL(k_sidekick_partial<3>, grid, dim3(64), 0, st, a, q0); break;
-      case 4: hipLaunchKernelGGL(k_sidekick_partial<4>, grid, dim3(64), 0, st, a, q0); break;
-      case 5: hipLaunchKernelGGL(k_sidekick_partial<5>, grid, dim3(64), 0, st, a, q0); break;
-      case 6: hipLaunchKernelGGL(k_sidekick_partial<6>, grid, dim3(64), 0, st, a, q0); break;
-      case 7: hipLaunchKernelGGL(k_sidekick_partial<7>, grid, dim3(64), 0, st, a, q0); break;
-      default: hipLaunchKernelGGL(k_sidekick_partial<8>, grid, dim3(64), 0, st, a, q0); break;
-    }
+  if (a.NQ <= 0 || a.T <= 0 || a.nvid <= 0) return 0;
+  DCF_CHECK(a.nvid <= SCORE_MAXVID, "sidekick: %d videos per launch > %d", a.nvid, SCORE_MAXVID);
+  int maxq = 0;
+  for (int v = 0; v < a.nvid; ++v) maxq = a.nq[v] > maxq ? a.nq[v] : maxq;
+  const int chunks = (maxq + SCORE_MAXQ - 1) / SCORE_MAXQ;
+  ProfScope prof("sidekick_score", st, 2.0 * (a.NQ + a.nvid) * a.D * a.T, 4.0 * (double)a.D * a.T * a.nvid * chunks);
+  hipLaunchKernelGGL(k_text_cls_norm, dim3(a.NQ), dim3(256), 0, st, a);
+  dim3 grid((a.T + 255) / 256, SCORE_SLICES, a.nvid * chunks);
+  switch (maxq < SCORE_MAXQ ? maxq : SCORE_MAXQ) {
+    case 1: hipLaunchKernelGGL(k_sidekick_partial<1>, grid, dim3(64), 0, st, a); break;
+    case 2: hipLaunchKernelGGL(k_sidekick_partial<2>, grid, dim3(64), 0, st, a); break;
+    case 3: hipLaunchKernelGGL(k_sidekick_partial<3>, grid, dim3(64), 0, st, a); break;
+    case 4: hipLaunchKernelGGL(k_sidekick_partial<4>, grid, dim3(64), 0, st, a); break;
+    case 5: hipLaunchKernelGGL(k_sidekick_partial<5>, grid, dim3(64), 0, st, a); break;
+    case 6: hipLaunchKernelGGL(k_sidekick_partial<6>, grid, dim3(64), 0, st, a); break;
+    case 7: hipLaunchKernelGGL(k_sidekick_partial<7>, grid, dim3(64), 0, st, a); break;
+    default: hipLaunchKernelGGL(k_sidekick_partial<8>, grid, dim3(64), 0, st, a); break;
   }
-  hipLaunchKernelGGL(k_sidekick_final, dim3((a.T + 255) / 256), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_sidekick_final, dim3((a.T + 255) / 256, a.nvid), dim3(256), 0, st, a);
   DCF_HIP(hipGetLastError());
   return 0;
 }
