@@ -340,12 +340,17 @@ static int resolve_tcn(dcf_model* m, const std::string& pre, int n_in, int n_lay
     GET(p + ".conv_1x1.weight", SH(TCN_HID, TCN_HID), t);
     if (pack3(m, t, 1, TCN_HID, TCN_HID, 0, 2, 1, st, &pk)) return -1;
     m->tcn_wp.push_back(pk);
+    if (m->gemm_terms == GEMM_F16X3) {                   // the layers run in f16x3 too: same weight range, same fallback
+      if (launch_f16_weight_range(m->tcn_wd.back(), 3 * TCN_HID * TCN_HID, m->status ? m->status + 1 : nullptr, st)) return -1;
+      if (launch_f16_weight_range(m->tcn_wp.back(), TCN_HID * TCN_HID, m->status ? m->status + 1 : nullptr, st)) return -1;
+    }
     GET(p + ".conv_1x1.bias", SH(TCN_HID), t); m->tcn_bp.push_back(t);
     GET(p + ".norm.weight", SH(TCN_HID), t); m->tcn_lnw.push_back(t);
     GET(p + ".norm.bias", SH(TCN_HID), t); m->tcn_lnb.push_back(t);
   }
   GET(pre + ".conv_out.weight", SH(TCN_HID, TCN_HID), t);
   if (pack3(m, t, 1, TCN_HID, TCN_HID, 0, 2, 1, st, &m->tcn_out_w)) return -1;
+  if (m->gemm_terms == GEMM_F16X3 && launch_f16_weight_range(m->tcn_out_w, TCN_HID * TCN_HID, m->status ? m->status + 1 : nullptr, st)) return -1;
   GET(pre + ".conv_out.bias", SH(TCN_HID), m->tcn_out_b);
   return 0;
 }
@@ -652,8 +657,11 @@ static int run_ffn(dcf_model* m, const float* X, const float* fc_w, const float*
 }
 
 // can this GEMM carry its LayerNorm in the epilogue?  (bf16-split path with planes for W, tile spanning the row)
+// ... and is its K loop long enough to pay for the heavier epilogue (two workgroup-wide reductions on a 64-row tile)?  At
+// K = 256 the fused kernel takes 117 us for 81920 rows against 55 + 39 us for the 128x256 kernel + the LayerNorm kernel (65
+// against 28 + 20 us at 40960 rows); at K = 768 (embedding convolutions) 232 against ~280 us, at K = 1024 a tie.
 static bool can_fuse_ln(dcf_model* m, const float* W, int M, int N, int K, GemmAMode mode) {
-  return m->gemm_terms != 0 && m->wsplit.count(W) && m->wsplit_ldw[W] == K && gemm_can_fuse_ln(M, N, K, mode);
+  return m->gemm_terms != 0 && m->wsplit.count(W) && m->wsplit_ldw[W] == K && K >= 512 && gemm_can_fuse_ln(M, N, K, mode);
 }
 
 // TransformerEncoder (vid_net) at one level.  Xin: [B*T_in][ldx]; output rows [B*T_out] at Xout (ld ldo).
@@ -1025,6 +1033,7 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
       ra.w_out = m->tcn_out_w; ra.b_out = m->tcn_out_b;
       ra.bufA = b.tcnA; ra.bufB = b.tcnB; ra.F = b.F; ra.ldf = E + TCN_HID; ra.E = E;
       ra.B = B; ra.T0 = T0; ra.n_levels = L; ra.n_layers = L;
+      ra.f16 = m->gemm_terms == GEMM_F16X3; ra.status = m->status;
       TRY(launch_refine(ra, lt, st));
     }
     TRY(run_head_pair(m, m->cls2, m->reg, b, *pl, E + TCN_HID, 1, 0, logits_out + (int64_t)q0 * S, 2, 1,
@@ -1719,6 +1728,7 @@ int dcf_op_tcn(dcf_model* m, const char* prefix, const float* x, const uint8_t* 
     ra.w_out = m->tcn_out_w; ra.b_out = m->tcn_out_b;
     ra.bufA = buf; ra.bufB = buf + (size_t)B * T * TCN_HID; ra.F = Y; ra.ldf = TCN_HID; ra.E = 0;
     ra.B = B; ra.T0 = T; ra.n_levels = n_in; ra.n_layers = n_layers;
+    ra.f16 = m->gemm_terms == GEMM_F16X3; ra.status = m->status;
     rc = launch_refine(ra, lt, st);
   }
   rc = scratch_end(m, st, rc);

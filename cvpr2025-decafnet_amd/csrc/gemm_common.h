@@ -138,50 +138,69 @@ __device__ __forceinline__ void gemm_epilogue_wide_body(const GemmArgs& p, f32x1
   const unsigned ldc = (unsigned)p.ldc, ldr = (unsigned)p.ldr;
   const int r = lane & 31, h = lane >> 5;
   const int rr = lane >> 3, c4 = (lane & 7) * 4;                       // read-back role: row rr + 8 p, columns c4 .. c4+3
+  constexpr int NF = TM * TN;                                          // 32x32 fragments of the wave, f = i * TN + j
+  // The residual rows of fragment f + 2 are requested while fragment f is transposed and stored: one exposed round trip per
+  // wave tile instead of one per fragment (8 x ~2 k cycles of a 128x256 tile's 16 k-cycle epilogue at K = 256).  Everything
+  // else the fragments read (row masks, bias, LayerScale) is fetched before the first of them.
+  f32x4 res[2][4];
+  auto load_res = [&](int f, f32x4 (&dst)[4]) __attribute__((always_inline)) {
+    const int i = f / TN, j = f % TN;
+    const unsigned colb = (unsigned)((wn * TN + j) * 32 + c4);
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    float mk[4] = {1.f, 1.f, 1.f, 1.f};
-    if constexpr (RES) {
-      if (Mb) {
+    for (int q = 0; q < 4; ++q) {
+      const unsigned row = (unsigned)((wm * TM + i) * 32 + rr + 8 * q);
+      dst[q] = (FULL || (int)row < rows_left) ? *reinterpret_cast<const f32x4*>(Rb + row * ldr + colb) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  if constexpr (RES) {
+    load_res(0, res[0]);
+    if constexpr (NF > 1) load_res(1, res[1]);
+  }
+  unsigned mkbits = ~0u;                                               // bit 4 i + q: row mask of read-back row q of fragment row i
+  if constexpr (RES) {
+    if (Mb) {
+      mkbits = 0u;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int row = (wm * TM + i) * 32 + rr + 8 * q;
-          if (FULL || row < rows_left) mk[q] = Mb[row] ? 1.f : 0.f;
+          if ((FULL || row < rows_left) ? Mb[row] != 0 : true) mkbits |= 1u << (4 * i + q);
         }
-      }
     }
+  }
+  f32x4 bias[TN], ls[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const unsigned colb = (unsigned)((wn * TN + j) * 32 + c4);
-      f32x4 bias = {0.f, 0.f, 0.f, 0.f}, ls = {1.f, 1.f, 1.f, 1.f};
-      if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + n0 + colb);
-      f32x4 res[4];
+  for (int j = 0; j < TN; ++j) {
+    const unsigned colb = (unsigned)((wn * TN + j) * 32 + c4);
+    bias[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ls[j] = f32x4{1.f, 1.f, 1.f, 1.f};
+    if (p.bias) bias[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + colb);
+    if constexpr (RES) { if (p.ls) ls[j] = *reinterpret_cast<const f32x4*>(p.ls + n0 + colb); }
+  }
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    const int i = f / TN, j = f % TN;
+    const unsigned colb = (unsigned)((wn * TN + j) * 32 + c4);
+    // D layout -> LDS: element e of lane (r, h) is row (e & 3) + 8 (e >> 2) + 4 h, column r
+#pragma unroll
+    for (int e = 0; e < 16; ++e) tile[((e & 3) + 8 * (e >> 2) + 4 * h) * EPI_PITCH + r] = acc[i][j][e];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned row = (unsigned)((wm * TM + i) * 32 + rr + 8 * q);
+      f32x4 v = *reinterpret_cast<const f32x4*>(tile + (rr + 8 * q) * EPI_PITCH + c4) + bias[j];
+      if constexpr (ACT == 1) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+      if constexpr (ACT == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       if constexpr (RES) {
-        if (p.ls) ls = *reinterpret_cast<const f32x4*>(p.ls + n0 + colb);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const unsigned row = (unsigned)((wm * TM + i) * 32 + rr + 8 * q);
-          res[q] = (FULL || (int)row < rows_left) ? *reinterpret_cast<const f32x4*>(Rb + row * ldr + colb) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        const float mkq = (mkbits >> (4 * i + q)) & 1u ? 1.f : 0.f;
+        if (flags & G_OUT_MASK) v *= mkq;
+        f32x4 r_ = res[f & 1][q];
+        if (flags & G_RES_MASK) r_ *= mkq;
+        v = r_ + ls[j] * v;
       }
-      // D layout -> LDS: element e of lane (r, h) is row (e & 3) + 8 (e >> 2) + 4 h, column r
-#pragma unroll
-      for (int e = 0; e < 16; ++e) tile[((e & 3) + 8 * (e >> 2) + 4 * h) * EPI_PITCH + r] = acc[i][j][e];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const unsigned row = (unsigned)((wm * TM + i) * 32 + rr + 8 * q);
-        f32x4 v = *reinterpret_cast<const f32x4*>(tile + (rr + 8 * q) * EPI_PITCH + c4) + bias;
-        if constexpr (ACT == 1) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
-        if constexpr (ACT == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if constexpr (RES) {
-          if (flags & G_OUT_MASK) v *= mk[q];
-          f32x4 r_ = res[q];
-          if (flags & G_RES_MASK) r_ *= mk[q];
-          v = r_ + ls * v;
-        }
-        if (FULL || (int)row < rows_left) *reinterpret_cast<f32x4*>(Cb + row * ldc + colb) = v;
-      }
+      if (FULL || (int)row < rows_left) *reinterpret_cast<f32x4*>(Cb + row * ldc + colb) = v;
     }
+    if constexpr (RES) { if (f + 2 < NF) load_res(f + 2, res[f & 1]); }
   }
 }
 

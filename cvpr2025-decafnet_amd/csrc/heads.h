@@ -48,7 +48,12 @@ struct RefineArgs {
   int B, T0, n_levels, n_layers;
   const float* stacked;               // optional [B*T0][n_levels] TCN input given directly (dcf_op_tcn); then logits1 / lt are
                                       // not read and nothing is pooled down a pyramid
+  int f16;                            // 1: the layers run on the matrix cores in the f16x3 arithmetic of the dense convolutions
+                                      // (weights range-checked with launch_f16_weight_range), 0: fp32 on the vector ALUs
+  unsigned* status;                   // f16: sticky numerics word (bit 0 raised on a non-finite intermediate), may be null
 };
 int launch_refine(const RefineArgs& a, const LevelTable& host_lt, hipStream_t st);
+// raises *flag if a weight of the TCN does not fit the scaled fp16 range of the f16 mode (|w| < 255.9)
+int launch_f16_weight_range(const float* w, int n, unsigned* flag, hipStream_t st);
 
 }  // namespace dcf

@@ -1,8 +1,7 @@
 // Head output convolutions + the iterative refinement branch (libs/modeling/model.py:442-471,
-// libs/modeling/tcn.py, libs/modeling/head.py).  These are thin (1-2 output channels, or 32 hidden
-// channels) so they run on the vector ALUs; the 32-channel TCN keeps a whole row in the registers
-// of ONE lane (each lane reads its row as full 128-byte lines) and takes the weights through
-// wave-uniform scalar loads.
+// libs/modeling/tcn.py, libs/modeling/head.py).  The output convolutions are thin (1-2 output channels) and run on the
+// vector ALUs.  The 32-channel TCN layers run on the matrix cores in the f16x3 arithmetic of the dense convolutions
+// (k_tcn_layer_mfma); the fp32 vector-ALU layer (k_tcn_layer) serves the other arithmetic modes.
 #include "common.h"
 #include "heads.h"
 
@@ -241,6 +240,202 @@ __global__ __launch_bounds__(256) void k_tcn_layer(const float* __restrict__ X, 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same layer on the matrix cores (f16x3 arithmetic of the dense convolutions: every fp32 operand as hi + lo fp16
+// planes, three v_mfma_f32_32x32x16_f16 products per step, operands pre-scaled by 2^4 / 2^8 -- gemm_bf16s.hip).
+// A wave owns 32 consecutive rows; the products are taken TRANSPOSED, D[co][row] = sum_k W[co][k] X[k][row], so that
+//   * the weights are the A operand: lane (co = lane & 31, h = lane >> 5) builds its fragments once per wave
+//     (dilated conv: 6 chunks of 16 k = (tap, 16 channels); 1x1 convs: 2 chunks) and keeps them in registers,
+//   * the activations are the B operand: lane (row, h) reads 8 consecutive channels of its own row -- 32-byte pieces of
+//     the 128-byte rows, no LDS, no transposition,
+//   * an accumulator lane holds, for its row, the 16 channels 8q + 4h + j (q, j = 0..3): element e = 4q + j.  Chunk c of
+//     the NEXT product (hidden -> 1x1 conv, LayerNorm output -> conv_out) takes elements 8c .. 8c + 7 as they are, and the
+//     weight fragments of that product are built with the same channel order (k position i of chunk c = channel
+//     8 (2c + i / 4) + 4h + i % 4), so three chained GEMMs never leave the registers.
+// The LayerNorm over the 32 channels of a row is 16 in-lane terms + one v_permlane32_swap.  LAST: refine.conv_out
+// (1x1, * mask) runs in the same kernel and writes columns [E, E + 32) of the level-0 pyramid rows.
+// 29 us per layer on the vector ALUs (19 TFLOP/s) -> 16 us.
+// ------------------------------------------------------------------------------------------
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+constexpr float TCN_SA = 16.f, TCN_SW = 256.f, TCN_UNSCALE = 1.f / 4096.f;
+
+__device__ __forceinline__ void split8(const float (&x)[8], float s, h16x8& hi, h16x8& lo) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const _Float16 hv = (_Float16)(x[i] * s);
+    hi[i] = hv;
+    lo[i] = (_Float16)__builtin_fmaf(x[i], s, -(float)hv);     // exact residual
+  }
+}
+__device__ __forceinline__ f32x16 mma3(const h16x8& ah, const h16x8& al, const h16x8& bh, const h16x8& bl, f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);     // smallest terms first
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+}
+// fragments of a (ci, co) 32x32 weight for a product whose B operand is an accumulator (see above)
+__device__ __forceinline__ void chain_frags(const float* __restrict__ w, int co, int h, h16x8 (&fh)[2], h16x8 (&fl)[2]) {
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = w[(8 * (2 * c + i / 4) + 4 * h + i % 4) * TCN_HID + co];
+    split8(x, TCN_SW, fh[c], fl[c]);
+  }
+}
+__device__ __forceinline__ void chan4(const float* __restrict__ v, int h, f32x4 (&out)[4]) {   // v[8q + 4h .. + 3], q = 0..3
+#pragma unroll
+  for (int q = 0; q < 4; ++q) out[q] = *reinterpret_cast<const f32x4*>(v + 8 * q + 4 * h);
+}
+
+template <bool LAST>
+__global__ __launch_bounds__(256) void k_tcn_layer_mfma(const float* __restrict__ X, float* __restrict__ Y,
+                                                         const float* __restrict__ wd, const float* __restrict__ bd,
+                                                         const float* __restrict__ wp, const float* __restrict__ bp,
+                                                         const float* __restrict__ lnw, const float* __restrict__ lnb,
+                                                         const uint8_t* __restrict__ mask, int B, int T0, int dil, int tiles_per_wave,
+                                                         const float* __restrict__ wo, const float* __restrict__ bo,
+                                                         float* __restrict__ F, int64_t ldf, int E, unsigned* __restrict__ status) {
+  const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
+  const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int rows = B * T0;
+  if (wave * tiles_per_wave * 32 >= rows) return;
+
+  h16x8 wd_h[6], wd_l[6], wp_h[2], wp_l[2], wo_h[2], wo_l[2];
+#pragma unroll
+  for (int kc = 0; kc < 6; ++kc) {                       // chunk kc = (tap, 16-channel half): k position i = channel 16 cc + 8 h + i
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = wd[((kc >> 1) * TCN_HID + 16 * (kc & 1) + 8 * h + i) * TCN_HID + n];
+    split8(x, TCN_SW, wd_h[kc], wd_l[kc]);
+  }
+  chain_frags(wp, n, h, wp_h, wp_l);
+  if constexpr (LAST) chain_frags(wo, n, h, wo_h, wo_l);
+  f32x4 bd4[4], bp4[4], lw4[4], lb4[4], bo4[4];
+  chan4(bd, h, bd4); chan4(bp, h, bp4); chan4(lnw, h, lw4); chan4(lnb, h, lb4);
+  if constexpr (LAST) chan4(bo, h, bo4);
+
+  bool bad = false;
+  for (int it = 0; it < tiles_per_wave; ++it) {
+    const int r = (wave * tiles_per_wave + it) * 32 + n;
+    if (r - n >= rows) break;
+    const bool live = r < rows;
+    const int t = live ? r % T0 : 0;
+    // ---- relu(dilated k3): the three taps of the row, zero outside the sequence
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    f32x4 xin[3][2][2];
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) {
+      const int tt = t + (tap - 1) * dil;
+      const bool ok = live && tt >= 0 && tt < T0;
+      const float* src = X + (int64_t)(ok ? r + (tap - 1) * dil : 0) * TCN_HID + 8 * h;
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(src + 16 * cc + 4 * u);
+          xin[tap][cc][u] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    f32x4 res[4];                                        // residual = the row itself, in accumulator channel order
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(X + (int64_t)(live ? r : 0) * TCN_HID + 8 * q + 4 * h);
+      res[q] = live ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float m = (live && mask[live ? r : 0]) ? 1.f : 0.f;
+#pragma unroll
+    for (int kc = 0; kc < 6; ++kc) {
+      const f32x4 a = xin[kc >> 1][kc & 1][0], b = xin[kc >> 1][kc & 1][1];
+      const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      h16x8 xh, xl;
+      split8(x, TCN_SA, xh, xl);
+      acc = mma3(wd_h[kc], wd_l[kc], xh, xl, acc);
+    }
+    float hid[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float v = acc[e] * TCN_UNSCALE + bd4[e >> 2][e & 3];
+      bad |= !(__builtin_fabsf(v) <= 3.4028234664e38f);
+      hid[e] = fmaxf(v, 0.f);
+    }
+    // ---- 1x1 conv, residual, mask
+    f32x16 acc2;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float x[8] = {hid[8 * c], hid[8 * c + 1], hid[8 * c + 2], hid[8 * c + 3], hid[8 * c + 4], hid[8 * c + 5], hid[8 * c + 6], hid[8 * c + 7]};
+      h16x8 xh, xl;
+      split8(x, TCN_SA, xh, xl);
+      acc2 = mma3(wp_h[c], wp_l[c], xh, xl, acc2);
+    }
+    float o[16], sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float v = acc2[e] * TCN_UNSCALE + bp4[e >> 2][e & 3];
+      bad |= !(__builtin_fabsf(v) <= 3.4028234664e38f);
+      o[e] = (res[e >> 2][e & 3] + v) * m;
+      sum += o[e];
+    }
+    // ---- LayerNorm over the 32 channels of the row (lanes n and n + 32)
+    const float mean = xor32_sum(sum) * (1.0f / TCN_HID);
+    float sq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { const float d = o[e] - mean; sq += d * d; }
+    const float rs = 1.0f / sqrtf(xor32_sum(sq) * (1.0f / TCN_HID) + 1e-5f);
+    float y[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) y[e] = (o[e] - mean) * rs * lw4[e >> 2][e & 3] + lb4[e >> 2][e & 3];
+    if constexpr (!LAST) {
+      if (live) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4*>(Y + (int64_t)r * TCN_HID + 8 * q + 4 * h) = f32x4{y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]};
+      }
+    } else {
+      // ---- refine.conv_out (1x1) * mask -> columns [E, E + 32) of the pyramid row
+      f32x16 acc3;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc3[e] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float x[8] = {y[8 * c], y[8 * c + 1], y[8 * c + 2], y[8 * c + 3], y[8 * c + 4], y[8 * c + 5], y[8 * c + 6], y[8 * c + 7]};
+        h16x8 xh, xl;
+        split8(x, TCN_SA, xh, xl);
+        acc3 = mma3(wo_h[c], wo_l[c], xh, xl, acc3);
+      }
+      if (live) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float u = acc3[4 * q + j] * TCN_UNSCALE + bo4[q][j];
+            bad |= !(__builtin_fabsf(u) <= 3.4028234664e38f);
+            v[j] = u * m;
+          }
+          *reinterpret_cast<f32x4*>(F + (int64_t)r * ldf + E + 8 * q + 4 * h) = v;
+        }
+      }
+    }
+  }
+  if (bad && status) atomicOr(status, 1u);
+}
+
+// |w| * 2^8 must stay inside fp16 for the kernel above: raises *flag otherwise (checked once per model, like the GEMM weights)
+__global__ void k_f16_weight_range(const float* __restrict__ w, int n, unsigned* __restrict__ flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && !(__builtin_fabsf(w[i]) * TCN_SW <= 65504.f)) atomicOr(flag, 1u);
+}
+int launch_f16_weight_range(const float* w, int n, unsigned* flag, hipStream_t st) {
+  if (n <= 0 || !flag) return 0;
+  hipLaunchKernelGGL(k_f16_weight_range, dim3((n + 255) / 256), dim3(256), 0, st, w, n, flag);
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
 // conv_out (1x1, 32->32) * mask, written into columns [E, E+32) of the level-0 pyramid rows
 __global__ __launch_bounds__(64) void k_refine_out(const float* __restrict__ X, const float* __restrict__ w,
                                                     const float* __restrict__ b, const uint8_t* __restrict__ mask,
@@ -353,13 +548,33 @@ int launch_refine(const RefineArgs& a, const LevelTable& lt, hipStream_t st) {
   hipLaunchKernelGGL(k_refine_in, g64, b64, 0, st, a);
   float* cur = a.bufA;
   float* nxt = a.bufB;
+  // f16x3 mode: the layers run on the matrix cores, the last one carries conv_out
+  const int tiles = (rows0 + 31) / 32;
+  const int tpw = 1;                                     // 32-row tiles per wave (measured at 81 920 rows: 1 -> 0.180 ms for the branch, 2 -> 0.189,
+                                                         // 4 -> 0.193, 8 -> 0.302: a tile is one dependent load -> split -> MFMA chain, more waves hide it best)
+  const dim3 gm((((tiles + tpw - 1) / tpw) + 3) / 4);
+  bool out_done = false;
   for (int i = 0; i < a.n_layers; ++i) {
     DCF_CHECK(a.host_w_dil && a.host_w_dil[i], "refine: missing TCN layer %d", i);
-    hipLaunchKernelGGL(k_tcn_layer, g64, dim3(256), 0, st, (const float*)cur, nxt, a.host_w_dil[i], a.host_b_dil[i], a.host_w_pw[i],
-                       a.host_b_pw[i], a.host_ln_w[i], a.host_ln_b[i], a.mask_all, a.B, a.T0, 1 << i);
+    if (a.f16) {
+      if (i + 1 < a.n_layers) {
+        hipLaunchKernelGGL(k_tcn_layer_mfma<false>, gm, dim3(256), 0, st, (const float*)cur, nxt, a.host_w_dil[i], a.host_b_dil[i],
+                           a.host_w_pw[i], a.host_b_pw[i], a.host_ln_w[i], a.host_ln_b[i], a.mask_all, a.B, a.T0, 1 << i, tpw,
+                           (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (int64_t)0, 0, a.status);
+      } else {
+        hipLaunchKernelGGL(k_tcn_layer_mfma<true>, gm, dim3(256), 0, st, (const float*)cur, nxt, a.host_w_dil[i], a.host_b_dil[i],
+                           a.host_w_pw[i], a.host_b_pw[i], a.host_ln_w[i], a.host_ln_b[i], a.mask_all, a.B, a.T0, 1 << i, tpw,
+                           a.w_out, a.b_out, a.F, a.ldf, a.E, a.status);
+        out_done = true;
+      }
+    } else {
+      hipLaunchKernelGGL(k_tcn_layer, g64, dim3(256), 0, st, (const float*)cur, nxt, a.host_w_dil[i], a.host_b_dil[i], a.host_w_pw[i],
+                         a.host_b_pw[i], a.host_ln_w[i], a.host_ln_b[i], a.mask_all, a.B, a.T0, 1 << i);
+    }
     float* t = cur; cur = nxt; nxt = t;
   }
-  hipLaunchKernelGGL(k_refine_out, g64, b64, 0, st, (const float*)cur, a.w_out, a.b_out, a.mask_all, a.F, a.ldf, a.E, rows0);
+  if (!out_done)
+    hipLaunchKernelGGL(k_refine_out, g64, b64, 0, st, (const float*)cur, a.w_out, a.b_out, a.mask_all, a.F, a.ldf, a.E, rows0);
   if (a.n_levels > 1 && !a.stacked) {
     const int W = 1 << (a.n_levels - 1);
     const size_t lds = (size_t)2 * (2 * W - 1) * TCN_HID * sizeof(float);
