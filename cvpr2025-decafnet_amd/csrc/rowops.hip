@@ -99,28 +99,43 @@ __global__ __launch_bounds__(256) void k_vidmap_combine(const float* __restrict_
 // ------------------------------------------------------------------------------------------
 // generic LayerNorm row kernel:  Y = [relu] LN(X) [+ pe[t] * mask]
 // ------------------------------------------------------------------------------------------
+// A wave takes LN_ROWS rows and requests all of them (and the affine parameters) before the first reduction: with one
+// row per wave the kernel held 1 KiB per wave in flight and ran at 4.3 TB/s.
+constexpr int LN_ROWS = 4;
 template <int NCH>
 __global__ __launch_bounds__(256) void k_ln(LnArgs p) {
   const int lane = threadIdx.x & 63;
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= p.rows) return;
-  Row<NCH> x;
-  x.load(p.X + (int64_t)r * p.ldx, p.C, lane);
-  if (!p.skip_ln) row_layernorm(x, p.C, lane, p.w, p.b);
-  const bool relu = p.relu;
-  const float* pe = nullptr;
-  if (p.pe && p.mask[r]) pe = p.pe + (int64_t)(r % p.T) * p.C;
+  const int r0 = (blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * LN_ROWS;
+  if (r0 >= p.rows) return;
+  Row<NCH> x[LN_ROWS];
 #pragma unroll
-  for (int j = 0; j < NCH; ++j) {
-    int c = 256 * j + 4 * lane;
-    if (c < p.C) {
-      f32x4 v = x.v[j];
-      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      if (pe) v += *reinterpret_cast<const f32x4*>(pe + c);
-      x.v[j] = v;
-    }
+  for (int u = 0; u < LN_ROWS; ++u) {
+    const int r = r0 + u < p.rows ? r0 + u : p.rows - 1;
+    x[u].load(p.X + (int64_t)r * p.ldx, p.C, lane);
   }
-  x.store(p.Y + (int64_t)r * p.ldy, p.C, lane);
+  RowParam<NCH> w, b;
+  w.init(p.skip_ln ? nullptr : p.w, p.C, lane);
+  b.init(p.skip_ln ? nullptr : p.b, p.C, lane);
+  const bool relu = p.relu;
+#pragma unroll
+  for (int u = 0; u < LN_ROWS; ++u) {
+    const int r = r0 + u;
+    if (r >= p.rows) break;
+    if (!p.skip_ln) row_layernorm(x[u], p.C, lane, w, b);
+    const float* pe = nullptr;
+    if (p.pe && p.mask[r]) pe = p.pe + (int64_t)(r % p.T) * p.C;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      int c = 256 * j + 4 * lane;
+      if (c < p.C) {
+        f32x4 v = x[u].v[j];
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (pe) v += *reinterpret_cast<const f32x4*>(pe + c);
+        x[u].v[j] = v;
+      }
+    }
+    x[u].store(p.Y + (int64_t)r * p.ldy, p.C, lane);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -525,7 +540,7 @@ int launch_ln(const LnArgs& a, hipStream_t st) {
   DCF_CHECK(a.ldx % 4 == 0 && a.ldy % 4 == 0, "launch_ln: row pitch must be a multiple of 4");
   DCF_CHECK(!a.pe || (a.mask && a.T > 0), "launch_ln: pe needs mask and T");
   ProfScope prof("layernorm", st, 8.0 * a.rows * a.C, 4.0 * a.rows * a.C * (a.pe ? 3.0 : 2.0));
-  DISPATCH_NCH(a.C, hipLaunchKernelGGL((k_ln<NCH>), dim3((a.rows + 3) / 4), dim3(256), 0, st, a));
+  DISPATCH_NCH(a.C, hipLaunchKernelGGL((k_ln<NCH>), dim3((a.rows + 4 * LN_ROWS - 1) / (4 * LN_ROWS)), dim3(256), 0, st, a));
   return 0;
 }
 
