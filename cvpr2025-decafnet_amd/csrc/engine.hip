@@ -908,15 +908,24 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
     sa.nvid = nvid; sa.tn = b.tn; sa.partial = b.partial; sa.correl = b.correl; sa.D = D; sa.T = T0; sa.NQ = nq; sa.norm = c.norm;
     TRY(launch_sidekick(sa, st));
   }
-  for (int v = 0; v < nvid; ++v) {
-    // deep and shallow halves of vid_map share one grid (same shape, blockIdx.z selects the operand set)
-    GemmArgs g[2];
+  {
+    // the deep and shallow halves of vid_map of every video have the same shape: three of them share a grid (blockIdx.z
+    // selects the operand set), so five videos are four full launches instead of five two-thirds-full ones
+    GemmArgs g[3];
     int ng = 0;
-    if (m->vid_w1) g[ng++] = gemm(vs.vid[v], T0, m->vid_w1, nullptr, b.P1 + (size_t)v * T0 * E, E, T0, E, D);
-    if (m->vid_w2) g[ng++] = gemm(vs.shallow[v], T0, m->vid_w2, nullptr, b.P2 + (size_t)v * T0 * E, E, T0, E, D);
-    for (int i = 0; i < ng; ++i) { g[i].ldw = m->vid_ldw; g[i].a_scale = 1.f; }
-    TRY(run_gemm(m, g, ng, A_CHANMAJOR, st));
-    if (nvid > 1) DCF_HIP(hipMemcpyAsync(b.maskv + (size_t)v * T0, vs.mask[v], (size_t)T0, hipMemcpyDeviceToDevice, st));
+    auto flush = [&]() -> int {
+      if (ng == 0) return 0;
+      for (int i = 0; i < ng; ++i) { g[i].ldw = m->vid_ldw; g[i].a_scale = 1.f; }
+      const int rc = run_gemm(m, g, ng, A_CHANMAJOR, st);
+      ng = 0;
+      return rc;
+    };
+    for (int v = 0; v < nvid; ++v) {
+      if (m->vid_w1) { g[ng++] = gemm(vs.vid[v], T0, m->vid_w1, nullptr, b.P1 + (size_t)v * T0 * E, E, T0, E, D); if (ng == 3) TRY(flush()); }
+      if (m->vid_w2) { g[ng++] = gemm(vs.shallow[v], T0, m->vid_w2, nullptr, b.P2 + (size_t)v * T0 * E, E, T0, E, D); if (ng == 3) TRY(flush()); }
+      if (nvid > 1) DCF_HIP(hipMemcpyAsync(b.maskv + (size_t)v * T0, vs.mask[v], (size_t)T0, hipMemcpyDeviceToDevice, st));
+    }
+    TRY(flush());
   }
   if (nvid > 1) vid_mask = b.maskv;
 
