@@ -304,50 +304,96 @@ __global__ __launch_bounds__(256) void k_xattn_mfma(XAttnArgs p) {
 
 // ------------------------------------------------------------------------------------------
 // sliding-window self attention.  One wave per query row, 8 waves per SIMD.  Measured alternatives (level 0, 26 us):
-// all K/V rows of the window requested up front (4 waves/SIMD) 0.107 -> 0.120 ms per step; next key prefetched in the
-// loop 0.113; K/V of a 16-row strip staged once through LDS (3 workgroups per CU) 0.157.
+// all K/V rows of the window requested up front (4 waves/SIMD) 0.107 -> 0.120 ms per step; K/V of a 16-row strip staged
+// once through LDS (3 workgroups per CU) 0.157; a strip of queries per wave with the window in a register ring 0.275 ->
+// 0.314 ms per five-video forward (profiles/r02_gemm_operand_stream.md).
 // ------------------------------------------------------------------------------------------
-template <int NCH, int LPH>
-__global__ __launch_bounds__(256) void k_local_attn(LocalAttnArgs p) {
+constexpr int LA_QPW = 2;      // (four rows per wave at 6 waves per SIMD: 0.251 ms per five-video forward against 0.231; one row: 0.256)
+// WMAX > 0: windows of at most WMAX keys.  A wave takes LA_QPW = two consecutive query rows: their windows overlap in all but one key,
+// so the 2 * (WMAX + 1) K / V row loads serve both (10 KiB instead of 18 KiB per query through the vector-memory path at
+// w = 9, which is what bounds this kernel).  The key loop is fully unrolled (no loop-carried registers: the rows of the
+// next keys stay in flight across the score -> exp -> accumulate chain of the current one with counted waits) and capped at
+// 64 registers = 8 waves per SIMD so that the scheduler cannot hoist the whole window's loads.
+// WMAX = 0: any window, one query per wave, one round trip per key.
+template <int NCH, int LPH, bool FULL, int WMAX>
+__global__ __launch_bounds__(256, WMAX > 0 && NCH == 1 ? 8 : 4) void k_local_attn(LocalAttnArgs p) {
+  constexpr int QPW = WMAX > 0 ? LA_QPW : 1;           // query rows per wave
   const int lane = threadIdx.x & 63;
-  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= (int64_t)p.B * p.T) return;
-  const int C = p.C;
-  const int t = (int)(r % p.T);
-  const int64_t base = r - t;
+  const int wps = (p.T + QPW - 1) / QPW;               // waves per sequence
+  const int64_t w = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the key loop is uniform
+  if (w >= (int64_t)p.B * wps) return;
+  const int C = FULL ? 256 * NCH : p.C;                 // FULL: every lane chunk exists, no per-lane channel predicate
+  const int t = (int)(w % wps) * QPW;
+  const int64_t base = (w / wps) * p.T, r = base + t;
   const int half = p.window / 2;
   const float scale = 1.0f / sqrtf(sqrtf((float)(C / p.heads)));
-  Row<NCH> q;
-  if (!p.mask[r]) {                                    // padded query rows are forced to 0 (blocks.py:293)
-    q.zero();
-    q.store(p.O + r * C, C, lane);
-    return;
-  }
-  q.load(p.Q + r * C, C, lane);
-  f32x4 acc[NCH];
-  float m[NCH], l[NCH];
+  // query z of the wave is row t + z (T may be odd: the second one may not exist); out-of-range keys are -inf (blocks.py:260-261)
+  const int nq = min(QPW, p.T - t);
+  const int lo = max(t - half, 0), hi = min(t + (nq - 1) + half, p.T - 1);
+  // validity of the window's keys: one mask byte per lane (lane l <-> key lo + l), one ballot
+  unsigned long long km = 0ull;
+  if constexpr (WMAX > 0) km = __ballot(lane <= hi - lo && p.mask[base + lo + lane] != 0);
+  bool live[QPW];
 #pragma unroll
-  for (int j = 0; j < NCH; ++j) { q.v[j] *= scale; acc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; m[j] = -INFINITY; l[j] = 0.f; }
-  const int lo = max(t - half, 0), hi = min(t + half, p.T - 1);   // out-of-range keys are -inf (blocks.py:260-261)
-  for (int u = lo; u <= hi; ++u) {
-    const float pen = p.mask[base + u] ? 0.f : -1e4f;  // padded keys get a finite -1e4 (blocks.py:279)
-    Row<NCH> k, v;
+  for (int z = 0; z < QPW; ++z) live[z] = z < nq && p.mask[r + (z < nq ? z : 0)] != 0;   // padded query rows are forced to 0 (blocks.py:293)
+  auto fetch = [&](int u, Row<NCH>& k, Row<NCH>& v) __attribute__((always_inline)) {
     k.load(p.K + (base + u) * C, C, lane);
     v.load(p.V + (base + u) * C, C, lane);
+  };
+  Row<NCH> kb[2], vb[2];
+  if constexpr (WMAX > 0) {
+    fetch(lo, kb[0], vb[0]);
+    fetch(lo + 1 <= hi ? lo + 1 : hi, kb[1], vb[1]);
+  }
+  Row<NCH> q[QPW];
+  f32x4 acc[QPW][NCH];
+  float m[QPW][NCH], l[QPW][NCH];
+#pragma unroll
+  for (int z = 0; z < QPW; ++z) {
+    q[z].load(p.Q + (r + (z < nq ? z : 0)) * C, C, lane);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) { q[z].v[j] *= scale; acc[z][j] = f32x4{0.f, 0.f, 0.f, 0.f}; m[z][j] = -INFINITY; l[z][j] = 0.f; }
+  }
+  auto key = [&](int z, bool valid, const Row<NCH>& k, const Row<NCH>& v) __attribute__((always_inline)) {
+    const float pen = valid ? 0.f : -1e4f;             // padded keys get a finite -1e4 (blocks.py:279)
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
-      float s = head_sum<LPH>(dot4(q.v[j], k.v[j] * scale)) + pen;
-      float mn = fmaxf(m[j], s);
-      float corr = fast_exp(m[j] - mn);                // exp(-inf) = 0 on the first key; v_exp_f32 instead of ~12-instruction expf
+      float s = head_sum<LPH>(dot4(q[z].v[j], k.v[j] * scale)) + pen;
+      float mn = fmaxf(m[z][j], s);
+      float corr = fast_exp(m[z][j] - mn);             // exp(-inf) = 0 on the first key; v_exp_f32 instead of ~12-instruction expf
       float e = fast_exp(s - mn);
-      acc[j] = acc[j] * corr + e * v.v[j];
-      l[j] = l[j] * corr + e;
-      m[j] = mn;
+      acc[z][j] = acc[z][j] * corr + e * v.v[j];
+      l[z][j] = l[z][j] * corr + e;
+      m[z][j] = mn;
+    }
+  };
+  if constexpr (WMAX > 0) {
+#pragma unroll
+    for (int i = 0; i < WMAX + QPW - 1; ++i) {
+      const int u = lo + i;
+      if (u > hi) break;
+      const bool valid = ((km >> i) & 1ull) != 0;
+#pragma unroll
+      for (int z = 0; z < QPW; ++z)
+        if (live[z] && u >= t + z - half && u <= t + z + half) key(z, valid, kb[i & 1], vb[i & 1]);
+      if (i + 2 < WMAX + QPW - 1 && u + 2 <= hi) fetch(u + 2, kb[i & 1], vb[i & 1]);   // this register set is free again
+    }
+  } else {
+    if (live[0]) {
+      for (int u = lo; u <= hi; ++u) {
+        fetch(u, kb[0], vb[0]);
+        key(0, p.mask[base + u] != 0, kb[0], vb[0]);
+      }
     }
   }
 #pragma unroll
-  for (int j = 0; j < NCH; ++j) q.v[j] = acc[j] / l[j];
-  q.store(p.O + r * C, C, lane);
+  for (int z = 0; z < QPW; ++z) {
+    if (z >= nq) break;
+    Row<NCH> o;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) o.v[j] = live[z] ? acc[z][j] / l[z][j] : f32x4{0.f, 0.f, 0.f, 0.f};
+    o.store(p.O + (r + z) * C, C, lane);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -388,8 +434,13 @@ __global__ __launch_bounds__(256) void k_local_attn(LocalAttnArgs p) {
 
 #define XATTN_LAUNCH(NCH_, LPH_, grid, lds, st, a) \
   hipLaunchKernelGGL((k_xattn_valu<NCH_, LPH_>), grid, dim3(256), lds, st, a)
-#define LOCAL_LAUNCH(NCH_, LPH_, grid, st, a) \
-  hipLaunchKernelGGL((k_local_attn<NCH_, LPH_>), grid, dim3(256), 0, st, a)
+#define LOCAL_LAUNCH_W(NCH_, LPH_, W_, grid, st, a) do { \
+    if ((a).C % 256 == 0) hipLaunchKernelGGL((k_local_attn<NCH_, LPH_, true, W_>), grid, dim3(256), 0, st, a); \
+    else hipLaunchKernelGGL((k_local_attn<NCH_, LPH_, false, W_>), grid, dim3(256), 0, st, a); } while (0)
+#define LOCAL_LAUNCH(NCH_, LPH_, grid, st, a) do { \
+    if ((a).window <= 9) LOCAL_LAUNCH_W(NCH_, LPH_, 9, grid, st, a); \
+    else if ((a).window <= 19) LOCAL_LAUNCH_W(NCH_, LPH_, 19, grid, st, a); \
+    else LOCAL_LAUNCH_W(NCH_, LPH_, 0, grid, st, a); } while (0)
 
 template <int D16>
 static int launch_xattn_mfma(const XAttnArgs& a, hipStream_t st) {
@@ -460,7 +511,8 @@ int launch_local_attn(const LocalAttnArgs& a, hipStream_t st) {
   int64_t rows = (int64_t)a.B * a.T;
   if (rows <= 0) return 0;
   DCF_CHECK(a.window >= 1 && (a.window & 1), "local_attn: window must be odd");
-  dim3 grid((unsigned)((rows + 3) / 4));
+  const int qpw = a.window <= 19 ? LA_QPW : 1;         // query rows per wave (k_local_attn)
+  dim3 grid((unsigned)(((int64_t)a.B * ((a.T + qpw - 1) / qpw) + 3) / 4));
   ProfScope prof("local_attn", st, 4.0 * rows * a.C * a.window, 4.0 * 4.0 * rows * a.C);
   DISPATCH_ATTN(LOCAL_LAUNCH, a.C, a.heads, grid, st, a);
   return 0;

@@ -217,7 +217,11 @@ def test_xattn_core(L, B, T, Lk, C, heads):
 
 
 @pytest.mark.parametrize('B,T,C,heads,w', [(2, 72, 32, 4, 9), (1, 256, 256, 4, 9), (2, 64, 128, 4, 5), (1, 90, 64, 2, 19),
-                                            (1, 8, 256, 4, 9), (1, 4, 128, 4, 5)])
+                                            (1, 8, 256, 4, 9), (1, 4, 128, 4, 5),
+                                            # odd lengths (the second row of a wave's pair does not exist at the end of a sequence),
+                                            # one-row sequences, a window wider than the unrolled variants, four chunks per row
+                                            (3, 7, 256, 4, 9), (2, 1, 256, 4, 9), (2, 33, 64, 2, 19), (1, 150, 256, 4, 71),
+                                            (2, 45, 1024, 16, 9)])
 def test_local_attn_core(L, B, T, C, heads, w):
     pkg, lib = L
     g = torch.Generator().manual_seed(T * 3 + C)
