@@ -46,6 +46,21 @@ __device__ __forceinline__ int block_exscan(int v, int* s_wave /* [NW+1] */, int
   return s_wave[w] + inc - v;
 }
 
+// the same for a 0/1 flag per thread: ballot + population counts, no cross-lane shuffles, every thread adds up the wave totals
+__device__ __forceinline__ int block_excount(bool f, int* s_wave /* [NW+1] */, int& total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned long long m = __ballot(f);
+  const int within = __popcll(m & ((1ull << lane) - 1ull));
+  __syncthreads();                                  // the previous use of s_wave has been read
+  if (lane == 0) s_wave[w] = __popcll(m);
+  __syncthreads();
+  int before = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) { const int t = s_wave[i]; tot += t; before += i < w ? t : 0; }
+  total = tot;
+  return before + within;
+}
+
 // in-LDS bitonic sort, descending, of n_pad (power of two) 64-bit keys
 __device__ __forceinline__ void bitonic_desc(unsigned long long* key, int n_pad) {
   for (int k = 2; k <= n_pad; k <<= 1) {
@@ -77,6 +92,10 @@ constexpr int CAND_CAP = 4096;    // >= pre_nms_topk
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// CACHE: S <= KPT * NT points: a thread keeps its KPT keys (points tid, tid + NT, ...) in registers for the three selection
+// passes and the compaction instead of re-reading them from global memory four times
+constexpr int KPT = 32;
+template <bool CACHE>
 __global__ __launch_bounds__(NT) void k_collect(CollectArgs p) {
   __shared__ unsigned long long key[CAND_CAP];
   __shared__ int hist[2048];
@@ -96,7 +115,10 @@ __global__ __launch_bounds__(NT) void k_collect(CollectArgs p) {
   // [j 2^l - (2^l - 1), j 2^l + (2^l - 1)] clipped to the video: read straight from the level-0 row, no pyramid buffer.
   const float* ext = p.ext ? p.ext + (size_t)q * p.T : nullptr;
   int cnt = 0;
-  for (int i = tid; i < S; i += NT) {
+  uint32_t kreg[CACHE ? KPT : 1];
+#pragma unroll
+  for (int c = 0; c < (CACHE ? KPT : 1); ++c) kreg[c] = 0u;
+  auto score = [&](int i) __attribute__((always_inline)) -> uint32_t {
     float s = sigmoidf_(logits[i]);
     if (ext) {
       int l = 0;
@@ -108,9 +130,20 @@ __global__ __launch_bounds__(NT) void k_collect(CollectArgs p) {
       s *= e;
     }
     s *= (mask[i] ? 1.f : 0.f);
-    uint32_t k = (s > p.pre_nms_thresh) ? __float_as_uint(s) : 0u;   // positive floats order as uints
-    skey[i] = k;
-    cnt += k != 0;
+    return (s > p.pre_nms_thresh) ? __float_as_uint(s) : 0u;   // positive floats order as uints
+  };
+  if constexpr (CACHE) {
+#pragma unroll
+    for (int c = 0; c < KPT; ++c) {
+      const int i = c * NT + tid;
+      if (i < S) { kreg[c] = score(i); cnt += kreg[c] != 0; }
+    }
+  } else {
+    for (int i = tid; i < S; i += NT) {
+      const uint32_t k = score(i);
+      skey[i] = k;
+      cnt += k != 0;
+    }
   }
   int n_cand;
   block_exscan(cnt, s_wave, n_cand);
@@ -126,16 +159,30 @@ __global__ __launch_bounds__(NT) void k_collect(CollectArgs p) {
       const int nb = 1 << bits[pass];
       for (int i = tid; i < nb; i += NT) hist[i] = 0;
       __syncthreads();
-      for (int i = tid; i < S; i += NT) {
-        uint32_t k = skey[i];
-        if (k && (k & pmask) == prefix) atomicAdd(&hist[(k >> shifts[pass]) & (nb - 1)], 1);
+      if constexpr (CACHE) {
+#pragma unroll
+        for (int c = 0; c < KPT; ++c) {
+          const uint32_t k = kreg[c];
+          if (k && (k & pmask) == prefix) atomicAdd(&hist[(k >> shifts[pass]) & (nb - 1)], 1);
+        }
+      } else {
+        for (int i = tid; i < S; i += NT) {
+          uint32_t k = skey[i];
+          if (k && (k & pmask) == prefix) atomicAdd(&hist[(k >> shifts[pass]) & (nb - 1)], 1);
+        }
       }
       __syncthreads();
-      if (tid == 0) {
-        int acc = 0, b = nb - 1;
-        for (; b > 0; --b) { if (acc + hist[b] >= need) break; acc += hist[b]; }
-        s_prefix = prefix | ((uint32_t)b << shifts[pass]);
-        s_need = need - acc;
+      // the bucket holding the need-th largest key: the highest b with sum_{j >= b} hist[j] >= need.  Thread t owns buckets
+      // 2t, 2t + 1 (the serial walk down the 2048 buckets by one thread was 60 us per pass)
+      {
+        const int b1 = 2 * tid + 1, b0 = 2 * tid;
+        const int h1 = b1 < nb ? hist[b1] : 0, h0 = b0 < nb ? hist[b0] : 0;
+        int tot;
+        const int below = block_exscan(h0 + h1, s_wave, tot);        // keys in buckets < 2t
+        const int above1 = tot - below - h0 - h1;                    // keys in buckets > 2t + 1
+        const int above0 = above1 + h1;
+        if (b1 < nb && above1 < need && above1 + h1 >= need) { s_prefix = prefix | ((uint32_t)b1 << shifts[pass]); s_need = need - above1; }
+        if (b0 < nb && above0 < need && above0 + h0 >= need) { s_prefix = prefix | ((uint32_t)b0 << shifts[pass]); s_need = need - above0; }
       }
       __syncthreads();
       prefix = s_prefix;
@@ -149,17 +196,26 @@ __global__ __launch_bounds__(NT) void k_collect(CollectArgs p) {
   // (3) ordered compaction of {key > kth} (there are K - need of them) plus the first `need` {key == kth}
   const int n_greater = K - need;
   int run_g = 0, run_e = 0;
-  for (int c0 = 0; c0 < S && K > 0; c0 += NT) {
-    const int i = c0 + tid;
-    const uint32_t k = i < S ? skey[i] : 0u;
+  auto place = [&](int i, uint32_t k) __attribute__((always_inline)) {
     const int g = k > kth, e = (k == kth && k != 0);
     int tg, te;
-    const int pg = block_exscan(g, s_wave, tg);
-    const int pe = block_exscan(e, s_wave, te);
+    const int pg = block_excount(g != 0, s_wave, tg);
+    const int pe = block_excount(e != 0, s_wave, te);
     if (g) key[run_g + pg] = ((unsigned long long)k << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i);
     if (e && run_e + pe < need) key[n_greater + run_e + pe] = ((unsigned long long)k << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i);
     run_g += tg;
     run_e += te;
+  };
+  if (K > 0) {
+    if constexpr (CACHE) {
+#pragma unroll
+      for (int c = 0; c < KPT; ++c) {
+        if (c * NT >= S) break;
+        place(c * NT + tid, kreg[c]);
+      }
+    } else {
+      for (int c0 = 0; c0 < S; c0 += NT) place(c0 + tid, c0 + tid < S ? skey[c0 + tid] : 0u);
+    }
   }
   __syncthreads();
   const int n_pad = next_pow2(max(K, 1));
@@ -188,7 +244,7 @@ __global__ __launch_bounds__(NT) void k_collect(CollectArgs p) {
       keep = (right - left) > p.seg_len_thresh;
     }
     int tot;
-    const int pos = block_exscan(keep, s_wave, tot);
+    const int pos = block_excount(keep != 0, s_wave, tot);
     if (keep) {
       out_segs[2 * (run + pos)] = left;
       out_segs[2 * (run + pos) + 1] = right;
@@ -204,7 +260,8 @@ int launch_collect(const CollectArgs& a, int nq, hipStream_t st) {
   DCF_CHECK(a.pre_nms_topk >= 1 && a.pre_nms_topk <= CAND_CAP, "collect: pre_nms_topk=%d exceeds %d", a.pre_nms_topk, CAND_CAP);
   DCF_CHECK(a.n_levels >= 1 && a.n_levels <= 16, "collect: bad n_levels");
   ProfScope prof("collect_segments", st, 0.0, 4.0 * 4.0 * nq * a.S);
-  hipLaunchKernelGGL(k_collect, dim3(nq), dim3(NT), 0, st, a);
+  if (a.S <= KPT * NT) hipLaunchKernelGGL(k_collect<true>, dim3(nq), dim3(NT), 0, st, a);
+  else hipLaunchKernelGGL(k_collect<false>, dim3(nq), dim3(NT), 0, st, a);
   DCF_HIP(hipGetLastError());
   return 0;
 }
