@@ -1437,10 +1437,10 @@ int dcf_collect_segments_ext(const float* logits, const float* offsets, const ui
   a.pre_nms_thresh = pre_nms_thresh; a.seg_len_thresh = seg_len_thresh; a.pre_nms_topk = pre_nms_topk;
   a.segs = segs_out; a.scores = scores_out; a.counts = counts_out;
   uint32_t* keys = nullptr;
-  DCF_HIP(hipMallocAsync((void**)&keys, (size_t)nq * acc * sizeof(uint32_t), (hipStream_t)stream));
+  if (dcf::collect_needs_scratch(acc)) DCF_HIP(hipMallocAsync((void**)&keys, (size_t)nq * acc * sizeof(uint32_t), (hipStream_t)stream));
   a.keys = keys;
   int rc = dcf::launch_collect(a, nq, (hipStream_t)stream);
-  DCF_HIP(hipFreeAsync(keys, (hipStream_t)stream));
+  if (keys) DCF_HIP(hipFreeAsync(keys, (hipStream_t)stream));
   return rc;
 }
 

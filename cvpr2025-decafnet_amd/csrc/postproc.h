@@ -21,6 +21,8 @@ struct CollectArgs {
   float* scores;            // [nq][pre_nms_topk]    out
   int* counts;              // [nq] out
 };
+// does launch_collect need the CollectArgs::keys scratch (nq * S words) for S points per query?  (no: the keys stay in registers)
+bool collect_needs_scratch(int S);
 int launch_collect(const CollectArgs& a, int nq, hipStream_t st);
 
 struct NmsArgs {

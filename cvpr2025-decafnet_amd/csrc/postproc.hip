@@ -10,6 +10,7 @@
 // reference's O(n^2) scalar loops by n short parallel steps.  Index-producing arithmetic (IoU,
 // thresholds, decay) uses exactly the reference's fp32 operation order so that the returned int64
 // indices are bit-identical; ties in the sorts are broken by the lower original index.
+#include <type_traits>
 #include "common.h"
 #include "postproc.h"
 
@@ -24,26 +25,31 @@ __device__ __forceinline__ uint32_t fkey(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// exclusive prefix sum of one int per thread over the workgroup; also returns the total
+// exclusive prefix sum of one int per thread over the workgroup; also returns the total.  Inside a wave: six DPP adds
+// (row shifts 1, 2, 4, 8, then lane 15 / lane 31 broadcast into the following rows); across waves every thread adds up the
+// wave totals itself.  (The first version -- six ds_bpermute steps and thread 0 walking the 16 wave totals through LDS --
+// cost ~3 k cycles per call with 1023 threads waiting, ten calls per decoded video.)
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int dpp_zero_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
 __device__ __forceinline__ int block_exscan(int v, int* s_wave /* [NW+1] */, int& total) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   int inc = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    int n = __shfl_up(inc, off, 64);
-    if (lane >= off) inc += n;
-  }
-  __syncthreads();
+  inc += dpp_zero_i<0x111>(inc);                     // row_shr:1
+  inc += dpp_zero_i<0x112>(inc);                     // row_shr:2
+  inc += dpp_zero_i<0x114>(inc);                     // row_shr:4
+  inc += dpp_zero_i<0x118>(inc);                     // row_shr:8  -> inclusive within each 16-lane row
+  inc += dpp_zero_i<DPP_BCAST15, 0xA>(inc);          // rows 1, 3 += total of rows 0, 2
+  inc += dpp_zero_i<DPP_BCAST31, 0xC>(inc);          // rows 2, 3 += total of rows 0 + 1
+  __syncthreads();                                   // the previous use of s_wave has been read
   if (lane == 63) s_wave[w] = inc;
   __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    for (int i = 0; i < NW; ++i) { int t = s_wave[i]; s_wave[i] = acc; acc += t; }
-    s_wave[NW] = acc;
-  }
-  __syncthreads();
-  total = s_wave[NW];
-  return s_wave[w] + inc - v;
+  int before = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) { const int t = s_wave[i]; tot += t; before += i < w ? t : 0; }
+  total = tot;
+  return before + inc - v;
 }
 
 // the same for a 0/1 flag per thread: ballot + population counts, no cross-lane shuffles, every thread adds up the wave totals
@@ -61,20 +67,183 @@ __device__ __forceinline__ int block_excount(bool f, int* s_wave /* [NW+1] */, i
   return before + within;
 }
 
-// in-LDS bitonic sort, descending, of n_pad (power of two) 64-bit keys
-__device__ __forceinline__ void bitonic_desc(unsigned long long* key, int n_pad) {
-  for (int k = 2; k <= n_pad; k <<= 1) {
+// Bitonic sort, descending, of the n_pad (power of two, <= 4096) 64-bit keys in key[] (entries beyond the live ones hold 0).
+// The keys live in REGISTERS: wave w owns the block [w * EW, (w + 1) * EW), EW = 64 * EPL, lane l holds keys w * EW + 64 m + l.
+// A compare-exchange step with distance j is then
+//   j <  64 : an exchange between lanes l and l ^ j -- DPP quad permutes / row mirrors, v_permlane16/32_swap: VALU speed,
+//   j <  EW : between two registers of the same lane,
+//   j >= EW : between waves, through key[] and two workgroup barriers
+// -- 10 barrier steps out of 66 for 2048 keys.  (All steps through LDS with a barrier each took 30 us of the 112 us proposal
+// decoding of a 32 640-point video; wave-local steps through LDS without barriers were no faster: 39 us.)
+template <int J>
+__device__ __forceinline__ uint32_t xor_lane(uint32_t x) {
+  const int v = (int)x;
+  if constexpr (J == 1) return (uint32_t)__builtin_amdgcn_update_dpp(v, v, DPP_XOR1, 0xf, 0xf, false);
+  if constexpr (J == 2) return (uint32_t)__builtin_amdgcn_update_dpp(v, v, DPP_XOR2, 0xf, 0xf, false);
+  if constexpr (J == 4) {                               // l ^ 4 = reverse the quad of (reverse the half row)
+    const int t = __builtin_amdgcn_update_dpp(v, v, DPP_HALF_MIRROR, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(t, t, 0x1B, 0xf, 0xf, false);       // quad_perm [3,2,1,0]
+  }
+  if constexpr (J == 8) {                               // l ^ 8 = reverse the half row of (reverse the row)
+    const int t = __builtin_amdgcn_update_dpp(v, v, DPP_MIRROR, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(t, t, DPP_HALF_MIRROR, 0xf, 0xf, false);
+  }
+  if constexpr (J == 16) {
+    auto t = __builtin_amdgcn_permlane16_swap(x, x, false, false);   // {r0,r0,r2,r2} / {r1,r1,r3,r3}
+    return ((threadIdx.x >> 4) & 1) ? t[0] : t[1];
+  }
+  if constexpr (J == 32) {
+    auto t = __builtin_amdgcn_permlane32_swap(x, x, false, false);   // {lo,lo} / {hi,hi}
+    return ((threadIdx.x >> 5) & 1) ? t[0] : t[1];
+  }
+  return x;
+}
+template <int J>
+__device__ __forceinline__ unsigned long long xor_lane64(unsigned long long x) {
+  return ((unsigned long long)xor_lane<J>((uint32_t)(x >> 32)) << 32) | xor_lane<J>((uint32_t)x);
+}
+// element i keeps the larger of (its key, its partner's key) if it is the lower index of a descending pair or the higher
+// index of an ascending one
+__device__ __forceinline__ unsigned long long cmpx_keep(unsigned long long v, unsigned long long pv, int i, int j, int k) {
+  const bool take_max = ((i & j) == 0) == ((i & k) == 0);
+  const bool gt = v > pv;
+  return (take_max == gt) ? v : pv;
+}
+
+template <int EPL>
+__device__ __forceinline__ void bitonic_desc_regs(unsigned long long* key, int n_pad) {
+  constexpr int EW = 64 * EPL;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n_eff = n_pad < 64 ? 64 : n_pad;            // a single wave sorts 64 slots, the padding slots hold 0
+  const bool active = w * EW < n_eff;
+  unsigned long long v[EPL];
+  int idx[EPL];
+  __syncthreads();                                      // key[] is complete
+#pragma unroll
+  for (int m = 0; m < EPL; ++m) {
+    idx[m] = w * EW + m * 64 + lane;
+    v[m] = (active && idx[m] < n_pad) ? key[idx[m]] : 0ull;
+  }
+  for (int k = 2; k <= n_eff; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      __syncthreads();
-      for (int i = threadIdx.x; i < n_pad; i += NT) {
-        int ixj = i ^ j;
-        if (ixj > i) {
-          unsigned long long a = key[i], b = key[ixj];
-          bool desc = (i & k) == 0;
-          if (desc ? (a < b) : (a > b)) { key[i] = b; key[ixj] = a; }
+      if (j >= EW) {
+        __syncthreads();                                // the readers of the previous exchange are done
+        if (active) {
+#pragma unroll
+          for (int m = 0; m < EPL; ++m) key[idx[m]] = v[m];
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+          for (int m = 0; m < EPL; ++m) v[m] = cmpx_keep(v[m], key[idx[m] ^ j], idx[m], j, k);
+        }
+      } else if (j >= 64) {
+        if constexpr (EPL > 1) {
+          auto pair = [&](auto lo_c, auto hi_c) __attribute__((always_inline)) {   // register indices known at compile time
+            constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+            const unsigned long long a = v[LO], b = v[HI];
+            v[LO] = cmpx_keep(a, b, idx[LO], j, k);
+            v[HI] = cmpx_keep(b, a, idx[HI], j, k);
+          };
+          using std::integral_constant;
+          if (j == 64) {
+            pair(integral_constant<int, 0>{}, integral_constant<int, 1>{});
+            if constexpr (EPL == 4) pair(integral_constant<int, 2>{}, integral_constant<int, 3>{});
+          } else {                                      // j == 128, EPL == 4
+            if constexpr (EPL == 4) {
+              pair(integral_constant<int, 0>{}, integral_constant<int, 2>{});
+              pair(integral_constant<int, 1>{}, integral_constant<int, 3>{});
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < EPL; ++m) {
+          unsigned long long pv;
+          switch (j) {
+            case 1: pv = xor_lane64<1>(v[m]); break;
+            case 2: pv = xor_lane64<2>(v[m]); break;
+            case 4: pv = xor_lane64<4>(v[m]); break;
+            case 8: pv = xor_lane64<8>(v[m]); break;
+            case 16: pv = xor_lane64<16>(v[m]); break;
+            default: pv = xor_lane64<32>(v[m]); break;
+          }
+          v[m] = cmpx_keep(v[m], pv, idx[m], j, k);
         }
       }
     }
+  }
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int m = 0; m < EPL; ++m)
+      if (idx[m] < n_pad) key[idx[m]] = v[m];
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void bitonic_desc(unsigned long long* key, int n_pad) {
+  if (n_pad <= 64 * NW) bitonic_desc_regs<1>(key, n_pad);
+  else if (n_pad <= 128 * NW) bitonic_desc_regs<2>(key, n_pad);
+  else bitonic_desc_regs<4>(key, n_pad);
+}
+
+// Stable LSD radix sort of n <= RS_MAX 64-bit keys by their upper 32 bits, DESCENDING, in four 8-bit passes (a bitonic
+// network spends n log^2 n / 2 compare-exchanges: 64 k cycles for 2048 keys on one CU; this is ~10x less work).  Element
+// e = m * NT + tid (m < RS_M).  Per pass: the lanes of a wave that share a digit find each other with eight ballots
+// (rank = population count of the peers in lower lanes, the first peer records the group size in table[digit][m][wave]);
+// one workgroup scan of the table in (digit descending, m, wave) order turns the sizes into output offsets; scatter.
+// The input order is kept among equal digits, so keys that arrive in candidate-index order leave ordered by (score
+// descending, index ascending).  key / key2 ping-pong; the result is in key.
+constexpr int RS_M = 2;
+constexpr int RS_MAX = RS_M * NT;
+constexpr int RS_TABLE = 256 * RS_M * NW;              // 8192 counters
+
+__device__ __forceinline__ void radix_sort_desc(unsigned long long* key, unsigned long long* key2, int* table, int n, int* s_wave) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  constexpr int EPT = RS_TABLE / NT;                   // table entries per thread in the scan (8)
+  unsigned long long* src = key;
+  unsigned long long* dst = key2;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 32 + 8 * pass;
+    __syncthreads();                                   // src is complete, the table is free
+#pragma unroll
+    for (int z = 0; z < EPT; ++z) table[tid * EPT + z] = 0;
+    __syncthreads();
+    unsigned long long kv[RS_M];
+    int slot[RS_M], rank[RS_M];
+#pragma unroll
+    for (int m = 0; m < RS_M; ++m) {
+      const int e = m * NT + tid;
+      const bool valid = e < n;
+      kv[m] = valid ? src[e] : 0ull;
+      const int d = (int)((kv[m] >> shift) & 0xffull);
+      unsigned long long peers = __ballot(valid);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const bool bit = (d >> b) & 1;
+        const unsigned long long bb = __ballot(bit);
+        peers &= bit ? bb : ~bb;
+      }
+      rank[m] = __popcll(peers & below);
+      slot[m] = ((255 - d) * RS_M + m) * NW + w;
+      if (valid && rank[m] == 0) table[slot[m]] = __popcll(peers);
+      if (!valid) slot[m] = -1;
+    }
+    __syncthreads();
+    int loc[EPT], sum = 0;
+#pragma unroll
+    for (int z = 0; z < EPT; ++z) { loc[z] = sum; sum += table[tid * EPT + z]; }
+    int tot;
+    const int base = block_exscan(sum, s_wave, tot);
+    __syncthreads();
+#pragma unroll
+    for (int z = 0; z < EPT; ++z) table[tid * EPT + z] = base + loc[z];
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < RS_M; ++m)
+      if (slot[m] >= 0) dst[table[slot[m]] + rank[m]] = kv[m];
+    unsigned long long* t = src; src = dst; dst = t;
   }
   __syncthreads();
 }
@@ -92,13 +261,16 @@ constexpr int CAND_CAP = 4096;    // >= pre_nms_topk
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// CACHE: S <= KPT * NT points: a thread keeps its KPT keys (points tid, tid + NT, ...) in registers for the three selection
-// passes and the compaction instead of re-reading them from global memory four times
+// CACHE: S <= KPT * NT points: a thread keeps its KPT keys (points tid, tid + NT, ...: coalesced loads) in registers for the
+// three selection passes and the compaction: no re-reads from global memory, and the ordered compaction takes its offsets
+// from ONE scan of the (chunk, wave) count table per class instead of two workgroup scans per 1024-point chunk (41 us of
+// the 112 us this kernel took at 32 640 points)
 constexpr int KPT = 32;
 template <bool CACHE>
 __global__ __launch_bounds__(NT) void k_collect(CollectArgs p) {
   __shared__ unsigned long long key[CAND_CAP];
-  __shared__ int hist[2048];
+  __shared__ unsigned long long key2[RS_MAX];
+  __shared__ int hist[RS_TABLE];                       // radix-select histogram (2048), compaction tables, sort table
   __shared__ int s_wave[NW + 1];
   __shared__ uint32_t s_prefix;
   __shared__ int s_need;
@@ -208,20 +380,46 @@ __global__ __launch_bounds__(NT) void k_collect(CollectArgs p) {
   };
   if (K > 0) {
     if constexpr (CACHE) {
+      // counts per (chunk c, wave w) in point order c * NW + w, one table per class (the histogram array is free now)
+      int* tab_g = hist;
+      int* tab_e = hist + KPT * NW;
+      const int lane = tid & 63, w = tid >> 6;
+      const unsigned long long below = (1ull << lane) - 1ull;
+      __syncthreads();
 #pragma unroll
       for (int c = 0; c < KPT; ++c) {
-        if (c * NT >= S) break;
-        place(c * NT + tid, kreg[c]);
+        const unsigned long long mg = __ballot(kreg[c] > kth), me = __ballot(kreg[c] == kth && kreg[c] != 0);
+        if (lane == 0) { tab_g[c * NW + w] = __popcll(mg); tab_e[c * NW + w] = __popcll(me); }
+      }
+      __syncthreads();
+      int tg, te;
+      const int sg = block_exscan(tid < KPT * NW ? tab_g[tid] : 0, s_wave, tg);
+      const int se = block_exscan(tid < KPT * NW ? tab_e[tid] : 0, s_wave, te);
+      __syncthreads();
+      if (tid < KPT * NW) { tab_g[tid] = sg; tab_e[tid] = se; }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < KPT; ++c) {
+        const uint32_t k = kreg[c];
+        const bool g = k > kth, e = k == kth && k != 0;
+        const unsigned long long mg = __ballot(g), me = __ballot(e);
+        const unsigned long long v = ((unsigned long long)k << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)(c * NT + tid));
+        if (g) key[tab_g[c * NW + w] + __popcll(mg & below)] = v;
+        if (e) { const int pe = tab_e[c * NW + w] + __popcll(me & below); if (pe < need) key[n_greater + pe] = v; }
       }
     } else {
       for (int c0 = 0; c0 < S; c0 += NT) place(c0 + tid, c0 + tid < S ? skey[c0 + tid] : 0u);
     }
   }
   __syncthreads();
-  const int n_pad = next_pow2(max(K, 1));
-  for (int i = K + tid; i < n_pad; i += NT) key[i] = 0ull;
-  // (4) sort: score descending, ties by lower candidate index (stable argsort)
-  bitonic_desc(key, n_pad);
+  // (4) sort: score descending, ties by lower candidate index (stable argsort); the candidates are in index order here
+  if (K <= RS_MAX) {
+    radix_sort_desc(key, key2, hist, K, s_wave);
+  } else {
+    const int n_pad = next_pow2(max(K, 1));
+    for (int i = K + tid; i < n_pad; i += NT) key[i] = 0ull;
+    bitonic_desc(key, n_pad);
+  }
 
   // (5) decode + length filter, order preserved
   float* out_segs = p.segs + (size_t)q * p.pre_nms_topk * 2;
@@ -255,12 +453,14 @@ __global__ __launch_bounds__(NT) void k_collect(CollectArgs p) {
   if (tid == 0) p.counts[q] = run;
 }
 
+bool collect_needs_scratch(int S) { return S > KPT * NT; }
+
 int launch_collect(const CollectArgs& a, int nq, hipStream_t st) {
   if (nq <= 0) return 0;
   DCF_CHECK(a.pre_nms_topk >= 1 && a.pre_nms_topk <= CAND_CAP, "collect: pre_nms_topk=%d exceeds %d", a.pre_nms_topk, CAND_CAP);
   DCF_CHECK(a.n_levels >= 1 && a.n_levels <= 16, "collect: bad n_levels");
   ProfScope prof("collect_segments", st, 0.0, 4.0 * 4.0 * nq * a.S);
-  if (a.S <= KPT * NT) hipLaunchKernelGGL(k_collect<true>, dim3(nq), dim3(NT), 0, st, a);
+  if (!collect_needs_scratch(a.S)) hipLaunchKernelGGL(k_collect<true>, dim3(nq), dim3(NT), 0, st, a);
   else hipLaunchKernelGGL(k_collect<false>, dim3(nq), dim3(NT), 0, st, a);
   DCF_HIP(hipGetLastError());
   return 0;

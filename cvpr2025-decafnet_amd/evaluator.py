@@ -122,6 +122,7 @@ class GroundingEvaluator:
         self.pre_nms_topk, self.pre_nms_thresh, self.seg_len_thresh = ev['pre_nms_topk'], ev['pre_nms_thresh'], ev['seg_len_thresh']
         self.nms_cfg = dict(opt['nms'])
         self.time_dict = defaultdict(list)
+        self._pinned, self._pinned_turn = {}, 0        # pinned host buffers of launch_proposals, two per shape
 
     @classmethod
     def from_checkpoint(cls, opt, root=None, ckpt=None, device='cuda'):
@@ -183,38 +184,64 @@ class GroundingEvaluator:
         return model_._last_flat, T
 
     @torch.no_grad()
-    def generate_proposals(self, flat, T, data=None, window_ext=None):
-        """_collect_segments + batched_nms + seconds for every query; results as in worker_v2.py:1124.
-        ``window_ext``: padded external scores (NQ, T) on the device (worker_v2.py:1078-1081) or None."""
+    def launch_proposals(self, flat, T, data=None, window_ext=None):
+        """Enqueue _collect_segments + batched_nms for every query of a video and the ONE device -> host copy of the kept rows
+        (<= max_num_segs segments + scores + count per query) into pinned memory, without waiting for any of it.  Returns a
+        handle for ``finish_proposals``; the caller may launch the next video's forward first, so that the host-side wait and
+        the launch latency of the next forward overlap with GPU work (``run`` does)."""
         logits, offsets, masks = flat
         t0 = time.perf_counter()
         segs, scores, counts = _nms.collect_segments(logits, offsets, masks, T, self.num_fpn_levels, self.pre_nms_thresh,
                                                      self.pre_nms_topk, self.seg_len_thresh, ext_scores=window_ext)
         self.time_dict['post_process'].append(time.perf_counter() - t0)
-        t0 = time.perf_counter()
-        # every query of the video in one pass on the device; ONE device -> host copy of (<= max_num_segs rows + count) per query
         cfg = self.nms_cfg
-        if cfg.get('max_num_segs', 0) > 0:
-            s_all, c_all, k_all = _nms.batched_nms_queries(segs, scores, counts, **cfg)
-            if data is not None:
-                s_all = s_all * self.vid_stride
-                s_all = (s_all * data['clip_stride'] + 0.5 * data['clip_size']) / data['fps']      # worker_v2.py:1120-1122
-                s_all = torch.clamp(s_all, min=0, max=data['duration'])
-            nq, M = c_all.shape
-            packed = torch.cat((s_all.reshape(nq, 2 * M), c_all, k_all[:, None].to(c_all.dtype)), 1).cpu()   # the only sync
-            results = []
-            for q in range(nq):
-                k = int(packed[q, 3 * M])
-                results.append({'segments': packed[q, :2 * M].view(M, 2)[:k], 'scores': packed[q, 2 * M:3 * M][:k]})
-        else:                                           # max_num_segs <= 0 keeps nothing in the reference either (nms.py:144-146)
+        if cfg.get('max_num_segs', 0) <= 0:             # keeps nothing in the reference either (nms.py:144-146): per query on the host
+            return ('eager', segs, scores, counts, data)
+        t0 = time.perf_counter()
+        # every query of the video in one pass on the device
+        s_all, c_all, k_all = _nms.batched_nms_queries(segs, scores, counts, **cfg)
+        nq, M = c_all.shape
+        packed = torch.cat((s_all.reshape(nq, 2 * M), c_all, k_all[:, None].to(c_all.dtype)), 1)
+        pool = self._pinned.setdefault(tuple(packed.shape), [])
+        if len(pool) < 2:                               # two buffers per shape: one being filled while the previous is read
+            pool.append(torch.empty(packed.shape, dtype=packed.dtype, pin_memory=True))
+        host = pool[self._pinned_turn % 2] if len(pool) == 2 else pool[0]
+        self._pinned_turn += 1
+        host.copy_(packed, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        self.time_dict['nms'].append(time.perf_counter() - t0)
+        return ('packed', done, host, nq, M, data)
+
+    def finish_proposals(self, handle):
+        """Wait for a video's kept rows and turn them into the reference's result list (worker_v2.py:1120-1124)."""
+        if handle[0] == 'eager':
+            _, segs, scores, counts, data = handle
             counts_h = counts.cpu()
             results = []
-            for q in range(logits.shape[0]):
+            for q in range(segs.shape[0]):
                 n = int(counts_h[q])
-                s, c = _nms.batched_nms(segs[q, :n], scores[q, :n], **cfg)
+                s, c = _nms.batched_nms(segs[q, :n], scores[q, :n], **self.nms_cfg)
                 results.append({'segments': s.cpu(), 'scores': c.cpu()})
-        self.time_dict['nms'].append(time.perf_counter() - t0)
+            return results
+        _, done, host, nq, M, data = handle
+        done.synchronize()                              # the only wait
+        packed = host.clone()                           # the pinned buffer is reused two videos later
+        s_host = packed[:, :2 * M].reshape(nq, M, 2)
+        if data is not None:                            # on the <= max_num_segs kept rows, on the host: the same fp32 operations
+            s_host = s_host * self.vid_stride
+            s_host = (s_host * data['clip_stride'] + 0.5 * data['clip_size']) / data['fps']        # worker_v2.py:1120-1122
+            s_host = torch.clamp(s_host, min=0, max=data['duration'])
+        results = []
+        for q in range(nq):
+            k = int(packed[q, 3 * M])
+            results.append({'segments': s_host[q, :k], 'scores': packed[q, 2 * M:3 * M][:k]})
         return results
+
+    def generate_proposals(self, flat, T, data=None, window_ext=None):
+        """_collect_segments + batched_nms + seconds for every query; results as in worker_v2.py:1124.
+        ``window_ext``: padded external scores (NQ, T) on the device (worker_v2.py:1078-1081) or None."""
+        return self.finish_proposals(self.launch_proposals(flat, T, data, window_ext))
 
     def predict(self, data):
         flat, T = self.forward(data)
@@ -256,8 +283,17 @@ class GroundingEvaluator:
             self._check_numerics([self.model])
             return counter
         if n_streams <= 1:
+            # one video per forward like the reference, software-pipelined by one video: the proposals of video i are waited for
+            # after the forward of video i + 1 has been launched (same stream: its kernels run after video i's decode / NMS)
+            prev = None
             for data in dataset:
-                counter.update(self.predict(data), data['segment'])
+                flat, T = self.forward(data)
+                handle = self.launch_proposals(flat, T, data, self._window_ext)
+                if prev is not None:
+                    counter.update(self.finish_proposals(prev[0]), prev[1]['segment'])
+                prev = (handle, data)
+            if prev is not None:
+                counter.update(self.finish_proposals(prev[0]), prev[1]['segment'])
             self._check_numerics([self.model])
             return counter
         # throughput mode: n_streams videos in flight, one model replica (shared parameters, own workspace) and one HIP

@@ -220,6 +220,11 @@ def batched_nms_queries(segs, scores, counts, iou_thresh, min_score, max_num_seg
         top = torch.nn.functional.pad(top, (0, 0, 0, pad))
     if mode is not None and voting_thresh > 0:
         nms_segs = voting_device(top.contiguous(), kc, M, segs, scores, counts, K, voting_thresh)
+    if mode is not None:
+        # batched_nms ends with a descending argsort of the kept scores (nms.py:143-146).  Both NMS variants already emit their
+        # picks in non-increasing score order (greedy NMS walks the sorted candidates; every soft-NMS pick is the maximum of a
+        # set that only shrinks and decays), and the reference's sort is stable, so it is the identity here: no launches.
+        return nms_segs, nms_scores, kc
     valid = torch.arange(M, device=dev)[None] < kc[:, None]
     order = torch.where(valid, nms_scores, nms_scores.new_full((), float('-inf'))).sort(dim=1, descending=True, stable=True)[1]
     out_segs = torch.gather(nms_segs, 1, order[..., None].expand(-1, -1, 2))
