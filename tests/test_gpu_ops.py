@@ -577,6 +577,35 @@ def test_collect_multi_query_vs_oracle(L):
         torch.testing.assert_close(segs[q, :n].cpu(), ws, rtol=1e-6, atol=1e-4)
 
 
+@pytest.mark.parametrize('T0,Lv,topk,shift,quant', [
+    (32768, 2, 4000, -2.0, 0),      # 49152 points: keys re-read from global memory; 4000 kept: the bitonic network, 4 keys per lane
+    (16384, 8, 2000, -2.0, 0),      # the bench shape: keys in registers, radix sort
+    (16384, 8, 2000, -9.0, 0),      # few candidates above the score threshold (fewer than top-k)
+    (4096, 8, 300, 0.0, 16),        # logits quantised to 16 levels: many exactly equal scores, ties broken by the lower index
+    (64, 1, 2000, 0.0, 0),          # fewer points than threads
+])
+def test_collect_paths_vs_oracle(L, T0, Lv, topk, shift, quant):
+    """every code path of the proposal decoder against the oracle: scores exact, order exact (stable), segments 1e-6"""
+    pkg, lib = L
+    g = torch.Generator().manual_seed(T0 + topk)
+    S = sum(T0 >> l for l in range(Lv))
+    logits = torch.randn(1, S, generator=g) * 2 + shift
+    if quant:
+        logits = torch.round(logits * quant / 8) * 8 / quant
+    offsets = torch.rand(1, S, 2, generator=g) * 5
+    masks = torch.ones(1, S, dtype=torch.bool)
+    masks[0, int(S * 0.9):] = False
+    pts = R.generate_points(T0, Lv, 4, 0.5)
+    sizes = [T0 >> l for l in range(Lv)]
+    segs, scores, counts = pkg.nms.collect_segments(logits.cuda(), offsets.cuda(), masks.cuda(), T0, Lv, pre_nms_topk=topk)
+    ws, wc = R.collect_segments(pts, [x[None] for x in logits[0].split(sizes)], [x[None] for x in offsets[0].split(sizes)],
+                                [x[None] for x in masks[0].split(sizes)], pre_nms_topk=topk)
+    n = int(counts[0])
+    assert n == len(wc), (n, len(wc))
+    torch.testing.assert_close(scores[0, :n].cpu(), wc, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(segs[0, :n].cpu(), ws, rtol=1e-6, atol=1e-4)
+
+
 def test_collect_with_ext_scores(L):
     """external per-clip scores, max-pooled down the pyramid (worker_v2.py:1150-1156): reference fixture at nq = 1 and the
     oracle at nq = 3 with per-query rows"""
