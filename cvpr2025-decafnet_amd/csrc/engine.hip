@@ -118,6 +118,7 @@ struct EncW {   // one TransformerEncoder of vid_net
 struct DecW {   // one TransformerDecoder of the fusion
   const float *ln_q_w, *ln_q_b, *ln_kv_w, *ln_kv_b, *dw, *qn_w, *qn_b;
   const float *wq, *bq, *wk, *bk, *wv, *bv, *wp, *bp;
+  const float *wp_il, *bp_il;                // xattn.proj with its output rows in blocks of (32 scale rows, 32 shift rows of the same channels)
   const float *ln_ffn_w, *ln_ffn_b, *fc_w, *fc_b, *pj_w, *pj_b, *ls_ffn;
 };
 struct TextEncW {   // one TransformerEncoder of text_net (stride 0: no depthwise convs, global attention)
@@ -320,6 +321,13 @@ static int resolve_decoder(dcf_model* m, const std::string& p, int E, int TE, hi
   GET(p + ".drop_path_ffn.scale", SH(E), w.ls_ffn);
   SPLIT(w.wq, E, E); SPLIT(w.wk, E, TE); SPLIT(w.wv, E, TE); SPLIT(w.wp, 2 * E, E);
   SPLIT(w.fc_w, 4 * E, E); SPLIT(w.pj_w, E, 4 * E);
+  // the same projection for the GEMM that applies the modulation in its epilogue (G_ADALN): rows (2, E / 32, 32) -> (E / 32, 2, 32)
+  w.wp_il = w.bp_il = nullptr;
+  if (E % 32 == 0) {
+    if (pack3(m, w.wp, 2, E / 32, 32 * E, 1, 0, 2, st, &w.wp_il)) return -1;
+    if (pack3(m, w.bp, 2, E / 32, 32, 1, 0, 2, st, &w.bp_il)) return -1;
+    SPLIT(w.wp_il, 2 * E, E);
+  }
   return 0;
 }
 
@@ -644,6 +652,7 @@ static int run_gemm(dcf_model* m, GemmArgs* g, int count, GemmAMode mode, hipStr
     g[i].status = m->status;
   }
   if (split && mode == A_CHANMAJOR && (g[0].N % 128 != 0 || g[0].M % 4 != 0)) split = false;
+  for (int i = 0; i < count; ++i) DCF_CHECK(split || !(g[i].flags & G_ADALN), "internal: G_ADALN needs the split-operand GEMM");
   return split ? launch_gemm_split(g, count, mode, terms, st) : launch_gemm(g, count, mode, st);
 }
 
@@ -809,9 +818,19 @@ static int run_fusion(dcf_model* m, Buffers& b, float* X, int64_t ldx, int B, in
       XAttnArgs xa{b.R[2], b.Kt, b.Vt, b.kvmask, b.R[0], B, T, Lk, E, c.fusion_heads};
       TRY(launch_xattn(xa, st));
     }
-    GemmArgs gh = gemm(b.R[0], E, w.wp, w.bp, b.H2, 2 * E, rows, 2 * E, E);
-    TRY(run_gemm(m, &gh, 1, A_ROWS, st));
-    TRY(launch_dec_mid(b.R[1], b.H2, w.ln_ffn_w, w.ln_ffn_b, b.R[2], b.R[0], rows, E, st));
+    if (m->gemm_terms != 0 && w.wp_il && m->wsplit.count(w.wp_il) && gemm_can_fuse_adaln(rows, 2 * E, E)) {
+      // q3 = Xa * scale + shift in the epilogue of the projection (blocks.py:643-646): the (rows, 2E) scale / shift tensor is
+      // never written; Xn = ln_ffn(q3) by the LayerNorm kernel
+      GemmArgs gh = gemm(b.R[0], E, w.wp_il, w.bp_il, b.R[2], E, rows, 2 * E, E);
+      gh.flags = G_ADALN; gh.R = b.R[1]; gh.ldr = E;
+      TRY(run_gemm(m, &gh, 1, A_ROWS, st));
+      LnArgs ln{}; ln.X = b.R[2]; ln.ldx = E; ln.Y = b.R[0]; ln.ldy = E; ln.w = w.ln_ffn_w; ln.b = w.ln_ffn_b; ln.rows = rows; ln.C = E;
+      TRY(launch_ln(ln, st));
+    } else {
+      GemmArgs gh = gemm(b.R[0], E, w.wp, w.bp, b.H2, 2 * E, rows, 2 * E, E);
+      TRY(run_gemm(m, &gh, 1, A_ROWS, st));
+      TRY(launch_dec_mid(b.R[1], b.H2, w.ln_ffn_w, w.ln_ffn_b, b.R[2], b.R[0], rows, E, st));
+    }
     GemmArgs go = gemm(b.HID, 4 * E, w.pj_w, w.pj_b, X, ldx, rows, E, 4 * E);
     go.flags = G_RES | G_OUT_MASK; go.rowmask = mask; go.ls = w.ls_ffn; go.R = b.R[2]; go.ldr = E;
     if (li + 1 == m->dec.size() && m->fus_out_w && can_fuse_ln(m, w.pj_w, rows, E, 4 * E, A_ROWS)) {

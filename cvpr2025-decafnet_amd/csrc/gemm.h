@@ -18,6 +18,10 @@ enum GemmFlags {
   G_RES_MASK = 8,
   G_OUT_MASK = 16,
   G_AMASK = 32,     // A_ROWS: multiply A rows by rowmask on load (MaskedConv1D's x * mask)
+  G_ADALN = 64,     // the N output columns are blocks of (32 scale columns, 32 shift columns of the same channels) -- weight
+                    // rows ordered like that by the caller: C[m][c] = R[m][c] * scale[m][c] + shift[m][c], the AdaLN modulation
+                    // of the fusion decoder (blocks.py:643-646); C and R have N / 2 columns.  Split kernel, tiles whose waves
+                    // span 64 columns only (gemm_can_fuse_adaln); no other epilogue flag
 };
 
 struct GemmArgs {
@@ -69,5 +73,8 @@ int launch_split_planes(const float* W, unsigned short* out, int N, int K, int64
 // true if launch_gemm_split can run g with its LayerNorm fused (one tile spans all N columns and the grid still
 // fills the chip); otherwise the caller launches the LayerNorm kernel itself
 bool gemm_can_fuse_ln(int M, int N, int K, GemmAMode mode);
+// true if launch_gemm_split runs an A_ROWS GEMM of this shape with a tile kernel that implements G_ADALN (not the k-sliced
+// kernel of the small grids)
+bool gemm_can_fuse_adaln(int M, int N, int K);
 
 }  // namespace dcf

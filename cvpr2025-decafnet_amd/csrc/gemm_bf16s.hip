@@ -347,7 +347,10 @@ __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4 || (NST > 2
     __syncthreads();                                    // the A tile is dead: its LDS becomes the row-statistics scratch
     gemm_epilogue_ln<WN, TM, TN>(p, acc, m0, wn, lane, reinterpret_cast<float*>(smem_b));
   } else {
-    if (gemm_wide_ok(p)) {                              // uniform
+    if (p.flags & G_ADALN) {                            // uniform
+      __syncthreads();
+      gemm_epilogue_adaln<WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, lane, reinterpret_cast<float*>(smem_b) + wave * EPI_WAVE_FLOATS);
+    } else if (gemm_wide_ok(p)) {                       // uniform
       __syncthreads();                                  // the A tile is dead: every wave takes a private transpose tile in it
       gemm_epilogue_wide<WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, lane, reinterpret_cast<float*>(smem_b) + wave * EPI_WAVE_FLOATS);
     } else {
@@ -513,6 +516,7 @@ template <int WM, int WN, int TM, int TN>
 static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterms, hipStream_t stream) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const GemmArgs& p = b.g[0];
+  DCF_CHECK(!(p.flags & G_ADALN) || TN % 2 == 0, "launch_gemm_split: G_ADALN needs a tile whose waves span 64 columns (got %dx%d)", BM, BN);
   dim3 grid(tile_grid<BM, BN>(p), 1, count);
   char name[96];
   static const bool shapes = getenv("DCF_PROF_SHAPES") != nullptr;   // per-shape labels for tools/ (not used by bench.py)
@@ -591,6 +595,15 @@ static int launch_kslice(const GemmBatch& b, int count, int nterms, hipStream_t 
   return 0;
 }
 
+// mirrors the dispatch below: true when an A_ROWS GEMM of this shape goes to the 128x256 or the 64x256 tile kernel, whose
+// waves own 64 columns = one (scale, shift) pair of 32-column fragments
+bool gemm_can_fuse_adaln(int M, int N, int K) {
+  if (N % 256 != 0 || K % SBK != 0) return false;
+  const long tiles64 = (long)((M + 63) / 64) * (N / 64);
+  if (K >= 4 * SBK && tiles64 <= 512) return false;                   // k-sliced kernel (small grids)
+  return M >= 65536 || (long)((M + 63) / 64) * (N / 256) >= 448;      // 128x256 / 64x256 (WANT workgroups)
+}
+
 bool gemm_can_fuse_ln(int M, int N, int K, GemmAMode mode) {
   // The fused kernel needs a 64 x N tile, i.e. M / 64 workgroups.  Measured at T = 16384 (rocprofv3): with 256
   // workgroups (M = 16384, one per CU) conv + LN fused 64 us vs 40 + 8 us as two kernels on 64x128 tiles; with 510
@@ -614,6 +627,11 @@ int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, 
     if (mode == A_ROWS_TAP3) DCF_CHECK(g[i].nbr && g[i].cin % 32 == 0 && g[i].K == 3 * g[i].cin, "launch_gemm_split: bad tap3 args");
     if (g[i].flags & (G_AMASK | G_RES_MASK | G_OUT_MASK)) DCF_CHECK(g[i].rowmask, "launch_gemm_split: rowmask missing");
     if (g[i].flags & G_RES) DCF_CHECK(g[i].R, "launch_gemm_split: residual missing");
+    if (g[i].flags & G_ADALN)
+      DCF_CHECK(g[i].flags == G_ADALN && mode == A_ROWS && g[i].R && !g[i].ln_w && g[i].ldc % 4 == 0 && g[i].ldr % 4 == 0 &&
+                (reinterpret_cast<uintptr_t>(g[i].C) & 15) == 0 && (reinterpret_cast<uintptr_t>(g[i].R) & 15) == 0 &&
+                (!g[i].bias || (reinterpret_cast<uintptr_t>(g[i].bias) & 15) == 0) && gemm_can_fuse_adaln(g[i].M, g[i].N, g[i].K),
+                "launch_gemm_split: G_ADALN needs A_ROWS, a residual, 16-byte aligned C / R, no other epilogue flag and a tile-kernel grid");
   }
   if (p.M <= 0) return 0;
   DCF_CHECK(p.K > 0 && p.K % SBK == 0 && p.N > 0 && p.N % 32 == 0, "launch_gemm_split: bad N=%d / K=%d", p.N, p.K);

@@ -235,6 +235,66 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& p, f32x16 (&a
   else gemm_epilogue_wide_flags<false, WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, lane, tile);
 }
 
+// ---- epilogue of the AdaLN projection (G_ADALN) ---------------------------------------------------------------
+// The N output columns come in blocks of 64: 32 scale columns, then the 32 shift columns of the same channels (the caller
+// orders the weight rows like that), so the two 32x32 fragments of a wave's 64-column tile are (scale, shift) of the same 32
+// channels.  After the transposition through the wave's LDS tile a lane holds 4 consecutive channels of one row of each: it
+// reads the 4 modulated channels of R and writes 4 channels of C, 16 bytes each.  The (rows, 2E) projection never reaches
+// memory and the separate modulation pass (3 reads + 1 write of a row) is gone.
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_adaln(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0_, int n0_, int wm, int wn,
+                                                    int lane, float* tile /* wave private, EPI_WAVE_FLOATS */) {
+  if constexpr (TN % 2 == 0) {
+    const int m0 = __builtin_amdgcn_readfirstlane(m0_), n0 = __builtin_amdgcn_readfirstlane(n0_);
+    const int rows_left = p.M - m0;
+    float* __restrict__ Cb = p.C + (int64_t)m0 * p.ldc + n0 / 2;
+    const float* __restrict__ Rb = p.R + (int64_t)m0 * p.ldr + n0 / 2;
+    const unsigned ldc = (unsigned)p.ldc, ldr = (unsigned)p.ldr;
+    const int r = lane & 31, h = lane >> 5;
+    const int rr = lane >> 3, c4 = (lane & 7) * 4;
+    constexpr int NP = TM * TN / 2;                      // (scale, shift) fragment pairs of the wave, f = i * (TN / 2) + jp
+    f32x4 res[2][4];
+    auto load_res = [&](int f, f32x4 (&dst)[4]) __attribute__((always_inline)) {
+      const int i = f / (TN / 2), jp = f % (TN / 2);
+      const unsigned ch = (unsigned)((wn * (TN / 2) + jp) * 32 + c4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned row = (unsigned)((wm * TM + i) * 32 + rr + 8 * q);
+        dst[q] = (int)row < rows_left ? *reinterpret_cast<const f32x4*>(Rb + row * ldr + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    load_res(0, res[0]);
+    if constexpr (NP > 1) load_res(1, res[1]);
+#pragma unroll
+    for (int f = 0; f < NP; ++f) {
+      const int i = f / (TN / 2), jp = f % (TN / 2);
+      const unsigned ch = (unsigned)((wn * (TN / 2) + jp) * 32 + c4);
+      f32x4 bs = {0.f, 0.f, 0.f, 0.f}, bh = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
+        bs = *reinterpret_cast<const f32x4*>(p.bias + n0 + (wn * TN + 2 * jp) * 32 + c4);
+        bh = *reinterpret_cast<const f32x4*>(p.bias + n0 + (wn * TN + 2 * jp + 1) * 32 + c4);
+      }
+      f32x4 sc[4];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) tile[((e & 3) + 8 * (e >> 2) + 4 * h) * EPI_PITCH + r] = acc[i][2 * jp][e];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sc[q] = *reinterpret_cast<const f32x4*>(tile + (rr + 8 * q) * EPI_PITCH + c4) + bs;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) tile[((e & 3) + 8 * (e >> 2) + 4 * h) * EPI_PITCH + r] = acc[i][2 * jp + 1][e];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned row = (unsigned)((wm * TM + i) * 32 + rr + 8 * q);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(tile + (rr + 8 * q) * EPI_PITCH + c4) + bh;
+        const f32x4 o = res[f & 1][q] * sc[q] + sh;
+        if ((int)row < rows_left) *reinterpret_cast<f32x4*>(Cb + row * ldc + ch) = o;
+      }
+      if (f + 2 < NP) load_res(f + 2, res[f & 1]);
+    }
+  } else {
+    __builtin_trap();                                    // the launcher only sends G_ADALN to tiles with an even TN
+  }
+}
+
 // ---- epilogue with a fused channel LayerNorm (blocks.py:125-131) ---------------------------------------------
 // The workgroup tile spans all N = WN * TN * 32 output channels of its BM = TM * 32 rows (WM = 1).  Row statistics
 // are taken in two passes like the reference (mean, then the mean of squared deviations): every lane adds its TN
