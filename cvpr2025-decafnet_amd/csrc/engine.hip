@@ -720,6 +720,7 @@ static int run_head(dcf_model* m, const HeadW& h, Buffers& b, const Plan& pl, in
   float* HA = b.HA + (int64_t)row0 * Cin;
   float* HB = b.HB + (int64_t)row0 * Cin;
   const uint8_t* nbr = b.nbr_all + row0;
+  const float *last_ln_w = nullptr, *last_ln_b = nullptr;
   for (size_t i = 0; i < h.conv.size(); ++i) {
     GemmArgs g = gemm(in, ldin, h.conv[i], nullptr, HA, Cin, rowsAll, Cin, 3 * Cin);
     g.cin = Cin; g.nbr = nbr;
@@ -728,15 +729,20 @@ static int run_head(dcf_model* m, const HeadW& h, Buffers& b, const Plan& pl, in
       g.C = nullptr; g.ln_w = h.ln_w[i]; g.ln_b = h.ln_b[i]; g.Y = outp; g.ldy = Cin; g.ln_relu = 1;
       TRY(run_gemm(m, &g, 1, A_ROWS_TAP3, st));
     } else {
-      g.C = outp;                                                // raw conv output, normalised in place
+      g.C = outp;                                                // raw conv output, normalised in place ...
       TRY(run_gemm(m, &g, 1, A_ROWS_TAP3, st));
-      LnArgs ln{}; ln.X = outp; ln.ldx = Cin; ln.Y = outp; ln.ldy = Cin; ln.w = h.ln_w[i]; ln.b = h.ln_b[i];
-      ln.rows = rowsAll; ln.C = Cin; ln.relu = 1;
-      TRY(launch_ln(ln, st));
+      if (i + 1 == h.conv.size()) {                              // ... or, for the last layer, by the output convolution on load
+        last_ln_w = h.ln_w[i]; last_ln_b = h.ln_b[i];
+      } else {
+        LnArgs ln{}; ln.X = outp; ln.ldx = Cin; ln.Y = outp; ln.ldy = Cin; ln.w = h.ln_w[i]; ln.b = h.ln_b[i];
+        ln.rows = rowsAll; ln.C = Cin; ln.relu = 1;
+        TRY(launch_ln(ln, st));
+      }
     }
     in = outp; ldin = Cin;
   }
   ConvOutArgs co{};
+  co.ln_w = last_ln_w; co.ln_b = last_ln_b;
   co.X = in; co.ldx = ldin; co.nbr = nbr; co.W = h.out_w; co.bias = h.out_b; co.lt = pl.d_lt;
   co.out = query_major ? out : out + row0;
   co.rows = rowsAll; co.C = Cin; co.NO = NO; co.row0 = row0; co.mode = mode; co.query_major = query_major;
@@ -771,9 +777,11 @@ static int run_head_pair(dcf_model* m, const HeadW& h1, const HeadW& h2, Buffers
     }
     TRY(run_gemm(m, g, 2, A_ROWS_TAP3, st));
     for (int k = 0; k < 2; ++k) {
-      LnArgs ln{}; ln.X = outp[k]; ln.ldx = Cin; ln.Y = outp[k]; ln.ldy = Cin; ln.w = hs[k]->ln_w[i]; ln.b = hs[k]->ln_b[i];
-      ln.rows = rowsAll; ln.C = Cin; ln.relu = 1;
-      TRY(launch_ln(ln, st));
+      if (i + 1 < h1.conv.size()) {                              // the last layer is normalised by the output convolution on load
+        LnArgs ln{}; ln.X = outp[k]; ln.ldx = Cin; ln.Y = outp[k]; ln.ldy = Cin; ln.w = hs[k]->ln_w[i]; ln.b = hs[k]->ln_b[i];
+        ln.rows = rowsAll; ln.C = Cin; ln.relu = 1;
+        TRY(launch_ln(ln, st));
+      }
       in[k] = outp[k];
     }
     ldin = Cin;
@@ -784,6 +792,7 @@ static int run_head_pair(dcf_model* m, const HeadW& h1, const HeadW& h2, Buffers
     ConvOutArgs co{};
     co.X = in[k]; co.ldx = ldin; co.nbr = b.nbr_all; co.W = hs[k]->out_w; co.bias = hs[k]->out_b; co.lt = pl.d_lt;
     co.out = outs[k]; co.rows = rowsAll; co.C = Cin; co.NO = NOs[k]; co.row0 = 0; co.mode = modes[k]; co.query_major = 1;
+    co.ln_w = hs[k]->ln_w.back(); co.ln_b = hs[k]->ln_b.back();
     TRY(launch_conv_out(co, st));
   }
   return 0;

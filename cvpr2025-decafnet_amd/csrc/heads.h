@@ -30,6 +30,8 @@ struct ConvOutArgs {
   int row0;                           // pyramid row of X[0] (X, nbr and, for internal order, out are pre-offset by it)
   int mode;                           // 0: raw logits   1: relu(scale_l * y)  (RegHead, head.py:102-103)
   int query_major;                    // 0: out[row*NO+o] (internal order)   1: out[(b*S + off_l + t)*NO + o]
+  const float* ln_w; const float* ln_b;   // optional: X holds the RAW output of the trunk's last convolution and the kernel applies
+                                      // its LayerNorm + ReLU on load (one pass over X instead of a LayerNorm pass + this one)
 };
 int launch_conv_out(const ConvOutArgs& a, hipStream_t st);
 

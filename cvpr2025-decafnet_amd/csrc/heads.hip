@@ -92,10 +92,141 @@ __global__ __launch_bounds__(256) void k_conv_out(ConvOutArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same output convolution reading the RAW output of the trunk's last k3 convolution: LayerNorm + ReLU of a row happen in
+// registers as it streams in, so the normalised trunk (188 MB per head at five videos) is neither written by a LayerNorm
+// pass nor read back here.  A wave walks a strip of LC_STRIP output rows; every input row is requested two rows ahead,
+// normalised once, and reduced to its 3 x NO tap products d[tap][o] = w[o][tap] . relu(ln(x_row)) (wave sums: uniform
+// values); output row i is then d_{i-1}[0] + d_i[1] + d_{i+1}[2] under the neighbour flags of row i.  Parameters live in
+// registers for the whole strip (a load inside the loop would wait for the row loads before it).
+// (An earlier attempt normalised the 10 rows of k_conv_out's window on load: 0.377 + 0.141 -> 0.211 + 0.299 ms, no gain --
+// two dependent reductions per row ahead of the loads it serialised.)
+// ------------------------------------------------------------------------------------------
+constexpr int LC_STRIP = 16;
+
+template <int NCH, int NO>
+__global__ __launch_bounds__(256) void k_ln_conv_out(ConvOutArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int r0 = (blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * LC_STRIP;   // scalar strip loop
+  if (r0 >= p.rows) return;
+  const int C = p.C;
+  const int r1 = min(r0 + LC_STRIP, p.rows);            // output rows [r0, r1)
+  RowParam<NCH> lnw, lnb;
+  lnw.init(p.ln_w, C, lane); lnb.init(p.ln_b, C, lane);
+  f32x4 w[NO][3][NCH];
+#pragma unroll
+  for (int o = 0; o < NO; ++o)
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {
+        const int c = 256 * j + 4 * lane;
+        w[o][tap][j] = c < C ? *reinterpret_cast<const f32x4*>(p.W + ((size_t)o * 3 + tap) * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+  // flags of the strip's output rows: lane l <-> row r0 + l
+  const unsigned fl = (lane < LC_STRIP && r0 + lane < p.rows) ? p.nbr[r0 + lane] : 0u;
+  const unsigned long long m_self = __ballot((fl & 1u) != 0), m_left = __ballot((fl & 2u) != 0), m_right = __ballot((fl & 4u) != 0);
+
+  auto fetch = [&](int r, Row<NCH>& x) __attribute__((always_inline)) {     // rows outside [0, rows) are never used by a flag
+    x.load(p.X + (int64_t)(r < 0 ? 0 : (r < p.rows ? r : p.rows - 1)) * p.ldx, C, lane);
+  };
+  // tap products of one input row
+  auto taps = [&](Row<NCH>& x, float (&d)[3][NO]) __attribute__((always_inline)) {
+    row_layernorm(x, C, lane, lnw, lnb);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      f32x4 v = x.v[j];
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      x.v[j] = v;
+    }
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+      for (int o = 0; o < NO; ++o) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+          const f32x4 xv = x.v[j], ww = w[o][tap][j];
+          a += (xv.x * ww.x + xv.y * ww.y) + (xv.z * ww.z + xv.w * ww.w);
+        }
+        d[tap][o] = wave_sum(a);
+      }
+  };
+
+  Row<NCH> x0, x1, xa;
+  float dp[3][NO], dc[3][NO], dn[3][NO];               // tap products of rows i - 1, i, i + 1
+  fetch(r0 - 1, xa); fetch(r0, x0); fetch(r0 + 1, x1);
+  taps(xa, dp);
+  fetch(r0 + 2, xa);
+  taps(x0, dc);
+  fetch(r0 + 3, x0);                                    // three rows in flight: i + 1 (x1), i + 2 (xa), i + 3 (x0)
+  float res[NO];                                        // this lane's output row (lane l <-> row r0 + l)
+#pragma unroll
+  for (int o = 0; o < NO; ++o) res[o] = 0.f;
+  auto emit = [&](int i, Row<NCH>& buf) __attribute__((always_inline)) {   // buf holds row i + 1; refilled with row i + 4
+    taps(buf, dn);
+    if (i + 4 <= r1) fetch(i + 4, buf);
+    const int l = i - r0;
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      float y = 0.f;
+      if ((m_left >> l) & 1ull) y += dp[0][o];
+      if ((m_self >> l) & 1ull) y += dc[1][o];
+      if ((m_right >> l) & 1ull) y += dn[2][o];
+      res[o] = lane == l ? y : res[o];
+    }
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+      for (int o = 0; o < NO; ++o) { dp[tap][o] = dc[tap][o]; dc[tap][o] = dn[tap][o]; }
+  };
+  // three row buffers in rotation, the loop unrolled by three so that their names are static
+  for (int i = r0; i < r1; i += 3) {
+    emit(i, x1);                                        // x1: row i + 1 -> refilled with row i + 4
+    if (i + 1 < r1) emit(i + 1, xa);                    // xa: row i + 2 -> row i + 5
+    if (i + 2 < r1) emit(i + 2, x0);                    // x0: row i + 3 -> row i + 6
+  }
+  if (lane < LC_STRIP && r0 + lane < p.rows) {          // lane l writes row r0 + l
+    const int r = r0 + lane;
+    const LevelTable* lt = p.lt;
+    const int l = find_level(lt, p.row0 + r);
+    int64_t dst = r;
+    if (p.query_major) {
+      const int rel = p.row0 + r - lt->start[l];
+      const int b = rel / lt->T[l], t = rel - b * lt->T[l];
+      dst = (int64_t)b * lt->S + lt->off[l] + t;
+    }
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      float y = res[o] + p.bias[o];
+      if (p.mode == 1) y = fmaxf(y * lt->scale[l], 0.f);
+      p.out[dst * NO + o] = y;
+    }
+  }
+}
+
 int launch_conv_out(const ConvOutArgs& a, hipStream_t st) {
   if (a.rows <= 0) return 0;
   const int n = (a.C + 255) / 256;
   DCF_CHECK(a.C % 4 == 0 && n >= 1 && n <= 4 && (a.NO == 1 || a.NO == 2), "conv_out: C=%d / NO=%d unsupported", a.C, a.NO);
+  if (a.ln_w) {                                          // LayerNorm + ReLU of the trunk on load
+    DCF_CHECK(a.ln_b, "conv_out: ln_b missing");
+    const int strips = (a.rows + LC_STRIP - 1) / LC_STRIP;
+    dim3 grid((strips + 3) / 4), blk(256);
+    ProfScope prof("ln_conv_out", st, (8.0 + 6.0 * a.NO) * a.rows * a.C, 4.0 * a.rows * a.C);
+#define LCO(NCH_)                                                                            \
+    if (a.NO == 1) hipLaunchKernelGGL((k_ln_conv_out<NCH_, 1>), grid, blk, 0, st, a);        \
+    else hipLaunchKernelGGL((k_ln_conv_out<NCH_, 2>), grid, blk, 0, st, a)
+    switch (n) {
+      case 1: LCO(1); break;
+      case 2: LCO(2); break;
+      case 3: LCO(3); break;
+      default: LCO(4); break;
+    }
+#undef LCO
+    DCF_HIP(hipGetLastError());
+    return 0;
+  }
   const int strips = (a.rows + CO_STRIP - 1) / CO_STRIP;
   dim3 grid((strips + 3) / 4), blk(256);
   ProfScope prof("conv_out", st, 6.0 * a.rows * a.C * a.NO, 4.0 * a.rows * a.C);
