@@ -96,8 +96,8 @@ __global__ __launch_bounds__(256) void k_conv_out(ConvOutArgs p) {
 // The same output convolution reading the RAW output of the trunk's last k3 convolution: LayerNorm + ReLU of a row happen in
 // registers as it streams in, so the normalised trunk (188 MB per head at five videos) is neither written by a LayerNorm
 // pass nor read back here.  A wave walks a strip of LC_STRIP output rows; every input row is requested two rows ahead,
-// normalised once, and reduced to its 3 x NO tap products d[tap][o] = w[o][tap] . relu(ln(x_row)) (wave sums: uniform
-// values); output row i is then d_{i-1}[0] + d_i[1] + d_{i+1}[2] under the neighbour flags of row i.  Parameters live in
+// normalised once, and turned into its 3 x NO per-lane tap partials d[tap][o] (w[o][tap] . relu(ln(x_row)) over the lane's
+// channels); output row i is the wave sum of d_{i-1}[0] + d_i[1] + d_{i+1}[2] under the neighbour flags of row i.  Parameters live in
 // registers for the whole strip (a load inside the loop would wait for the row loads before it).
 // (An earlier attempt normalised the 10 rows of k_conv_out's window on load: 0.377 + 0.141 -> 0.211 + 0.299 ms, no gain --
 // two dependent reductions per row ahead of the loads it serialised.)
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_ln_conv_out(ConvOutArgs p) {
   auto fetch = [&](int r, Row<NCH>& x) __attribute__((always_inline)) {     // rows outside [0, rows) are never used by a flag
     x.load(p.X + (int64_t)(r < 0 ? 0 : (r < p.rows ? r : p.rows - 1)) * p.ldx, C, lane);
   };
-  // tap products of one input row
+  // per-lane partial tap products of one input row (the wave reduction happens once per output, below)
   auto taps = [&](Row<NCH>& x, float (&d)[3][NO]) __attribute__((always_inline)) {
     row_layernorm(x, C, lane, lnw, lnb);
 #pragma unroll
@@ -143,18 +143,15 @@ __global__ __launch_bounds__(256) void k_ln_conv_out(ConvOutArgs p) {
     for (int tap = 0; tap < 3; ++tap)
 #pragma unroll
       for (int o = 0; o < NO; ++o) {
-        float a = 0.f;
+        f32x4 t = x.v[0] * w[o][tap][0];
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-          const f32x4 xv = x.v[j], ww = w[o][tap][j];
-          a += (xv.x * ww.x + xv.y * ww.y) + (xv.z * ww.z + xv.w * ww.w);
-        }
-        d[tap][o] = wave_sum(a);
+        for (int j = 1; j < NCH; ++j) t += x.v[j] * w[o][tap][j];
+        d[tap][o] = (t.x + t.y) + (t.z + t.w);
       }
   };
 
   Row<NCH> x0, x1, xa;
-  float dp[3][NO], dc[3][NO], dn[3][NO];               // tap products of rows i - 1, i, i + 1
+  float dp[3][NO], dc[3][NO], dn[3][NO];               // per-lane tap partials of rows i - 1, i, i + 1
   fetch(r0 - 1, xa); fetch(r0, x0); fetch(r0 + 1, x1);
   taps(xa, dp);
   fetch(r0 + 2, xa);
@@ -167,12 +164,10 @@ __global__ __launch_bounds__(256) void k_ln_conv_out(ConvOutArgs p) {
     taps(buf, dn);
     if (i + 4 <= r1) fetch(i + 4, buf);
     const int l = i - r0;
+    const bool fl_ = (m_left >> l) & 1ull, fs_ = (m_self >> l) & 1ull, fr_ = (m_right >> l) & 1ull;
 #pragma unroll
     for (int o = 0; o < NO; ++o) {
-      float y = 0.f;
-      if ((m_left >> l) & 1ull) y += dp[0][o];
-      if ((m_self >> l) & 1ull) y += dc[1][o];
-      if ((m_right >> l) & 1ull) y += dn[2][o];
+      const float y = wave_sum((fl_ ? dp[0][o] : 0.f) + (fs_ ? dc[1][o] : 0.f) + (fr_ ? dn[2][o] : 0.f));
       res[o] = lane == l ? y : res[o];
     }
 #pragma unroll
