@@ -554,20 +554,43 @@ __global__ __launch_bounds__(256) void k_tcn_layer_mfma(const float* __restrict_
                                                          const float* __restrict__ wo, const float* __restrict__ bo,
                                                          float* __restrict__ F, int64_t ldf, int E, unsigned* __restrict__ status) {
   const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
-  const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = blockIdx.x * 4 + wv;
   const int rows = B * T0;
-  if (wave * tiles_per_wave * 32 >= rows) return;
 
+  // weight fragments: the four waves of the workgroup build a quarter each (gather + split) and share them through LDS --
+  // building all of them per wave cost as much as the wave's tile
+  constexpr int NPAIR = LAST ? 10 : 8;                   // (hi, lo) fragment pairs: 6 dilated-conv chunks, 2 + 2 chained ones
+  __shared__ h16x8 s_frag[NPAIR][2][64];
+#pragma unroll
+  for (int f = 0; f < NPAIR; ++f) {
+    if ((f & 3) != wv) continue;
+    float x[8];
+    if (f < 6) {                                         // chunk f = (tap, 16-channel half): k position i = channel 16 cc + 8 h + i
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = wd[((f >> 1) * TCN_HID + 16 * (f & 1) + 8 * h + i) * TCN_HID + n];
+    } else {                                             // chained products: k position i of chunk c = channel 8 (2c + i / 4) + 4 h + i % 4
+      const float* __restrict__ wsrc = f < 8 ? wp : wo;
+      const int c = f & 1;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = wsrc[(8 * (2 * c + i / 4) + 4 * h + i % 4) * TCN_HID + n];
+    }
+    h16x8 fh, fl;
+    split8(x, TCN_SW, fh, fl);
+    s_frag[f][0][lane] = fh;
+    s_frag[f][1][lane] = fl;
+  }
+  __syncthreads();
+  if (wave * tiles_per_wave * 32 >= rows) return;
   h16x8 wd_h[6], wd_l[6], wp_h[2], wp_l[2], wo_h[2], wo_l[2];
 #pragma unroll
-  for (int kc = 0; kc < 6; ++kc) {                       // chunk kc = (tap, 16-channel half): k position i = channel 16 cc + 8 h + i
-    float x[8];
+  for (int kc = 0; kc < 6; ++kc) { wd_h[kc] = s_frag[kc][0][lane]; wd_l[kc] = s_frag[kc][1][lane]; }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] = wd[((kc >> 1) * TCN_HID + 16 * (kc & 1) + 8 * h + i) * TCN_HID + n];
-    split8(x, TCN_SW, wd_h[kc], wd_l[kc]);
+  for (int c = 0; c < 2; ++c) { wp_h[c] = s_frag[6 + c][0][lane]; wp_l[c] = s_frag[6 + c][1][lane]; }
+  if constexpr (LAST) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { wo_h[c] = s_frag[8 + c][0][lane]; wo_l[c] = s_frag[8 + c][1][lane]; }
   }
-  chain_frags(wp, n, h, wp_h, wp_l);
-  if constexpr (LAST) chain_frags(wo, n, h, wo_h, wo_l);
   f32x4 bd4[4], bp4[4], lw4[4], lb4[4], bo4[4];
   chan4(bd, h, bd4); chan4(bp, h, bp4); chan4(lnw, h, lw4); chan4(lnb, h, lb4);
   if constexpr (LAST) chan4(bo, h, bo4);
