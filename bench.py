@@ -51,7 +51,7 @@ def parse():
     ap.add_argument('--max-batch', type=int, default=8)
     ap.add_argument('--videos', type=int, default=3,
                     help='videos per step: independent videos in flight on their own HIP streams (one model instance each)')
-    ap.add_argument('--batch', type=int, default=5,
+    ap.add_argument('--batch', type=int, default=8,
                     help='videos per forward (forward_videos: same-length videos batched through every kernel); a step then '
                          'holds --videos x --batch videos')
     ap.add_argument('--shard-T', type=int, default=0,
@@ -402,7 +402,7 @@ def main():
         # figure comes from the committed summary of tools/pmc_traffic.sh -- valid only for the SAME kernel sources (hash) and
         # the default workload; null otherwise
         try:
-            if (args.T, args.nq, args.videos, args.batch, args.vid_len) != (16384, 1, 3, 5, 0):
+            if (args.T, args.nq, args.videos, args.batch, args.vid_len) != (16384, 1, 3, 8, 0):
                 raise KeyError('non-default workload')
             with open(os.path.join(ROOT, 'profiles', 'r02_pmc_gemm_traffic.json')) as fh:
                 summ = json.load(fh)
