@@ -469,12 +469,43 @@ int launch_collect(const CollectArgs& a, int nq, hipStream_t st) {
 // ------------------------------------------------------------------------------------------
 // hard NMS
 // ------------------------------------------------------------------------------------------
-constexpr int NMS_CAP = 4096;
+constexpr int NMS_BIG_MAX = 1 << 22;  // 32-bit positions, a few hundred MB of scratch at most
+constexpr int NMS_CAP = 4096;     // candidates per query that fit one workgroup's LDS; beyond that the BIG instantiations
 
-__global__ __launch_bounds__(NT) void k_nms(NmsArgs p) {
-  __shared__ unsigned long long key[NMS_CAP];
-  __shared__ float x1[NMS_CAP], x2[NMS_CAP], ar[NMS_CAP];
-  __shared__ unsigned char alive[NMS_CAP];
+// plain bitonic network over keys in global memory (n_pad a power of two, any size): one compare-exchange per element
+// pair and step, a workgroup barrier per step.  Only the n > NMS_CAP kernels use it.
+__device__ __forceinline__ void bitonic_desc_global(unsigned long long* key, int n_pad) {
+  __syncthreads();
+  for (int k = 2; k <= n_pad; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < n_pad; i += NT) {
+        const int o = i ^ j;
+        if (o > i) {
+          const unsigned long long a = key[i], b = key[o];
+          const bool desc = (i & k) == 0;
+          if (desc ? a < b : a > b) { key[i] = b; key[o] = a; }
+        }
+      }
+      __syncthreads();
+    }
+}
+
+// per-query scratch of the BIG kernels (bytes, 16-byte aligned pieces)
+static inline size_t nms_big_scratch(int n) {
+  size_t np = 1;
+  while (np < (size_t)n) np <<= 1;
+  return np * 8 + (size_t)n * 12 + (((size_t)n + 15) & ~(size_t)15);
+}
+static inline size_t softnms_big_scratch(int n) { return (size_t)n * 24; }
+
+// BIG = false: every array in LDS (n <= NMS_CAP).  BIG = true: the same algorithm with the arrays in a global scratch
+// block (n > NMS_CAP: the reference takes any n, nms_cpu.cpp:20-63); one workgroup per query either way, a workgroup
+// barrier orders its global writes for its own later reads.
+template <bool BIG>
+__global__ __launch_bounds__(NT) void k_nms(NmsArgs p, unsigned char* scratch, size_t scratch_per_q) {
+  __shared__ unsigned long long s_key[BIG ? 1 : NMS_CAP];
+  __shared__ float s_x1[BIG ? 1 : NMS_CAP], s_x2[BIG ? 1 : NMS_CAP], s_ar[BIG ? 1 : NMS_CAP];
+  __shared__ unsigned char s_alive[BIG ? 1 : NMS_CAP];
   __shared__ int s_wave[NW + 1];
   const int q = blockIdx.x, tid = threadIdx.x;
   const int n = p.counts ? min(p.counts[q], p.n_max) : p.n_max;
@@ -483,9 +514,25 @@ __global__ __launch_bounds__(NT) void k_nms(NmsArgs p) {
   long long* out = p.keep + (size_t)q * p.stride;
   if (n <= 0) { if (tid == 0) p.keep_counts[q] = 0; return; }
   const int n_pad = next_pow2(n);
+  unsigned long long* key;
+  float *x1, *x2, *ar;
+  unsigned char* alive;
+  if constexpr (BIG) {
+    unsigned char* base = scratch + (size_t)q * scratch_per_q;
+    const int n_cap = p.n_max;
+    int np_cap = 1;
+    while (np_cap < n_cap) np_cap <<= 1;
+    key = reinterpret_cast<unsigned long long*>(base);
+    x1 = reinterpret_cast<float*>(base + (size_t)np_cap * 8);
+    x2 = x1 + n_cap; ar = x2 + n_cap;
+    alive = reinterpret_cast<unsigned char*>(ar + n_cap);
+  } else {
+    key = s_key; x1 = s_x1; x2 = s_x2; ar = s_ar; alive = s_alive;
+  }
   for (int i = tid; i < n_pad; i += NT)
     key[i] = i < n ? (((unsigned long long)fkey(scores[i]) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i)) : 0ull;
-  bitonic_desc(key, n_pad);
+  if constexpr (BIG) bitonic_desc_global(key, n_pad);
+  else bitonic_desc(key, n_pad);
   for (int a = tid; a < n; a += NT) {
     const int i = (int)(0xFFFFFFFFu - (uint32_t)(key[a] & 0xFFFFFFFFu));
     const float l = segs[2 * i], r = segs[2 * i + 1];
@@ -585,11 +632,22 @@ __global__ __launch_bounds__(NT) void k_nms(NmsArgs p) {
 
 int launch_nms(const NmsArgs& a, int nq, hipStream_t st) {
   if (nq <= 0) return 0;
-  DCF_CHECK(a.n_max >= 0 && a.n_max <= NMS_CAP, "nms: n=%d exceeds the on-chip capacity %d", a.n_max, NMS_CAP);
+  DCF_CHECK(a.n_max >= 0 && a.n_max <= NMS_BIG_MAX, "nms: n=%d exceeds %d", a.n_max, NMS_BIG_MAX);
   DCF_CHECK(a.stride >= a.n_max, "nms: stride < n_max");
   ProfScope prof("nms_1d", st, 0.0, 0.0);
-  hipLaunchKernelGGL(k_nms, dim3(nq), dim3(NT), 0, st, a);
-  DCF_HIP(hipGetLastError());
+  if (a.n_max <= NMS_CAP) {
+    hipLaunchKernelGGL(k_nms<false>, dim3(nq), dim3(NT), 0, st, a, (unsigned char*)nullptr, (size_t)0);
+    DCF_HIP(hipGetLastError());
+    return 0;
+  }
+  // more candidates than one workgroup's LDS holds: stream-ordered scratch, same kernel over global arrays
+  const size_t per_q = (nms_big_scratch(a.n_max) + 255) & ~(size_t)255;
+  unsigned char* scratch = nullptr;
+  DCF_HIP(hipMallocAsync((void**)&scratch, per_q * nq, st));
+  hipLaunchKernelGGL(k_nms<true>, dim3(nq), dim3(NT), 0, st, a, scratch, per_q);
+  const hipError_t e = hipGetLastError();
+  DCF_HIP(hipFreeAsync(scratch, st));
+  DCF_HIP(e);
   return 0;
 }
 
@@ -603,10 +661,11 @@ __device__ __forceinline__ MaxPos better(MaxPos a, MaxPos b) {
   return a;
 }
 
-__global__ __launch_bounds__(NT) void k_softnms(SoftNmsArgs p) {
-  __shared__ float x1[NMS_CAP], x2[NMS_CAP], sc[NMS_CAP], ar[NMS_CAP];
-  __shared__ int ind[NMS_CAP];
-  __shared__ int slot[NMS_CAP];
+template <bool BIG>
+__global__ __launch_bounds__(NT) void k_softnms(SoftNmsArgs p, unsigned char* scratch, size_t scratch_per_q) {
+  __shared__ float s_x1[BIG ? 1 : NMS_CAP], s_x2[BIG ? 1 : NMS_CAP], s_sc[BIG ? 1 : NMS_CAP], s_ar[BIG ? 1 : NMS_CAP];
+  __shared__ int s_ind[BIG ? 1 : NMS_CAP];
+  __shared__ int s_slot[BIG ? 1 : NMS_CAP];
   __shared__ int s_wave[NW + 1];
   __shared__ float s_v[NW];
   __shared__ int s_p[NW];
@@ -618,6 +677,16 @@ __global__ __launch_bounds__(NT) void k_softnms(SoftNmsArgs p) {
   float* dets = p.dets + (size_t)q * p.stride * 3;
   long long* out = p.inds + (size_t)q * p.stride;
   if (n <= 0) { if (tid == 0) p.out_counts[q] = 0; return; }
+  float *x1, *x2, *sc, *ar;
+  int *ind, *slot;
+  if constexpr (BIG) {
+    float* base = reinterpret_cast<float*>(scratch + (size_t)q * scratch_per_q);
+    const int n_cap = p.n_max;
+    x1 = base; x2 = x1 + n_cap; sc = x2 + n_cap; ar = sc + n_cap;
+    ind = reinterpret_cast<int*>(ar + n_cap); slot = ind + n_cap;
+  } else {
+    x1 = s_x1; x2 = s_x2; sc = s_sc; ar = s_ar; ind = s_ind; slot = s_slot;
+  }
   for (int i = tid; i < n; i += NT) {
     const float l = segs[2 * i], r = segs[2 * i + 1];
     x1[i] = l; x2[i] = r; sc[i] = scores[i]; ar[i] = (r - l) + 1e-6f; ind[i] = i;
@@ -712,12 +781,22 @@ __global__ __launch_bounds__(NT) void k_softnms(SoftNmsArgs p) {
 
 int launch_softnms(const SoftNmsArgs& a, int nq, hipStream_t st) {
   if (nq <= 0) return 0;
-  DCF_CHECK(a.n_max >= 0 && a.n_max <= NMS_CAP, "softnms: n=%d exceeds the on-chip capacity %d", a.n_max, NMS_CAP);
+  DCF_CHECK(a.n_max >= 0 && a.n_max <= NMS_BIG_MAX, "softnms: n=%d exceeds %d", a.n_max, NMS_BIG_MAX);
   DCF_CHECK(a.method >= 0 && a.method <= 2, "softnms: method must be 0, 1 or 2");
   DCF_CHECK(a.stride >= a.n_max, "softnms: stride < n_max");
   ProfScope prof("softnms_1d", st, 0.0, 0.0);
-  hipLaunchKernelGGL(k_softnms, dim3(nq), dim3(NT), 0, st, a);
-  DCF_HIP(hipGetLastError());
+  if (a.n_max <= NMS_CAP) {
+    hipLaunchKernelGGL(k_softnms<false>, dim3(nq), dim3(NT), 0, st, a, (unsigned char*)nullptr, (size_t)0);
+    DCF_HIP(hipGetLastError());
+    return 0;
+  }
+  const size_t per_q = (softnms_big_scratch(a.n_max) + 255) & ~(size_t)255;
+  unsigned char* scratch = nullptr;
+  DCF_HIP(hipMallocAsync((void**)&scratch, per_q * nq, st));
+  hipLaunchKernelGGL(k_softnms<true>, dim3(nq), dim3(NT), 0, st, a, scratch, per_q);
+  const hipError_t e = hipGetLastError();
+  DCF_HIP(hipFreeAsync(scratch, st));
+  DCF_HIP(e);
   return 0;
 }
 

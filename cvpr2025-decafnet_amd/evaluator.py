@@ -122,7 +122,7 @@ class GroundingEvaluator:
         self.pre_nms_topk, self.pre_nms_thresh, self.seg_len_thresh = ev['pre_nms_topk'], ev['pre_nms_thresh'], ev['seg_len_thresh']
         self.nms_cfg = dict(opt['nms'])
         self.time_dict = defaultdict(list)
-        self._pinned, self._pinned_turn = {}, 0        # pinned host buffers of launch_proposals, two per shape
+        self._pinned = {}                              # free pinned host buffers of launch_proposals, by packed shape
 
     @classmethod
     def from_checkpoint(cls, opt, root=None, ckpt=None, device='cuda'):
@@ -202,11 +202,10 @@ class GroundingEvaluator:
         s_all, c_all, k_all = _nms.batched_nms_queries(segs, scores, counts, **cfg)
         nq, M = c_all.shape
         packed = torch.cat((s_all.reshape(nq, 2 * M), c_all, k_all[:, None].to(c_all.dtype)), 1)
-        pool = self._pinned.setdefault(tuple(packed.shape), [])
-        if len(pool) < 2:                               # two buffers per shape: one being filled while the previous is read
-            pool.append(torch.empty(packed.shape, dtype=packed.dtype, pin_memory=True))
-        host = pool[self._pinned_turn % 2] if len(pool) == 2 else pool[0]
-        self._pinned_turn += 1
+        # the pinned buffer belongs to the handle until finish_proposals has read it, then goes back to the free list of its
+        # shape: two handles never share one, whatever order shapes arrive in (nq differs between videos)
+        free = self._pinned.setdefault(tuple(packed.shape), [])
+        host = free.pop() if free else torch.empty(packed.shape, dtype=packed.dtype, pin_memory=True)
         host.copy_(packed, non_blocking=True)
         done = torch.cuda.Event()
         done.record()
@@ -226,7 +225,8 @@ class GroundingEvaluator:
             return results
         _, done, host, nq, M, data = handle
         done.synchronize()                              # the only wait
-        packed = host.clone()                           # the pinned buffer is reused two videos later
+        packed = host.clone()
+        self._pinned.setdefault(tuple(host.shape), []).append(host)      # back to the free list: a later video may take it now
         s_host = packed[:, :2 * M].reshape(nq, M, 2)
         if data is not None:                            # on the <= max_num_segs kept rows, on the host: the same fp32 operations
             s_host = s_host * self.vid_stride

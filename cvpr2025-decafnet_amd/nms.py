@@ -20,7 +20,8 @@ import torch
 
 from . import _lib
 
-NMS_CAPACITY = 4096
+NMS_CAPACITY = 4096        # candidates per query that stay in one workgroup's LDS; larger problems run the same kernels over
+                           # a global-memory scratch block (any n, like the reference: nms_cpu.cpp:20-63)
 
 
 def _device():
@@ -87,8 +88,6 @@ def nms(segs, scores, iou_thresh):
         return torch.empty(0, dtype=torch.int64)
     _check_float(segs, 'segs')
     n = segs.shape[0]
-    if n > NMS_CAPACITY:
-        raise RuntimeError(f'nms_1d: n={n} exceeds the on-chip capacity {NMS_CAPACITY} of the HIP kernel')
     dev = _device()
     keep, kc = nms_device(segs.to(dev)[None], scores.to(dev, torch.float32)[None].contiguous(), None, n, n, iou_thresh)
     k = int(kc.item())
@@ -105,8 +104,6 @@ def softnms(segs, scores, dets, iou_thresh, sigma, min_score, method):
     for x, nme in ((segs, 'segs'), (scores, 'scores'), (dets, 'dets')):
         _check_float(x, nme)
     n = segs.shape[0]
-    if n > NMS_CAPACITY:
-        raise RuntimeError(f'softnms_1d: n={n} exceeds the on-chip capacity {NMS_CAPACITY} of the HIP kernel')
     dev = _device()
     d, inds, oc = softnms_device(segs.to(dev)[None], scores.to(dev)[None], None, n, n, iou_thresh, sigma, min_score, method)
     k = int(oc.item())
@@ -142,8 +139,6 @@ def batched_nms(segs, scores, iou_thresh, min_score, max_num_segs, mode='soft_nm
                 keep = c > min_score
                 s, c = s[keep].contiguous(), c[keep].contiguous()
             n = s.shape[0]
-            if n > NMS_CAPACITY:
-                raise RuntimeError(f'batched_nms: n={n} exceeds the on-chip capacity {NMS_CAPACITY}')
             if n == 0:
                 nms_segs, nms_scores = s, c
             else:
@@ -155,8 +150,6 @@ def batched_nms(segs, scores, iou_thresh, min_score, max_num_segs, mode='soft_nm
                 nms_segs, nms_scores = s[idx].contiguous(), c[idx].contiguous()
         elif mode == 'soft_nms':
             n = segs_d.shape[0]
-            if n > NMS_CAPACITY:
-                raise RuntimeError(f'batched_nms: n={n} exceeds the on-chip capacity {NMS_CAPACITY}')
             # SoftNMSop only keeps the first max_num_segs picks (nms.py:54-59): stop there
             d, inds, oc = softnms_device(segs_d[None], scores_d[None], None, n, n, iou_thresh, sigma, min_score, 2,
                                          max_iters=max_num_segs if max_num_segs > 0 else 0)
@@ -184,8 +177,6 @@ def batched_nms_queries(segs, scores, counts, iou_thresh, min_score, max_num_seg
     beyond out_counts[q] are padding.  Same values per query as ``batched_nms``."""
     assert segs.is_cuda and segs.dim() == 3 and max_num_segs > 0
     nq, K = scores.shape
-    if K > NMS_CAPACITY:
-        raise RuntimeError(f'batched_nms: n={K} exceeds the on-chip capacity {NMS_CAPACITY}')
     M = int(max_num_segs)
     dev = segs.device
     segs = segs.contiguous()

@@ -552,6 +552,31 @@ def gen_nms(ext):
     save('nms_kat.npz', out)
 
 
+@torch.no_grad()
+def gen_nms_big(ext):
+    """more candidates than one workgroup's LDS holds (n > 4096): the reference extension takes any n (nms_cpu.cpp:20-63)"""
+    g = torch.Generator().manual_seed(4321)
+    out, cases = {}, []
+    for n, thr, min_score in ((4097, 0.5, 0.001), (8192, 0.5, 0.001), (6000, 0.3, 0.05)):
+        c = torch.rand(n, generator=g) * 60.0 * n ** 0.5
+        ln = torch.rand(n, generator=g) * 60.0 + 0.2
+        segs = torch.stack((c - ln / 2, c + ln / 2), -1).contiguous()
+        scores = torch.rand(n, generator=g)
+        while len(torch.unique(scores)) != n:
+            scores = torch.rand(n, generator=g)
+        i = len(cases)
+        out[f'k{i}/segs'], out[f'k{i}/scores'] = segs, scores.contiguous()
+        out[f'k{i}/nms'] = ext.nms(segs, scores, iou_thresh=float(thr))
+        for method in (1, 2):
+            dets = torch.full((n, 3), -7.0)
+            idx = ext.softnms(segs, scores, dets, iou_thresh=float(thr), sigma=0.9, min_score=float(min_score), method=method)
+            out[f'k{i}/soft{method}/idx'] = idx
+            out[f'k{i}/soft{method}/dets'] = dets[:len(idx)]
+        cases.append(dict(n=n, iou_thresh=thr, sigma=0.9, min_score=min_score))
+    out['cases'] = cases
+    save('nms_kat_big.npz', out)
+
+
 # ------------------------------------------------------------------ G6: feature files / annotations / text-CLS table
 def write_data_tree(root, arrays):
     """materialise the synthetic dataset of data_io.npz under ``root`` (also used by tests/test_data_io.py)"""
@@ -657,5 +682,7 @@ if __name__ == '__main__':
         gen_postproc_ext()
     if 'nms' in which:
         gen_nms(ext)
+    if 'nms_big' in which:
+        gen_nms_big(ext)
     if 'data_io' in which:
         gen_data_io()

@@ -452,6 +452,33 @@ def test_nms_known_answers(L):
                 assert (dets[len(idx):] == -7.0).all()
 
 
+def test_nms_known_answers_beyond_4096_candidates(L):
+    """n = 4097 / 6000 / 8192: more candidates than one workgroup's LDS holds -- the same kernels over a global scratch block;
+    expected indices / dets from the reference's extension (the reference takes any n, nms_cpu.cpp:20-63)"""
+    pkg, lib = L
+    nms = pkg.nms
+    g = Golden('nms_kat_big.npz')
+    for i, c in enumerate(g.js('cases')):
+        segs, scores = g.t(f'k{i}/segs'), g.t(f'k{i}/scores')
+        assert torch.equal(nms.nms(segs, scores, c['iou_thresh']), g.t(f'k{i}/nms')), c
+        for method in (1, 2):
+            dets = torch.full((len(segs), 3), -7.0)
+            idx = nms.softnms(segs, scores, dets, c['iou_thresh'], c['sigma'], c['min_score'], method)
+            assert torch.equal(idx, g.t(f'k{i}/soft{method}/idx')), (c, method)
+            torch.testing.assert_close(dets[:len(idx)], g.t(f'k{i}/soft{method}/dets'), rtol=1e-6, atol=1e-7)
+    # batched_nms over device tensors of that size (both modes), against the oracle's composition
+    segs, scores = g.t('k1/segs'), g.t('k1/scores')
+    for mode in ('nms', 'soft_nms'):
+        s, c = nms.batched_nms(segs.cuda(), scores.cuda(), 0.5, 0.0 if mode == 'nms' else 0.001, 50, mode=mode, sigma=0.9, voting_thresh=0.0)
+        if mode == 'nms':
+            keep = nms_oracle.nms(segs, scores, 0.5)[:50]
+            assert torch.equal(s.cpu(), segs[keep]) and torch.equal(c.cpu(), scores[keep])
+        else:
+            d = torch.zeros(len(segs), 3)
+            nms_oracle.softnms(segs, scores, d, 0.5, 0.9, 0.001, 2)
+            torch.testing.assert_close(c.cpu(), d[:50, 2], rtol=1e-6, atol=1e-7)
+
+
 def test_nms_module_abi(L):
     """the drop-in module: name, keyword names, CPU/contiguity/dtype checks (nms_cpu.cpp:11-17,184-194)"""
     import nms_1d_cpu_vg as ext
@@ -475,8 +502,9 @@ def test_nms_fuzz_vs_oracle(L):
     pkg, lib = L
     nms = pkg.nms
     g = torch.Generator().manual_seed(321)
-    for trial in range(25):
-        n = int(torch.randint(1, 1500, (1,), generator=g))
+    for trial in range(28):
+        # 25 random sizes, then the default pre-NMS top-k (2000), the LDS capacity (4096) and one past it (global scratch)
+        n = int(torch.randint(1, 1500, (1,), generator=g)) if trial < 25 else (2000, 4096, 4097)[trial - 25]
         c = torch.rand(n, generator=g) * (20 + 3 * n ** 0.5)
         ln = torch.rand(n, generator=g) * 30 + 0.1
         segs = torch.stack((c - ln / 2, c + ln / 2), -1).contiguous()

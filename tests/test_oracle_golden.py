@@ -206,6 +206,19 @@ def test_nms_known_answers():
             assert torch.equal(dets[:len(idx)], want), (c, method)
 
 
+def test_nms_known_answers_beyond_4096_candidates():
+    """n = 4097 / 6000 / 8192 (more than the HIP kernels keep in LDS): the oracle against the reference's extension"""
+    g = Golden('nms_kat_big.npz')
+    for i, c in enumerate(g.js('cases')):
+        segs, scores = g.t(f'k{i}/segs'), g.t(f'k{i}/scores')
+        assert torch.equal(nms_oracle.nms(segs, scores, c['iou_thresh']), g.t(f'k{i}/nms')), c
+        for method in (1, 2):
+            dets = torch.full((len(segs), 3), -7.0)
+            idx = nms_oracle.softnms(segs, scores, dets, c['iou_thresh'], c['sigma'], c['min_score'], method)
+            assert torch.equal(idx, g.t(f'k{i}/soft{method}/idx')), (c, method)
+            assert torch.equal(dets[:len(idx)], g.t(f'k{i}/soft{method}/dets')), (c, method)
+
+
 def test_nms_vs_compiled_reference_random():
     """When oracle/_ref holds the reference's own extension, fuzz the C oracle against it."""
     import importlib.util
