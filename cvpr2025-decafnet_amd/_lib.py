@@ -38,6 +38,7 @@ SIGNATURES = {
     'dcf_text_encode': (i32, [vp, c_f32p, c_u8p, i32, c_f32p, c_u8p, vp]),
     'dcf_model_finalize': (i32, [vp, vp]),
     'dcf_numerics_status': (i32, [vp, i32, vp]),
+    'dcf_numerics_status_async': (i32, [vp, vp, vp]),
     'dcf_points_per_query': (i64, [vp, i64]),
     'dcf_forward_eval': (i32, [vp, c_f32p, c_f32p, c_u8p, i64, i32, ctypes.POINTER(vp), ctypes.POINTER(vp),
                                ctypes.POINTER(i32), c_f32p, c_f32p, c_f32p, c_u8p, vp]),

@@ -76,8 +76,12 @@ __global__ void k_permute3(const float* __restrict__ src, float* __restrict__ ds
   dst[o] = src[i];
 }
 
-// masks_out[b][off_l + t] = mask_all[start_l + b*T_l + t]
-__global__ void k_masks_out(const uint8_t* __restrict__ mask_all, uint8_t* __restrict__ out, const LevelTable* lt) {
+// masks_out[b][off_l + t] = mask_all[start_l + b*T_l + t].  Last kernel of a forward: when the sticky numerics word of the
+// f16x3 GEMMs is raised (an operand left the fp16 range somewhere upstream, and a ReLU / max may have swallowed the
+// NaN since) the logits of the forward are overwritten with NaN, so that a caller who never asks dcf_numerics_status --
+// the reference's Evaluator -- sees invalid scores instead of plausible wrong ones.
+__global__ void k_masks_out(const uint8_t* __restrict__ mask_all, uint8_t* __restrict__ out, const LevelTable* lt,
+                            const unsigned* __restrict__ status, float* __restrict__ logits) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   const int total = lt->start[lt->n_levels];
   if (r >= total) return;
@@ -85,7 +89,9 @@ __global__ void k_masks_out(const uint8_t* __restrict__ mask_all, uint8_t* __res
   while (l + 1 < lt->n_levels && r >= lt->start[l + 1]) ++l;
   const int rel = r - lt->start[l];
   const int b = rel / lt->T[l], t = rel - b * lt->T[l];
-  out[(int64_t)b * lt->S + lt->off[l] + t] = mask_all[r];
+  const int64_t o = (int64_t)b * lt->S + lt->off[l] + t;
+  out[o] = mask_all[r];
+  if (status && (status[0] & 1u)) logits[o] = __uint_as_float(0x7fc00000u);
 }
 
 // gate[b][t] = override[q0 + b][t]; mask = vid_mask (msf) or vid_mask & gate (model.py:544-545)
@@ -1077,7 +1083,8 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
                       offsets_out + (int64_t)q0 * S * 2, st));
     }
     hipLaunchKernelGGL(k_masks_out, dim3((rowsAll + 255) / 256), dim3(256), 0, st, (const uint8_t*)b.mask_all,
-                       masks_out + (int64_t)q0 * S, (const LevelTable*)pl->d_lt);
+                       masks_out + (int64_t)q0 * S, (const LevelTable*)pl->d_lt, (const unsigned*)m->status,
+                       logits_out + (int64_t)q0 * S);
     DCF_HIP(hipGetLastError());
 
     m->dbg.correl = b.correl; m->dbg.gate = b.gate; m->dbg.F = b.F;
@@ -1163,7 +1170,7 @@ static int text_encode(dcf_model* m, const float* tokens, const uint8_t* token_m
 extern "C" {
 
 const char* dcf_last_error(void) { return dcf::g_err.c_str(); }
-int dcf_abi_version(void) { return 4; }
+int dcf_abi_version(void) { return 5; }
 
 int dcf_model_create(const dcf_config* cfg, dcf_model** out) {
   DCF_CHECK(cfg && out, "dcf_model_create: null argument");
@@ -1326,6 +1333,13 @@ int dcf_numerics_status(dcf_model* m, int32_t reset, void* stream) {
     if (flag) out |= 1;
   }
   return out;
+}
+
+int dcf_numerics_status_async(dcf_model* m, int32_t* host_dst, void* stream) {
+  DCF_CHECK(m && host_dst, "dcf_numerics_status_async: null argument");
+  if (!m->status) { *host_dst = 0; return 0; }
+  DCF_HIP(hipMemcpyAsync(host_dst, m->status, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return 0;
 }
 
 int64_t dcf_points_per_query(const dcf_model* m, int64_t T) {

@@ -327,7 +327,9 @@ class _Engine:
         _lib.check(self.lib.dcf_model_create(ctypes.byref(cfg), ctypes.byref(self.handle)), 'dcf_model_create')
         self.signature = None
         self.cached = None
+        self.cached_ids = None
         self.keepalive = []
+        self.status_probe = None                     # (pinned int32, event) of the last forward's numerics word
         self.pe_cache = {}
         self.text_pe_cache = {}
 
@@ -343,10 +345,15 @@ class _Engine:
         (state_dict) costs about as much host time as a whole T = 16384 forward takes on the GPU, so the tensor list is
         cached per engine and only a cheap signature -- storage address and in-place version counter of every cached
         parameter -- is compared on the hot path (``.cuda()`` / ``.to()`` swap ``param.data``, ``load_state_dict`` copies
-        in place and bumps ``_version``; both keep the Parameter objects).  Registering new parameters after the first
-        forward needs ``model._engine = None``."""
-        if self.cached is None:
+        in place and bumps ``_version``; both keep the Parameter objects)."""
+        # replaced Parameter OBJECTS (module.weight = nn.Parameter(...), load_state_dict(assign=True), re-parametrisation)
+        # keep neither the storage nor the version counter of the cached ones: the identity of every parameter slot is
+        # part of the check (a walk over _parameters dicts, no state_dict construction: ~0.1 ms for 400 tensors)
+        ids = model._parameter_ids()
+        if self.cached is None or ids != self.cached_ids:
             self.cached = model._named_engine_tensors()
+            self.cached_ids = ids
+            self.signature = None
         named_tensors = self.cached
         sig = tuple((t.data_ptr(), t._version) for _, t in named_tensors)
         if sig == self.signature:
@@ -379,6 +386,7 @@ def _encode_text(model, tokens, token_masks):
         raise RuntimeError('encode_text runs on the MI355X only: move the tokens to the GPU')
     if model._engine is None:
         model._engine = _Engine(model._config())
+    model._raise_if_flagged()
     eng = model._engine
     eng.bind(model)
     tn = model.text_net
@@ -520,6 +528,36 @@ class PtTransformerEarlyFusionIterative(nn.Module):
     def _named_engine_tensors(self):
         return list(self.state_dict(keep_vars=True).items())
 
+    def _parameter_ids(self):
+        return tuple(id(p) for mod in self.modules() for p in mod._parameters.values())
+
+    # The f16x3 range flag of a plain model(...) call: the forward ends with a 4-byte async copy of the sticky word into
+    # pinned memory; the NEXT call into the model (forward / forward_videos / encode_text) looks at it if that copy has
+    # completed -- no wait -- and raises.  (The forward itself has already overwritten its logits with NaN on the device.)
+    def _probe_numerics(self):
+        eng = self._engine
+        if eng.status_probe is None:
+            eng.status_probe = [torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event(), False]
+        host, ev, _ = eng.status_probe
+        _lib.check(eng.lib.dcf_numerics_status_async(eng.handle, ctypes.c_void_p(host.data_ptr()), _lib.current_stream()),
+                   'dcf_numerics_status_async')
+        ev.record()
+        eng.status_probe[2] = True
+
+    def _raise_if_flagged(self):
+        eng = self._engine
+        if eng is None or eng.status_probe is None or not eng.status_probe[2]:
+            return
+        host, ev, _ = eng.status_probe
+        if not ev.query():
+            return
+        eng.status_probe[2] = False
+        if int(host[0]) & 1:
+            self.numerics_status(reset=True)
+            raise RuntimeError("an activation left the fp16 operand range of the f16x3 GEMM mode (|a| >= 4094) in an earlier "
+                               "forward of this model: its logits were set to NaN.  Re-run with opt.model.gemm_mode = 'bf16x6' "
+                               "(or 'fp32'); the flag has been reset.")
+
     def _position_encoding(self, T, device):
         """vid_net.pe for length T, token-major (T, E) (video_net.py:75-78,141-151)."""
         eng = self._engine
@@ -555,6 +593,7 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         dev = videos[0][0].device
         if self._engine is None:
             self._engine = _Engine(self._config())
+        self._raise_if_flagged()
         eng = self._engine
         eng.bind(self)
         lib = eng.lib
@@ -602,6 +641,7 @@ class PtTransformerEarlyFusionIterative(nn.Module):
                                                _lib.ptr(offsets), _lib.ptr(masks), _lib.current_stream()), 'dcf_forward_eval_videos')
         self._last_inputs = (keep, pe)
         self._last_flat = (logits, offsets, masks)
+        self._probe_numerics()
         L = self.vid_net.arch[2]
         sizes = [T >> l for l in range(L)]
         out, q = [], 0
@@ -622,6 +662,7 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         dev = vid.device
         if self._engine is None:
             self._engine = _Engine(self._config())
+        self._raise_if_flagged()
         eng = self._engine
         eng.bind(self)
         lib = eng.lib
@@ -672,6 +713,7 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         # keep the borrowed inputs alive until the stream has consumed them
         self._last_inputs = (vid_c, sh_c, mask_c, cls_c, keep, pe)
         self._last_flat = (logits, offsets, masks)
+        self._probe_numerics()
         L = self.vid_net.arch[2]
         sizes = [T >> l for l in range(L)]
         lg = [tuple(x.unsqueeze(0) for x in logits[q].split(sizes)) for q in range(nq)]

@@ -83,6 +83,11 @@ int dcf_model_bind(dcf_model* m, const char* name, const float* data, const int6
  *       gemm_mode = 6;   2 = a weight did not fit (|w| >= 255.9) and the model fell back to bf16x6 at finalize;
  *   4 = the model runs bf16x6;  8 = the model runs the native fp32 MFMA path.   reset != 0 clears bit 1's source. */
 int dcf_numerics_status(dcf_model* m, int32_t reset, void* stream);
+/* The same status word without blocking: enqueues a 4-byte device -> host copy of the sticky flag (bit 0 above) into
+ * `host_dst` (pinned memory) on `stream`; the caller reads it once an event recorded after the call has completed.
+ * Independently of either call, a forward that ends with the flag raised overwrites its logits with NaN, so that a plain
+ * `model(...)` caller (the reference's Evaluator, libs/worker_v2.py:1007) cannot mistake them for valid scores. */
+int dcf_numerics_status_async(dcf_model* m, int32_t* host_dst, void* stream);
 
 /* Absolute position encoding buffer `vid_net.pe` (non-persistent in the reference,
  * libs/modeling/video_net.py:75-78): token-major (T, E) fp32 already resampled for length T

@@ -30,6 +30,25 @@ def collect(path, counter):
     return per
 
 
+def last_forward(path, counter):
+    """per-kernel counter sums (KiB) over the LAST forward of the run: dispatches from the last sidekick-scoring kernel (the
+    first kernel of a forward) to the end of the trace"""
+    rows = [r for r in csv.DictReader(open(path)) if r['Counter_Name'] == counter]
+    rows.sort(key=lambda r: int(r['Dispatch_Id']))
+    starts = [i for i, r in enumerate(rows) if 'k_sidekick_partial' in r['Kernel_Name']]
+    if not starts:
+        return {}, 0
+    per = {}
+    for r in rows[starts[-1]:]:
+        import re
+        n = re.sub(r'^void ', '', r['Kernel_Name'])
+        n = re.sub(r'\(.*$', '', n).replace('dcf::', '')
+        d = per.setdefault(n, {'launches': 0, 'kib': 0.0})
+        d['launches'] += 1
+        d['kib'] += float(r['Counter_Value'])
+    return per, len(rows) - starts[-1]
+
+
 f, w = collect(sys.argv[1], 'FETCH_SIZE'), collect(sys.argv[2], 'WRITE_SIZE')
 out = {}
 for fam in f:
@@ -42,6 +61,21 @@ out['note'] = ('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate pass
                '--no-cpu-baseline --no-post`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per '
                '128-B request); counters in KiB; averages over every launch of the kernel family (tile kernel + k-sliced kernel; gemm_f16x3 = the '
                'default two-plane fp16 mode, gemm_bf16s = the bf16x6 instantiations, here the two vid_map products)')
+# byte budget of one whole forward (every kernel family), when the run was single-stream (tools/pmc_traffic.sh passes
+# --videos 1 --batch 8: eight videos per forward, one forward at a time)
+ff, nf = last_forward(sys.argv[1], 'FETCH_SIZE')
+fw_, nw = last_forward(sys.argv[2], 'WRITE_SIZE')
+if ff and nf == nw:
+    by = {}
+    for n in ff:
+        fetch = 2.0 * 1024.0 * ff[n]['kib']
+        write = 1024.0 * fw_.get(n, {'kib': 0.0})['kib']
+        by[n] = {'launches': ff[n]['launches'], 'fetch_bytes_x2': fetch, 'write_bytes': write, 'hbm_bytes': fetch + write}
+    by = dict(sorted(by.items(), key=lambda kv: -kv[1]['hbm_bytes']))
+    videos = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+    out['forward'] = {'videos': videos, 'dispatches': nf, 'hbm_bytes': sum(v['hbm_bytes'] for v in by.values()), 'by_kernel': by,
+                      'note': 'FETCH_SIZE x2 + WRITE_SIZE of every dispatch of the LAST forward of the run (from its sidekick-scoring kernel '
+                              'to the end of the trace), summed by kernel; HBM / Infinity-Fabric side of L2, i.e. what the kernels miss in L2'}
 import bench  # noqa: E402  (csrc_hash: bench.py only quotes this summary for the same kernel sources)
 out['csrc_sha16'] = bench.csrc_hash()
 print(json.dumps(out, indent=1))

@@ -9,6 +9,6 @@ tag=${1:-r03}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/solo_$tag
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/solo_$tag -- python3 $R/bench.py --videos 1 --batch 8 --steps 10 --warmup 3 --no-cpu-baseline --no-post > $R/gpurun_out/${tag}_bench_n1_solo.json 2> /tmp/solo_$tag.err || { tail -20 /tmp/solo_$tag.err; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/solo_$tag -- python3 $R/bench.py --videos 1 --batch 8 --steps 10 --warmup 3 --min-timed-s 0 --no-cpu-baseline --no-post > $R/gpurun_out/${tag}_bench_n1_solo.json 2> /tmp/solo_$tag.err || { tail -20 /tmp/solo_$tag.err; exit 1; }
 cp $(ls /tmp/solo_$tag/*/*kernel_stats.csv | head -1) $R/gpurun_out/${tag}_bench_n1_solo_kernel_stats.csv
 cd $R && python3 tools/solo_check.py gpurun_out/${tag}_bench_n1_solo_kernel_stats.csv gpurun_out/${tag}_bench_n1_solo.json | tee gpurun_out/${tag}_solo_check.txt
