@@ -23,7 +23,7 @@ class DcfConfig(ctypes.Structure):
                                    'n_stem', 'n_levels', 'win', 'head_layers', 'sn')] + \
                [('sratio', f32)] + [(n, i32) for n in ('msf', 'norm', 'use_abs_pe', 'max_batch', 'gemm_mode', 'model_kind', 'second_fusion',
                                                       'text_in', 'text_layers', 'text_heads', 'text_abs_pe', 'text_bkgd',
-                                                      'scat', 'sfonly', 'text_kind')]
+                                                      'scat', 'sfonly', 'text_kind', 'xattn_affine')]
 
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
@@ -45,6 +45,11 @@ SIGNATURES = {
     'dcf_forward_eval_videos': (i32, [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), i64, ctypes.POINTER(i32),
                                       ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(i32), ctypes.POINTER(vp),
                                       c_f32p, c_f32p, c_u8p, vp]),
+    'dcf_forward_train_videos': (i32, [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), i64, ctypes.POINTER(i32),
+                                       ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(i32), ctypes.POINTER(vp),
+                                       c_f32p, c_f32p, c_f32p, c_u8p, vp]),
+    'dcf_sigmoid_focal_loss': (i32, [c_f32p, c_f32p, c_u8p, i64, f32, f32, i32, c_f32p, c_f32p, c_i32p, vp]),
+    'dcf_ctr_iou_loss': (i32, [c_f32p, c_f32p, c_u8p, i64, i32, f32, c_f32p, c_f32p, c_i32p, vp]),
     'dcf_forward_eval_gated': (i32, [vp, c_f32p, c_f32p, c_u8p, i64, i32, ctypes.POINTER(vp), ctypes.POINTER(vp),
                                      ctypes.POINTER(i32), c_f32p, c_f32p, c_f32p, c_u8p, vp]),
     'dcf_debug_copy': (i32, [vp, i32, c_f32p, i64, vp]),
@@ -60,6 +65,7 @@ SIGNATURES = {
     'dcf_op_linear_split': (i32, [c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, i32, i32, vp]),
     'dcf_op_linear_cm': (i32, [c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, vp]),
     'dcf_op_linear_ln': (i32, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, i32, i32, vp]),
+    'dcf_op_linear_ln_carry': (i32, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, i32, i32, i32, vp]),
     'dcf_op_linear_cm_split': (i32, [c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, i32, vp]),
     'dcf_op_conv3': (i32, [c_f32p, c_u8p, c_f32p, c_f32p, i32, i32, i32, i32, vp]),
     'dcf_op_conv3_split': (i32, [c_f32p, c_u8p, c_f32p, c_f32p, i32, i32, i32, i32, i32, vp]),

@@ -15,9 +15,15 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libdecafnet_hip.so')
-SOURCES = ['engine.hip', 'gemm.hip', 'gemm_bf16s.hip', 'rowops.hip', 'attn.hip', 'score.hip', 'heads.hip', 'postproc.hip']
+SOURCES = ['engine.hip', 'gemm.hip', 'gemm_bf16s.hip', 'rowops.hip', 'attn.hip', 'score.hip', 'heads.hip', 'postproc.hip', 'loss.hip']
 ARCH = 'gfx950'
 FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
+
+
+# per-file flags.  gemm_bf16s.hip: no SLP vectorisation -- it packs adjacent fp32 epilogue operations into v_pk_fma_f32 /
+# v_pk_mul_f32, which are slower than the scalar pair on this part (MI355X_MICROARCH.md, per-instruction constants) and, in the
+# row-statistics epilogue, produced sporadically wrong low halves in lanes 48-63 (tools/dbg_carry.py; scalar code is exact)
+EXTRA = {'gemm_bf16s.hip': ['-fno-slp-vectorize']}
 
 
 def hipcc():
@@ -45,7 +51,7 @@ def build(force=False, verbose=False):
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace('.hip', '.o'))
         if force or _stale(obj, [src] + headers):
-            jobs.append([cc] + FLAGS + ['-c', src, '-o', obj])
+            jobs.append([cc] + FLAGS + EXTRA.get(s, []) + ['-c', src, '-o', obj])
 
     def run(cmd):
         if verbose:

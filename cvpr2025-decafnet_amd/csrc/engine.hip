@@ -94,6 +94,18 @@ __global__ void k_masks_out(const uint8_t* __restrict__ mask_all, uint8_t* __res
   if (status && (status[0] & 1u)) logits[o] = __uint_as_float(0x7fc00000u);
 }
 
+// out[b][off_l + t] = rows[start_l + b*T_l + t]: a per-point value of the pyramid from level-major to query-major order
+__global__ void k_points_out(const float* __restrict__ rows, float* __restrict__ out, const LevelTable* lt) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = lt->start[lt->n_levels];
+  if (r >= total) return;
+  int l = 0;
+  while (l + 1 < lt->n_levels && r >= lt->start[l + 1]) ++l;
+  const int rel = r - lt->start[l];
+  const int b = rel / lt->T[l], t = rel - b * lt->T[l];
+  out[(int64_t)b * lt->S + lt->off[l] + t] = rows[r];
+}
+
 // gate[b][t] = override[q0 + b][t]; mask = vid_mask (msf) or vid_mask & gate (model.py:544-545)
 __global__ void k_apply_gate(const float* __restrict__ gate_in, const uint8_t* __restrict__ vid_mask, float* __restrict__ gate,
                              uint8_t* __restrict__ mask_out, int T, int rows, int msf) {
@@ -104,6 +116,25 @@ __global__ void k_apply_gate(const float* __restrict__ gate_in, const uint8_t* _
   const bool m = vid_mask[t] != 0;
   gate[r] = g;
   mask_out[r] = msf ? m : (m && g != 0.f);
+}
+
+// LayerNorm folded into the 1x1 convolution that consumes it (GemmArgs::stats_in): Wf[n][k] = W[n][k] g[k],
+// s[n] = sum_k Wf[n][k], c[n] = bias[n] + sum_k beta[k] W[n][k].  One wave per output channel.
+__global__ __launch_bounds__(64) void k_fold_ln(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ g,
+                                                const float* __restrict__ beta, float* __restrict__ Wf, float* __restrict__ s,
+                                                float* __restrict__ c, int K) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  float a1 = 0.f, a2 = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float w = W[(int64_t)n * K + k];
+    const float wf = w * g[k];
+    Wf[(int64_t)n * K + k] = wf;
+    a1 += wf;
+    a2 += beta[k] * w;
+  }
+  a1 = wave_sum(a1);
+  a2 = wave_sum(a2);
+  if (lane == 0) { s[n] = a1; c[n] = (bias ? bias[n] : 0.f) + a2; }
 }
 
 struct Bound {
@@ -120,12 +151,14 @@ struct EncW {   // one TransformerEncoder of vid_net
   const float *ln_attn_w, *ln_attn_b, *dw_q, *dw_k, *dw_v, *qn_w, *qn_b, *kn_w, *kn_b, *vn_w, *vn_b;
   const float *wq, *bq, *wk, *bk, *wv, *bv, *wp, *bp, *ls_attn;
   const float *ln_ffn_w, *ln_ffn_b, *fc_w, *fc_b, *pj_w, *pj_b, *ls_ffn;
+  const float *fc_wf, *fc_s, *fc_c;          // ffn.fc with ln_ffn folded in (k_fold_ln); nullptr where not built
 };
 struct DecW {   // one TransformerDecoder of the fusion
   const float *ln_q_w, *ln_q_b, *ln_kv_w, *ln_kv_b, *dw, *qn_w, *qn_b;
   const float *wq, *bq, *wk, *bk, *wv, *bv, *wp, *bp;
   const float *wp_il, *bp_il;                // xattn.proj with its output rows in blocks of (32 scale rows, 32 shift rows of the same channels)
   const float *ln_ffn_w, *ln_ffn_b, *fc_w, *fc_b, *pj_w, *pj_b, *ls_ffn;
+  const float *fc_wf, *fc_s, *fc_c;          // ffn.fc with ln_ffn folded in
 };
 struct TextEncW {   // one TransformerEncoder of text_net (stride 0: no depthwise convs, global attention)
   const float *ln_attn_w, *ln_attn_b, *wq, *bq, *wk, *bk, *wv, *bv, *wp, *bp, *ls_attn;
@@ -284,6 +317,19 @@ static int split_weight(dcf_model* m, const float* W, int N, int K, hipStream_t 
 }
 #define SPLIT(W, N, K) do { if (split_weight(m, (W), (N), (K), st)) return -1; } while (0)
 
+// the (N, K) weight W / bias of a 1x1 convolution behind LayerNorm(g, beta): folded copies owned by the model (+ weight image)
+static int fold_ln(dcf_model* m, const float* W, const float* bias, const float* g, const float* beta, int N, int K, hipStream_t st,
+                   const float** wf, const float** s_out, const float** c_out) {
+  float* buf = nullptr;
+  DCF_HIP(hipMalloc(&buf, ((size_t)N * K + 2 * (size_t)N) * sizeof(float)));
+  m->owned.push_back(buf);
+  float* sv = buf + (size_t)N * K;
+  hipLaunchKernelGGL(k_fold_ln, dim3(N), dim3(64), 0, st, W, bias, g, beta, buf, sv, sv + N, K);
+  DCF_HIP(hipGetLastError());
+  *wf = buf; *s_out = sv; *c_out = sv + N;
+  return split_weight(m, buf, N, K, st);
+}
+
 #define GET(name, shape, dst) do { if (get(m, (name), shape, &(dst))) return -1; } while (0)
 #define SH(...) std::initializer_list<int64_t>{__VA_ARGS__}
 
@@ -307,6 +353,8 @@ static int resolve_encoder(dcf_model* m, const std::string& p, int E, hipStream_
   GET(p + ".drop_path_ffn.scale", SH(E), w.ls_ffn);
   SPLIT(w.wq, E, E); SPLIT(w.wk, E, E); SPLIT(w.wv, E, E); SPLIT(w.wp, E, E);
   SPLIT(w.fc_w, 4 * E, E); SPLIT(w.pj_w, E, 4 * E);
+  w.fc_wf = w.fc_s = w.fc_c = nullptr;
+  if (m->gemm_terms != 0 && E % 64 == 0 && fold_ln(m, w.fc_w, w.fc_b, w.ln_ffn_w, w.ln_ffn_b, 4 * E, E, st, &w.fc_wf, &w.fc_s, &w.fc_c)) return -1;
   return 0;
 }
 
@@ -327,6 +375,8 @@ static int resolve_decoder(dcf_model* m, const std::string& p, int E, int TE, hi
   GET(p + ".drop_path_ffn.scale", SH(E), w.ls_ffn);
   SPLIT(w.wq, E, E); SPLIT(w.wk, E, TE); SPLIT(w.wv, E, TE); SPLIT(w.wp, 2 * E, E);
   SPLIT(w.fc_w, 4 * E, E); SPLIT(w.pj_w, E, 4 * E);
+  w.fc_wf = w.fc_s = w.fc_c = nullptr;
+  if (m->gemm_terms != 0 && E % 128 == 0 && fold_ln(m, w.fc_w, w.fc_b, w.ln_ffn_w, w.ln_ffn_b, 4 * E, E, st, &w.fc_wf, &w.fc_s, &w.fc_c)) return -1;
   // the same projection for the GEMM that applies the modulation in its epilogue (G_ADALN): rows (2, E / 32, 32) -> (E / 32, 2, 32)
   w.wp_il = w.bp_il = nullptr;
   if (E % 32 == 0) {
@@ -577,6 +627,7 @@ struct Buffers {
   float *P1, *P2, *tn, *partial, *correl, *gate;
   uint8_t *mask_all, *nbr_all, *kvmask, *maskv;
   float *X, *R[7], *H2, *HID, *F, *HA, *HB, *HC, *HD, *logits1, *tcnA, *tcnB, *kvn, *Kt, *Vt;
+  float* stats;                               // [rows][E / 64] (sum, sum of squares): row statistics carried between GEMMs
 };
 
 static void carve(Arena& a, const dcf_config& c, int T0, int B, int nq, int S, int Lk, int nvid, Buffers& b) {
@@ -595,6 +646,7 @@ static void carve(Arena& a, const dcf_config& c, int T0, int B, int nq, int S, i
   b.kvmask = a.take<uint8_t>((size_t)B * Lk);
   b.X = a.take<float>(rows0 * E);
   for (int i = 0; i < 7; ++i) b.R[i] = a.take<float>((i < 3 ? rowsF : rows0) * E);
+  b.stats = a.take<float>(rowsF * (size_t)((E + 63) / 64) * 2);
   b.H2 = a.take<float>(rowsF * 2 * E);
   b.HID = a.take<float>(rowsF * 4 * E);
   b.F = a.take<float>(rowsAll * EH);
@@ -663,12 +715,24 @@ static int run_gemm(dcf_model* m, GemmArgs* g, int count, GemmAMode mode, hipStr
 }
 
 // FFN (blocks.py:535-538): fc with the erf GELU in its epilogue, then proj (`go`: residual / LayerScale / mask epilogue)
+constexpr int STATS_W = 64;
+// stats != nullptr: X holds the RAW rows, fc_w / fc_b are the LayerNorm-folded weight and bias and ln_s its row sums; the row
+// statistics come from the GEMM that produced X (GemmArgs::stats_in)
 static int run_ffn(dcf_model* m, const float* X, const float* fc_w, const float* fc_b, GemmArgs go, float* HID, int rows, int E,
-                   hipStream_t st) {
+                   hipStream_t st, const float* stats = nullptr, const float* ln_s = nullptr) {
   GemmArgs gf = gemm(X, E, fc_w, fc_b, HID, 4 * E, rows, 4 * E, E);
   gf.flags = G_GELU;
+  if (stats) { gf.stats_in = stats; gf.ln_s = ln_s; gf.stats_slots = E / STATS_W; gf.stats_w = STATS_W; }
   TRY(run_gemm(m, &gf, 1, A_ROWS, st));
   return run_gemm(m, &go, 1, A_ROWS, st);
+}
+
+// can the LayerNorm between a producer GEMM (rows x n_prod, K = k_prod) and the ffn.fc that consumes it ride as row statistics?
+static bool can_carry_ln(dcf_model* m, const float* fc_wf, int rows, int n_prod, int k_prod, int E) {
+  static const bool off = getenv("DCF_NO_LN_CARRY") != nullptr;      // developer switch: standalone LayerNorm launches instead
+  if (off || !fc_wf || m->gemm_terms == 0 || !m->wsplit.count(fc_wf)) return false;
+  const int terms = m->wsplit_terms[fc_wf];
+  return gemm_can_carry_stats(rows, n_prod, k_prod, 1, terms) && gemm_can_carry_stats(rows, 4 * E, E, 1, terms);
 }
 
 // can this GEMM carry its LayerNorm in the epilogue?  (bf16-split path with planes for W, tile spanning the row)
@@ -700,17 +764,23 @@ static int run_encoder(dcf_model* m, const EncW& w, Buffers& b, const float* Xin
   GemmArgs gp = gemm(b.R[0], E, w.wp, w.bp, b.R[1], E, rows, E, E);
   gp.flags = G_RES | G_RES_MASK; gp.rowmask = mask_out; gp.ls = w.ls_attn;
   if (stride == 2) { gp.R = b.R[3]; gp.ldr = E; } else { gp.R = Xin; gp.ldr = ldx; }
+  // out = x' + ls_ffn * ((ffn) * mask)                                  (blocks.py:589-590)
+  GemmArgs go = gemm(b.HID, 4 * E, w.pj_w, w.pj_b, Xout, ldo, rows, E, 4 * E);
+  go.flags = G_RES | G_OUT_MASK; go.rowmask = mask_out; go.ls = w.ls_ffn; go.R = b.R[1]; go.ldr = E;
   if (can_fuse_ln(m, w.wp, rows, E, E, A_ROWS)) {                 // ln_ffn(x') rides in the epilogue
     gp.ln_w = w.ln_ffn_w; gp.ln_b = w.ln_ffn_b; gp.Y = b.R[2]; gp.ldy = E;
     TRY(run_gemm(m, &gp, 1, A_ROWS, st));
+  } else if (can_carry_ln(m, w.fc_wf, rows, E, E, E)) {
+    // ... or as row statistics: the projection writes (sum, sum of squares) of every x' row, ffn.fc runs on the raw x' with
+    // ln_ffn folded into its weights and applies (mean, rstd) in its epilogue -- ln_ffn(x') is neither written nor read
+    gp.stats_out = b.stats; gp.stats_w = STATS_W;
+    TRY(run_gemm(m, &gp, 1, A_ROWS, st));
+    return run_ffn(m, b.R[1], w.fc_wf, w.fc_c, go, b.HID, rows, E, st, b.stats, w.fc_s);
   } else {
     TRY(run_gemm(m, &gp, 1, A_ROWS, st));
     LnArgs ln{}; ln.X = b.R[1]; ln.ldx = E; ln.Y = b.R[2]; ln.ldy = E; ln.w = w.ln_ffn_w; ln.b = w.ln_ffn_b; ln.rows = rows; ln.C = E;
     TRY(launch_ln(ln, st));
   }
-  // out = x' + ls_ffn * ((ffn) * mask)                                  (blocks.py:589-590)
-  GemmArgs go = gemm(b.HID, 4 * E, w.pj_w, w.pj_b, Xout, ldo, rows, E, 4 * E);
-  go.flags = G_RES | G_OUT_MASK; go.rowmask = mask_out; go.ls = w.ls_ffn; go.R = b.R[1]; go.ldr = E;
   TRY(run_ffn(m, b.R[2], w.fc_w, w.fc_b, go, b.HID, rows, E, st));
   return 0;
 }
@@ -815,8 +885,10 @@ static int run_fusion(dcf_model* m, Buffers& b, float* X, int64_t ldx, int B, in
   const int rows = lt ? lt->start[lt->n_levels] : B * T;
   for (size_t li = 0; li < m->dec.size(); ++li) {
     const DecW& w = m->dec[li];
+    bool carry = false;
     DecPreArgs dp{X, ldx, mask, w.ln_q_w, w.ln_q_b, w.dw, w.qn_w, w.qn_b, b.R[0], b.R[1], lt ? 1 : B, lt ? rows : T, E};
     dp.nbr = lt ? nbr : nullptr;
+    dp.affine = c.xattn_affine;
     TRY(launch_dec_pre(dp, st));
     GemmArgs gq = gemm(b.R[0], E, w.wq, w.bq, b.R[2], E, rows, E, E);
     TRY(run_gemm(m, &gq, 1, A_ROWS, st));
@@ -838,9 +910,13 @@ static int run_fusion(dcf_model* m, Buffers& b, float* X, int64_t ldx, int B, in
       // never written; Xn = ln_ffn(q3) by the LayerNorm kernel
       GemmArgs gh = gemm(b.R[0], E, w.wp_il, w.bp_il, b.R[2], E, rows, 2 * E, E);
       gh.flags = G_ADALN; gh.R = b.R[1]; gh.ldr = E;
+      carry = can_carry_ln(m, w.fc_wf, rows, 2 * E, E, E);            // ln_ffn(q3) as row statistics (see run_encoder)
+      if (carry) { gh.stats_out = b.stats; gh.stats_w = STATS_W; }
       TRY(run_gemm(m, &gh, 1, A_ROWS, st));
-      LnArgs ln{}; ln.X = b.R[2]; ln.ldx = E; ln.Y = b.R[0]; ln.ldy = E; ln.w = w.ln_ffn_w; ln.b = w.ln_ffn_b; ln.rows = rows; ln.C = E;
-      TRY(launch_ln(ln, st));
+      if (!carry) {
+        LnArgs ln{}; ln.X = b.R[2]; ln.ldx = E; ln.Y = b.R[0]; ln.ldy = E; ln.w = w.ln_ffn_w; ln.b = w.ln_ffn_b; ln.rows = rows; ln.C = E;
+        TRY(launch_ln(ln, st));
+      }
     } else {
       GemmArgs gh = gemm(b.R[0], E, w.wp, w.bp, b.H2, 2 * E, rows, 2 * E, E);
       TRY(run_gemm(m, &gh, 1, A_ROWS, st));
@@ -848,16 +924,19 @@ static int run_fusion(dcf_model* m, Buffers& b, float* X, int64_t ldx, int B, in
     }
     GemmArgs go = gemm(b.HID, 4 * E, w.pj_w, w.pj_b, X, ldx, rows, E, 4 * E);
     go.flags = G_RES | G_OUT_MASK; go.rowmask = mask; go.ls = w.ls_ffn; go.R = b.R[2]; go.ldr = E;
+    const float* fc_in = carry ? b.R[2] : b.R[0];
+    const float *fc_w = carry ? w.fc_wf : w.fc_w, *fc_b = carry ? w.fc_c : w.fc_b;
     if (li + 1 == m->dec.size() && m->fus_out_w && can_fuse_ln(m, w.pj_w, rows, E, 4 * E, A_ROWS)) {
       // last layer: only ln_out(x) is consumed afterwards (fusion.py:64-66), the raw stream is not written
-      GemmArgs gf = gemm(b.R[0], E, w.fc_w, w.fc_b, b.HID, 4 * E, rows, 4 * E, E);
+      GemmArgs gf = gemm(fc_in, E, fc_w, fc_b, b.HID, 4 * E, rows, 4 * E, E);
       gf.flags = G_GELU;
+      if (carry) { gf.stats_in = b.stats; gf.ln_s = w.fc_s; gf.stats_slots = E / STATS_W; gf.stats_w = STATS_W; }
       TRY(run_gemm(m, &gf, 1, A_ROWS, st));
       go.C = nullptr; go.ln_w = m->fus_out_w; go.ln_b = m->fus_out_b; go.Y = out; go.ldy = ld_out;
       TRY(run_gemm(m, &go, 1, A_ROWS, st));
       return 0;
     }
-    TRY(run_ffn(m, b.R[0], w.fc_w, w.fc_b, go, b.HID, rows, E, st));
+    TRY(run_ffn(m, fc_in, fc_w, fc_b, go, b.HID, rows, E, st, carry ? b.stats : nullptr, w.fc_s));
   }
   if (!m->fus_out_w) return 0;          // dcf_op_decoder: the bare layer stack, result left in X
   LnArgs ln{}; ln.X = X; ln.ldx = ldx; ln.Y = out; ln.ldy = ld_out; ln.w = m->fus_out_w; ln.b = m->fus_out_b; ln.rows = rows; ln.C = E;
@@ -877,6 +956,7 @@ struct VideoSet {
   const uint8_t* mask[DCF_MAX_VIDEOS];
   const float* text_cls[DCF_MAX_VIDEOS];      // (nq[v], D); with gate_override: the gate (nq, T)
   int nq[DCF_MAX_VIDEOS];
+  float* logits1_out = nullptr;               // optional (nq, S): the logits of the first cls_head (fpn_logits1, model.py:445,471)
 };
 
 static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
@@ -1067,6 +1147,11 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
     } else {
     // ---- heads: fuse_and_predict (model.py:442-471)
     TRY(run_head(m, m->cls1, b, *pl, E, 1, 0, 0, b.logits1, st));
+    if (vs.logits1_out) {
+      hipLaunchKernelGGL(k_points_out, dim3((rowsAll + 255) / 256), dim3(256), 0, st, (const float*)b.logits1,
+                         vs.logits1_out + (int64_t)q0 * S, (const LevelTable*)pl->d_lt);
+      DCF_HIP(hipGetLastError());
+    }
     {
       RefineArgs ra{};
       ra.logits1 = b.logits1; ra.lt = pl->d_lt; ra.mask_all = b.mask_all;
@@ -1212,7 +1297,7 @@ namespace dcf {
 static int forward_graph_on(dcf_model* m, const VideoSet& vs, int T0, int nq,
                             const float* const* text, const uint8_t* const* text_mask, const int32_t* text_len,
                             const float* gate, float* lo, float* oo, uint8_t* mo, hipStream_t st) {
-  std::vector<uint64_t> key = {(uint64_t)vs.nvid, (uint64_t)T0, (uint64_t)nq,
+  std::vector<uint64_t> key = {(uint64_t)vs.nvid, (uint64_t)T0, (uint64_t)nq, (uint64_t)vs.logits1_out,
                                (uint64_t)gate, (uint64_t)lo, (uint64_t)oo, (uint64_t)mo, (uint64_t)st, (uint64_t)m->pe, (uint64_t)m->pe_T};
   for (int v = 0; v < vs.nvid; ++v) {
     key.push_back((uint64_t)vs.vid[v]); key.push_back((uint64_t)vs.shallow[v]); key.push_back((uint64_t)vs.mask[v]);
@@ -1377,6 +1462,28 @@ int dcf_forward_eval_videos(dcf_model* m, int32_t nvid, const float* const* vid,
     nq += nq_per_video[v];
   }
   return dcf::forward_maybe_graph(m, vs, (int)T, nq, text, text_mask, text_len, nullptr, logits_out, offsets_out, masks_out,
+                                  (hipStream_t)stream);
+}
+
+int dcf_forward_train_videos(dcf_model* m, int32_t nvid, const float* const* vid, const float* const* shallow_vid,
+                             const uint8_t* const* vid_mask, int64_t T, const int32_t* nq_per_video, const float* const* text,
+                             const uint8_t* const* text_mask, const int32_t* text_len, const float* const* text_cls,
+                             float* logits1_out, float* logits2_out, float* offsets_out, uint8_t* masks_out, void* stream) {
+  DCF_CHECK(m && vid && shallow_vid && vid_mask && nq_per_video && text && text_len && text_cls && logits1_out && logits2_out && offsets_out && masks_out,
+            "dcf_forward_train_videos: null argument");
+  DCF_CHECK(m->cfg.model_kind == 0, "dcf_forward_train_videos: the iterative early-fusion model only (model.py:567-632)");
+  DCF_CHECK(nvid >= 1 && nvid <= dcf::DCF_MAX_VIDEOS, "dcf_forward_train_videos: 1 .. %d videos per call", dcf::DCF_MAX_VIDEOS);
+  DCF_CHECK(T < (1ll << 24), "T too large");
+  dcf::VideoSet vs;
+  vs.nvid = nvid;
+  vs.logits1_out = logits1_out;
+  int nq = 0;
+  for (int v = 0; v < nvid; ++v) {
+    DCF_CHECK(vid[v] && shallow_vid[v] && vid_mask[v] && text_cls[v] && nq_per_video[v] >= 1, "dcf_forward_train_videos: video %d is incomplete", v);
+    vs.vid[v] = vid[v]; vs.shallow[v] = shallow_vid[v]; vs.mask[v] = vid_mask[v]; vs.text_cls[v] = text_cls[v]; vs.nq[v] = nq_per_video[v];
+    nq += nq_per_video[v];
+  }
+  return dcf::forward_maybe_graph(m, vs, (int)T, nq, text, text_mask, text_len, nullptr, logits2_out, offsets_out, masks_out,
                                   (hipStream_t)stream);
 }
 
@@ -1556,6 +1663,39 @@ int dcf_op_linear_ln(const float* A, const float* W, const float* bias, const fl
     rc = dcf::launch_gemm_split(&g, 1, dcf::A_ROWS, nterms, st);
   }
   DCF_HIP(hipFreeAsync(planes, st));
+  return rc;
+}
+
+int dcf_op_linear_ln_carry(const float* A, const float* W1, const float* b1, const float* R, const float* ln_w, const float* ln_b,
+                           const float* W2, const float* b2, float* X, float* Y, int32_t M, int32_t N1, int32_t K1, int32_t N2,
+                           int32_t gelu, int32_t nterms, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DCF_CHECK(A && W1 && ln_w && ln_b && W2 && X && Y, "dcf_op_linear_ln_carry: null argument");
+  DCF_CHECK(N1 % 64 == 0 && dcf::gemm_can_carry_stats(M, N1, K1, 1, nterms) && dcf::gemm_can_carry_stats(M, N2, N1, 1, nterms),
+            "dcf_op_linear_ln_carry: %dx%dx%d -> %d runs on the k-sliced kernel (no row statistics there)", M, N1, K1, N2);
+  unsigned short *p1 = nullptr, *p2 = nullptr;
+  float *wf = nullptr, *stats = nullptr;
+  DCF_HIP(hipMallocAsync((void**)&p1, (size_t)3 * N1 * K1 * sizeof(unsigned short), st));
+  DCF_HIP(hipMallocAsync((void**)&p2, (size_t)3 * N2 * N1 * sizeof(unsigned short), st));
+  DCF_HIP(hipMallocAsync((void**)&wf, ((size_t)N2 * N1 + 2 * (size_t)N2) * sizeof(float), st));
+  DCF_HIP(hipMallocAsync((void**)&stats, (size_t)M * (N1 / 64) * 2 * sizeof(float), st));
+  float* sv = wf + (size_t)N2 * N1;
+  hipLaunchKernelGGL(dcf::k_fold_ln, dim3(N2), dim3(64), 0, st, W2, b2, ln_w, ln_b, wf, sv, sv + N2, N1);
+  int rc = dcf::launch_split_planes(W1, p1, N1, K1, K1, st, nterms);
+  if (rc == 0) rc = dcf::launch_split_planes(wf, p2, N2, N1, N1, st, nterms);
+  if (rc == 0) {
+    dcf::GemmArgs g = dcf::gemm(A, K1, W1, b1, X, N1, M, N1, K1);
+    g.Ws = p1; g.stats_out = stats; g.stats_w = 64;
+    if (R) { g.flags = dcf::G_RES; g.R = R; g.ldr = N1; }
+    rc = dcf::launch_gemm_split(&g, 1, dcf::A_ROWS, nterms, st);
+  }
+  if (rc == 0) {
+    dcf::GemmArgs g = dcf::gemm(X, N1, wf, sv + N2, Y, N2, M, N2, N1);
+    g.Ws = p2; g.flags = gelu ? dcf::G_GELU : 0;
+    g.stats_in = stats; g.ln_s = sv; g.stats_slots = N1 / 64; g.stats_w = 64;
+    rc = dcf::launch_gemm_split(&g, 1, dcf::A_ROWS, nterms, st);
+  }
+  DCF_HIP(hipFreeAsync(p1, st)); DCF_HIP(hipFreeAsync(p2, st)); DCF_HIP(hipFreeAsync(wf, st)); DCF_HIP(hipFreeAsync(stats, st));
   return rc;
 }
 

@@ -52,6 +52,19 @@ struct GemmArgs {
   const float* ln_pe;      // optional (ln_T, N) position encoding added where ln_mask != 0
   const uint8_t* ln_mask;  // [M] (with ln_pe)
   int ln_T;
+  // Row statistics carried between GEMMs instead of a LayerNorm pass (split tile kernels with the 16-byte epilogue only,
+  // gemm_can_carry_stats).  Producer: stats_out [M][n_out / stats_w] float2 receives, per output row and per block of
+  // stats_w columns, the partial (sum, sum of squares) of the values written to C (a workgroup tile fills the first slot it
+  // covers and zeroes the others, so a consumer adds up all slots of a row whatever tile produced them).  Consumer: A holds
+  // the RAW rows x, W is the weight with the LayerNorm gain folded in (W'[n][k] = W[n][k] g[k]), ln_s[n] = sum_k W'[n][k],
+  // bias[n] = b[n] + sum_k beta[k] W[n][k]; with (mean, rstd) of row m from stats_in (stats_slots slots, K channels)
+  //   acc'[m][n] = rstd[m] (acc[m][n] - mean[m] ln_s[n])        ( = sum_k LN(x)[m][k] g[k] W[n][k] without the beta term)
+  // replaces acc before bias / activation / residual: LayerNorm(x) W^T + b without reading or writing LayerNorm(x).
+  float* stats_out;
+  int stats_w;             // columns per statistics slot (64; a tile's BN must be a multiple)
+  const float* stats_in;   // [M][stats_slots] float2
+  const float* ln_s;       // [N]
+  int stats_slots;
   // f16x3 mode: sticky device word, bit 0 is set when an accumulator leaves the finite range (an operand overflowed the
   // fp16 range, or the inputs already held inf / NaN); nullptr = not reported
   unsigned* status;
@@ -76,5 +89,8 @@ bool gemm_can_fuse_ln(int M, int N, int K, GemmAMode mode);
 // true if launch_gemm_split runs an A_ROWS GEMM of this shape with a tile kernel that implements G_ADALN (not the k-sliced
 // kernel of the small grids)
 bool gemm_can_fuse_adaln(int M, int N, int K);
+// true if launch_gemm_split runs `count` A_ROWS GEMMs of this shape in mode `nterms` with a tile kernel whose epilogue can
+// write (stats_out) / consume (stats_in) row statistics: not the k-sliced kernel, tile width a multiple of 64 columns
+bool gemm_can_carry_stats(int M, int N, int K, int count, int nterms);
 
 }  // namespace dcf

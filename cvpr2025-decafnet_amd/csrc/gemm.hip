@@ -253,6 +253,7 @@ int launch_gemm(const GemmArgs* g, int count, GemmAMode mode, hipStream_t stream
     if (mode == A_ROWS_TAP3) DCF_CHECK(g[i].nbr && g[i].cin % 32 == 0 && g[i].K == 3 * g[i].cin, "launch_gemm: bad tap3 args");
     if (g[i].flags & (G_AMASK | G_RES_MASK | G_OUT_MASK)) DCF_CHECK(g[i].rowmask, "launch_gemm: rowmask missing");
     if (g[i].flags & G_RES) DCF_CHECK(g[i].R, "launch_gemm: residual missing");
+    DCF_CHECK(!g[i].stats_out && !g[i].stats_in, "launch_gemm: row statistics are carried by the split kernels only");
   }
   if (p.M <= 0) return 0;
   DCF_CHECK(p.K > 0 && p.K % 32 == 0, "launch_gemm: K=%d must be a positive multiple of 32", p.K);

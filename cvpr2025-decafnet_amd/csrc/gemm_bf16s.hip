@@ -149,7 +149,8 @@ int launch_split_planes(const float* W, unsigned short* out, int N, int K, int64
 // during step kt.  One K step is only 12 (64x32 wave tile, f16x3) .. 48 MFMAs = 400 .. 1500 cycles while an L2 /
 // Infinity Cache hit takes ~1000 and HBM ~2000+, and at T = 16384 most grids give one wave per SIMD, so nothing but
 // the prefetch distance hides that latency.  Buffers are indexed statically (steps unrolled in groups of NST).
-template <int WM, int WN, int TM, int TN, int AMODE, int NTERMS, bool LN = false, int NST = 3>
+// STATS = true: the instantiation whose epilogue writes / consumes row statistics (GemmArgs::stats_out / stats_in)
+template <int WM, int WN, int TM, int TN, int AMODE, int NTERMS, bool LN = false, int NST = 3, bool STATS = false>
 __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4 || (NST > 2 && TM * TN >= 4)) ? 2 : 3)) void gemm_bf16s_kernel(GemmBatch batch) {
   constexpr int NT = WM * WN * 64;                    // 4 or 8 wavefronts
   constexpr int BM = WM * TM * 32;
@@ -164,6 +165,9 @@ __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4 || (NST > 2
 
   extern __shared__ unsigned char smem_b[];
   unsigned char* As = smem_b;                          // [NPL][BM][ROWB]: the only LDS tile (A is shared by the N-waves)
+  // row-statistics block of the workgroup: behind the A tile and behind the epilogue's transpose tiles
+  constexpr int WG_OFF = (NPL * BM * ROWB > WM * WN * EPI_WAVE_FLOATS * 4 ? NPL * BM * ROWB : WM * WN * EPI_WAVE_FLOATS * 4);
+  float* wg_stats = reinterpret_cast<float*>(smem_b + WG_OFF);
 
   const GemmArgs p = LN ? batch.g[0] : (blockIdx.z == 0 ? batch.g[0] : (blockIdx.z == 1 ? batch.g[1] : batch.g[2]));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -174,6 +178,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4 || (NST > 2
   const int M = p.M, K = p.K;
   const int KT = K / SBK;
   const float sa = a_scale_of(p);
+  if constexpr (STATS) { if (p.stats_in) stats_load<BM, NT>(p, wg_stats, m0, tid); }     // uniform
 
   // K-invariant addressing (see gemm.hip: nothing but 16-byte loads inside the K loop)
   // A_ROWS / TAP3: thread -> (row, 8-float piece); A_CHANMAJOR (A[m][k] = X[k*lda + m]): thread -> (k pair p, 4 rows)
@@ -349,10 +354,10 @@ __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4 || (NST > 2
   } else {
     if (p.flags & G_ADALN) {                            // uniform
       __syncthreads();
-      gemm_epilogue_adaln<WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, lane, reinterpret_cast<float*>(smem_b) + wave * EPI_WAVE_FLOATS);
+      gemm_epilogue_adaln<WM, WN, TM, TN, STATS>(p, acc, m0, n0, wm, wn, lane, reinterpret_cast<float*>(smem_b) + wave * EPI_WAVE_FLOATS, wg_stats);
     } else if (gemm_wide_ok(p)) {                       // uniform
       __syncthreads();                                  // the A tile is dead: every wave takes a private transpose tile in it
-      gemm_epilogue_wide<WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, lane, reinterpret_cast<float*>(smem_b) + wave * EPI_WAVE_FLOATS);
+      gemm_epilogue_wide<WM, WN, TM, TN, STATS>(p, acc, m0, n0, wm, wn, lane, reinterpret_cast<float*>(smem_b) + wave * EPI_WAVE_FLOATS, wg_stats);
     } else {
       gemm_epilogue<WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, r, h);
     }
@@ -528,7 +533,16 @@ static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterm
                  4.0 * count * ((double)p.M * p.K / (mode == A_ROWS_TAP3 ? 3 : 1) + 1.5 * (double)p.N * p.K + (double)p.M * p.N * ((p.flags & G_RES) ? 2 : 1)));
   const int npl = nterms == 6 ? 3 : 2;
   size_t lds = (size_t)npl * BM * ROWB;
-  if (lds < (size_t)WM * WN * EPI_WAVE_FLOATS * sizeof(float)) lds = (size_t)WM * WN * EPI_WAVE_FLOATS * sizeof(float);
+  {   // epilogue: a transpose tile per wave; behind both that and the A tile, the row-statistics block of the workgroup
+    const size_t epi = (size_t)WM * WN * EPI_WAVE_FLOATS * sizeof(float);
+    if (lds < epi) lds = epi;
+    lds += stats_lds_floats<WM, WN, TM>() * sizeof(float);
+  }
+  if (p.stats_out || p.stats_in) {
+    DCF_CHECK(mode == A_ROWS && !p.ln_w && p.stats_w > 0, "launch_gemm_split: row statistics need A_ROWS, no fused LayerNorm and stats_w > 0");
+    if (p.stats_out) DCF_CHECK((((p.flags & G_ADALN) ? BN / 2 : BN) % p.stats_w) == 0, "launch_gemm_split: tile width %d is not a multiple of stats_w = %d", BN, p.stats_w);
+    if (p.stats_in) DCF_CHECK(p.ln_s && p.stats_slots >= 1, "launch_gemm_split: stats_in needs ln_s and stats_slots");
+  }
   if (p.ln_w) {
     DCF_CHECK(WM == 1 && TM == 2 && TN >= 2 && BN == p.N, "launch_gemm_split: fused LayerNorm needs a tile spanning all %d columns", p.N);
     const size_t need = ((size_t)WN * BM * LN_PITCH + BM) * sizeof(float);
@@ -547,6 +561,22 @@ static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterm
   } while (0)
 #define LS(MODE_, NT_) LSK(MODE_, NT_, false)
 #define LSN(MODE_, NT_) LSK(MODE_, NT_, true)
+  bool want_stats = false;
+  for (int i = 0; i < count; ++i) want_stats = want_stats || b.g[i].stats_out || b.g[i].stats_in;
+  if (want_stats) {
+    // only the tiles an A_ROWS GEMM with N % 64 == 0 is dispatched to have the statistics instantiation
+    if constexpr (BN % 64 == 0 && !(WM == 2 && TM == 2)) {
+      if (nterms == 6) {
+        if constexpr (DEEP) hipLaunchKernelGGL((gemm_bf16s_kernel<WM, WN, TM, TN, A_ROWS, 6, false, 2, true>), grid, dim3(WM * WN * 64), lds, stream, b);
+        else hipLaunchKernelGGL((gemm_bf16s_kernel<WM, WN, TM, TN, A_ROWS, 6, false, 2, true>), grid, dim3(WM * WN * 64), lds, stream, b);
+      } else {
+        if constexpr (DEEP) hipLaunchKernelGGL((gemm_bf16s_kernel<WM, WN, TM, TN, A_ROWS, T_F16, false, 3, true>), grid, dim3(WM * WN * 64), lds, stream, b);
+        else hipLaunchKernelGGL((gemm_bf16s_kernel<WM, WN, TM, TN, A_ROWS, T_F16, false, 2, true>), grid, dim3(WM * WN * 64), lds, stream, b);
+      }
+    } else {
+      DCF_CHECK(false, "launch_gemm_split: no row-statistics kernel for %dx%d tiles", BM, BN);
+    }
+  } else
   if (p.ln_w) {
     if constexpr (WM == 1 && TM == 2 && TN >= 2) {
       DCF_CHECK(mode != A_CHANMAJOR && count == 1, "launch_gemm_split: fused LayerNorm: unsupported mode");
@@ -604,6 +634,16 @@ bool gemm_can_fuse_adaln(int M, int N, int K) {
   return M >= 65536 || (long)((M + 63) / 64) * (N / 256) >= 448;      // 128x256 / 64x256 (WANT workgroups)
 }
 
+// mirrors the dispatch below for A_ROWS: k-sliced kernel -> no; tile kernels -> their width must be a multiple of 64 (all
+// of the N % 64 == 0 tiles are)
+bool gemm_can_carry_stats(int M, int N, int K, int count, int nterms) {
+  if (nterms == 0 || N % 64 != 0 || K % SBK != 0 || M <= 0) return false;
+  const long tiles64 = (long)((M + 63) / 64) * (N / 64) * count;
+  constexpr long kslice_max = 512;
+  if (K >= 4 * SBK && tiles64 <= ((K >= 16 * SBK && nterms != T_F16) ? kslice_max : kslice_max / 2)) return false;
+  return true;
+}
+
 bool gemm_can_fuse_ln(int M, int N, int K, GemmAMode mode) {
   // The fused kernel needs a 64 x N tile, i.e. M / 64 workgroups.  Measured at T = 16384 (rocprofv3): with 256
   // workgroups (M = 16384, one per CU) conv + LN fused 64 us vs 40 + 8 us as two kernels on 64x128 tiles; with 510
@@ -627,6 +667,14 @@ int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, 
     if (mode == A_ROWS_TAP3) DCF_CHECK(g[i].nbr && g[i].cin % 32 == 0 && g[i].K == 3 * g[i].cin, "launch_gemm_split: bad tap3 args");
     if (g[i].flags & (G_AMASK | G_RES_MASK | G_OUT_MASK)) DCF_CHECK(g[i].rowmask, "launch_gemm_split: rowmask missing");
     if (g[i].flags & G_RES) DCF_CHECK(g[i].R, "launch_gemm_split: residual missing");
+    if (g[i].stats_out || g[i].stats_in) {
+      // the 16-byte epilogue carries them (gemm_wide_ok), and only the tile kernels have it
+      DCF_CHECK(mode == A_ROWS && gemm_can_carry_stats(g[i].M, g[i].N, g[i].K, count, nterms), "launch_gemm_split: row statistics: %dx%dx%d (x%d) runs on the k-sliced kernel", g[i].M, g[i].N, g[i].K, count);
+      DCF_CHECK(g[i].ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(g[i].C) & 15) == 0 && (!g[i].bias || (reinterpret_cast<uintptr_t>(g[i].bias) & 15) == 0) &&
+                (!(g[i].flags & G_RES) || (g[i].ldr % 4 == 0 && (reinterpret_cast<uintptr_t>(g[i].R) & 15) == 0 && (!g[i].ls || (reinterpret_cast<uintptr_t>(g[i].ls) & 15) == 0))) &&
+                (!g[i].stats_in || (g[i].ln_s && (reinterpret_cast<uintptr_t>(g[i].ln_s) & 15) == 0 && g[i].stats_slots >= 1)) && g[i].stats_w > 0 && !g[i].ln_w,
+                "launch_gemm_split: row statistics need 16-byte aligned C / R / bias / ls / ln_s, stats_w > 0 and no fused LayerNorm");
+    }
     if (g[i].flags & G_ADALN)
       DCF_CHECK(g[i].flags == G_ADALN && mode == A_ROWS && g[i].R && !g[i].ln_w && g[i].ldc % 4 == 0 && g[i].ldr % 4 == 0 &&
                 (reinterpret_cast<uintptr_t>(g[i].C) & 15) == 0 && (reinterpret_cast<uintptr_t>(g[i].R) & 15) == 0 &&

@@ -126,9 +126,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
 constexpr int EPI_PITCH = 36;
 constexpr int EPI_WAVE_FLOATS = 32 * EPI_PITCH;
 
-template <bool FULL, int ACT, bool RES, int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void stats_flush(const GemmArgs& p, const float* wg_out, int m0, int c0, int n_cols, int tid, int bn_out);
+
+// Row statistics between GEMMs (GemmArgs::stats_in / stats_out): `wg` is a workgroup-shared LDS block of
+// stats_lds_floats<WM, WN, TM>() floats behind the wave-private transpose tiles: [BM] (mean, rstd) of the consumer's rows,
+// then [WN][BM] (sum, sum of squares) of the producer's wave tiles.
+template <int WM, int WN, int TM>
+constexpr int stats_lds_floats() { return (1 + WN) * (WM * TM * 32) * 2; }
+
+template <bool FULL, int ACT, bool RES, int WM, int WN, int TM, int TN, bool STATS>
 __device__ __forceinline__ void gemm_epilogue_wide_body(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0_, int n0_, int wm, int wn,
-                                                        int lane, float* tile /* wave private, EPI_WAVE_FLOATS */) {
+                                                        int lane, float* tile /* wave private, EPI_WAVE_FLOATS */, float* wg) {
+  constexpr int BM = WM * TM * 32;
+  // STATS is a kernel template argument: the plain kernels carry none of this (it cost the 128x256 tile 144 bytes of scratch)
+  const bool fold = STATS && p.stats_in != nullptr, emit = STATS && p.stats_out != nullptr;       // uniform
+  const float* wg_in = wg;
+  float* wg_out = wg + 2 * BM;
   const int flags = p.flags;
   const int m0 = __builtin_amdgcn_readfirstlane(m0_), n0 = __builtin_amdgcn_readfirstlane(n0_);
   const int rows_left = p.M - m0;
@@ -169,15 +183,18 @@ __device__ __forceinline__ void gemm_epilogue_wide_body(const GemmArgs& p, f32x1
         }
     }
   }
-  f32x4 bias[TN], ls[TN];
+  f32x4 bias[TN], ls[TN], lns[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const unsigned colb = (unsigned)((wn * TN + j) * 32 + c4);
     bias[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     ls[j] = f32x4{1.f, 1.f, 1.f, 1.f};
+    lns[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (p.bias) bias[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + colb);
     if constexpr (RES) { if (p.ls) ls[j] = *reinterpret_cast<const f32x4*>(p.ls + n0 + colb); }
+    if (fold) lns[j] = *reinterpret_cast<const f32x4*>(p.ln_s + n0 + colb);
   }
+  float ps[4] = {0.f, 0.f, 0.f, 0.f}, pss[4] = {0.f, 0.f, 0.f, 0.f};     // emit: this lane's share of rows rr + 8 q of row block i
 #pragma unroll
   for (int f = 0; f < NF; ++f) {
     const int i = f / TN, j = f % TN;
@@ -188,7 +205,19 @@ __device__ __forceinline__ void gemm_epilogue_wide_body(const GemmArgs& p, f32x1
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const unsigned row = (unsigned)((wm * TM + i) * 32 + rr + 8 * q);
-      f32x4 v = *reinterpret_cast<const f32x4*>(tile + (rr + 8 * q) * EPI_PITCH + c4) + bias[j];
+      f32x4 v = *reinterpret_cast<const f32x4*>(tile + (rr + 8 * q) * EPI_PITCH + c4);
+      if (fold) {                                                        // LayerNorm of the A row, folded (see GemmArgs)
+        const float mean = wg_in[2 * ((wm * TM + i) * 32 + rr + 8 * q)], rstd = wg_in[2 * ((wm * TM + i) * 32 + rr + 8 * q) + 1];
+        // explicit fused multiply-adds: the compiler's own contraction differs between tile instantiations, and a row must
+        // get the same bits whatever tile shape its batch size selects
+        const f32x4 l = lns[j], bb = bias[j];
+        v.x = __builtin_fmaf(__builtin_fmaf(-mean, l.x, v.x), rstd, bb.x);
+        v.y = __builtin_fmaf(__builtin_fmaf(-mean, l.y, v.y), rstd, bb.y);
+        v.z = __builtin_fmaf(__builtin_fmaf(-mean, l.z, v.z), rstd, bb.z);
+        v.w = __builtin_fmaf(__builtin_fmaf(-mean, l.w, v.w), rstd, bb.w);
+      } else {
+        v += bias[j];
+      }
       if constexpr (ACT == 1) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
       if constexpr (ACT == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       if constexpr (RES) {
@@ -199,23 +228,80 @@ __device__ __forceinline__ void gemm_epilogue_wide_body(const GemmArgs& p, f32x1
         v = r_ + ls[j] * v;
       }
       if (FULL || (int)row < rows_left) *reinterpret_cast<f32x4*>(Cb + row * ldc + colb) = v;
+      if (emit) {
+        if (j == 0) { ps[q] = 0.f; pss[q] = 0.f; }
+        ps[q] += (v.x + v.y) + (v.z + v.w);
+        pss[q] += __builtin_fmaf(v.x, v.x, v.y * v.y) + __builtin_fmaf(v.z, v.z, v.w * v.w);
+      }
+    }
+    if (emit && j == TN - 1) {                                          // the wave's TN * 32 columns of rows (i, rr + 8 q) are complete
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float s1 = group_sum<8>(ps[q]), s2 = group_sum<8>(pss[q]);
+        if ((lane & 7) == 0) {
+          float* o = wg_out + 2 * (wn * BM + (wm * TM + i) * 32 + rr + 8 * q);
+          o[0] = s1; o[1] = s2;
+        }
+      }
     }
     if constexpr (RES) { if (f + 2 < NF) load_res(f + 2, res[f & 1]); }
   }
+  if (emit) stats_flush<WM, WN, TM, TN>(p, wg_out, m0, n0, p.N, (wm * WN + wn) * 64 + lane, WN * TN * 32);
 }
 
-template <bool FULL, int WM, int WN, int TM, int TN>
+// the consumer's rows: (mean, rstd) from the slots of stats_in -> wg[0 .. 2 BM).  Called at kernel entry, before the K loop:
+// the block lies behind the A tile AND the transpose tiles in LDS, the K loop's barriers order it before the epilogue reads
+// it, and the latency of the statistics loads (a dependent chain per workgroup: +15 % on the ffn.fc kernels when it sat in
+// the epilogue) hides under the first operand loads
+template <int BM, int NT>
+__device__ __forceinline__ void stats_load(const GemmArgs& p, float* wg, int m0, int tid) {
+  for (int t = tid; t < BM; t += NT) {
+    const int row = m0 + t;
+    float s1 = 0.f, s2 = 0.f;
+    if (row < p.M) {
+      const float* sp = p.stats_in + (int64_t)row * p.stats_slots * 2;
+      for (int k = 0; k < p.stats_slots; ++k) { s1 += sp[2 * k]; s2 += sp[2 * k + 1]; }
+    }
+    const float inv = 1.0f / (float)p.K;
+    const float mean = s1 * inv;
+    const float var = fmaxf(__builtin_fmaf(-mean, mean, s2 * inv), 0.f);
+    wg[2 * t] = mean;
+    wg[2 * t + 1] = 1.0f / sqrtf(var + 1e-5f);
+  }
+}
+
+// the producer's rows: add the WN wave tiles of a row in a fixed order and write the slots this workgroup tile covers
+// (n_cols output columns per row in all, the tile starts at output column c0 and is BN_out wide)
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void stats_flush(const GemmArgs& p, const float* wg_out, int m0, int c0, int n_cols, int tid,
+                                            int bn_out) {
+  constexpr int BM = WM * TM * 32, NT = WM * WN * 64;
+  __syncthreads();
+  const int slots = n_cols / p.stats_w, first = c0 / p.stats_w, cover = bn_out / p.stats_w;
+  for (int t = tid; t < BM; t += NT) {
+    const int row = m0 + t;
+    if (row >= p.M) continue;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < WN; ++w) { s1 += wg_out[2 * (w * BM + t)]; s2 += wg_out[2 * (w * BM + t) + 1]; }
+    float* o = p.stats_out + ((int64_t)row * slots + first) * 2;
+    o[0] = s1; o[1] = s2;
+    for (int k = 1; k < cover; ++k) { o[2 * k] = 0.f; o[2 * k + 1] = 0.f; }
+  }
+}
+
+template <bool FULL, int WM, int WN, int TM, int TN, bool STATS>
 __device__ __forceinline__ void gemm_epilogue_wide_flags(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
-                                                         int lane, float* tile) {
+                                                         int lane, float* tile, float* wg) {
   const int act = (p.flags & G_GELU) ? 1 : ((p.flags & G_RELU) ? 2 : 0);
   if (p.flags & G_RES) {
-    if (act == 0) gemm_epilogue_wide_body<FULL, 0, true, WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, lane, tile);
-    else if (act == 1) gemm_epilogue_wide_body<FULL, 1, true, WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, lane, tile);
-    else gemm_epilogue_wide_body<FULL, 2, true, WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, lane, tile);
+    if (act == 0) gemm_epilogue_wide_body<FULL, 0, true, WM, WN, TM, TN, STATS>(p, acc, m0, n0, wm, wn, lane, tile, wg);
+    else if (act == 1) gemm_epilogue_wide_body<FULL, 1, true, WM, WN, TM, TN, STATS>(p, acc, m0, n0, wm, wn, lane, tile, wg);
+    else gemm_epilogue_wide_body<FULL, 2, true, WM, WN, TM, TN, STATS>(p, acc, m0, n0, wm, wn, lane, tile, wg);
   } else {
-    if (act == 0) gemm_epilogue_wide_body<FULL, 0, false, WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, lane, tile);
-    else if (act == 1) gemm_epilogue_wide_body<FULL, 1, false, WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, lane, tile);
-    else gemm_epilogue_wide_body<FULL, 2, false, WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, lane, tile);
+    if (act == 0) gemm_epilogue_wide_body<FULL, 0, false, WM, WN, TM, TN, STATS>(p, acc, m0, n0, wm, wn, lane, tile, wg);
+    else if (act == 1) gemm_epilogue_wide_body<FULL, 1, false, WM, WN, TM, TN, STATS>(p, acc, m0, n0, wm, wn, lane, tile, wg);
+    else gemm_epilogue_wide_body<FULL, 2, false, WM, WN, TM, TN, STATS>(p, acc, m0, n0, wm, wn, lane, tile, wg);
   }
 }
 
@@ -225,14 +311,15 @@ __device__ __forceinline__ bool gemm_wide_ok(const GemmArgs& p) {
   if (p.flags & G_RES) ok = ok && (p.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(p.R) & 15) == 0;
   if (p.bias) ok = ok && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
   if ((p.flags & G_RES) && p.ls) ok = ok && (reinterpret_cast<uintptr_t>(p.ls) & 15) == 0;
+  if (p.stats_in) ok = ok && (reinterpret_cast<uintptr_t>(p.ln_s) & 15) == 0;
   return ok;
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool STATS = false>
 __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
-                                                   int lane, float* tile) {
-  if (m0 + WM * TM * 32 <= p.M) gemm_epilogue_wide_flags<true, WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, lane, tile);
-  else gemm_epilogue_wide_flags<false, WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, lane, tile);
+                                                   int lane, float* tile, float* wg) {
+  if (m0 + WM * TM * 32 <= p.M) gemm_epilogue_wide_flags<true, WM, WN, TM, TN, STATS>(p, acc, m0, n0, wm, wn, lane, tile, wg);
+  else gemm_epilogue_wide_flags<false, WM, WN, TM, TN, STATS>(p, acc, m0, n0, wm, wn, lane, tile, wg);
 }
 
 // ---- epilogue of the AdaLN projection (G_ADALN) ---------------------------------------------------------------
@@ -241,10 +328,14 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& p, f32x16 (&a
 // channels.  After the transposition through the wave's LDS tile a lane holds 4 consecutive channels of one row of each: it
 // reads the 4 modulated channels of R and writes 4 channels of C, 16 bytes each.  The (rows, 2E) projection never reaches
 // memory and the separate modulation pass (3 reads + 1 write of a row) is gone.
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool STATS = false>
 __device__ __forceinline__ void gemm_epilogue_adaln(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0_, int n0_, int wm, int wn,
-                                                    int lane, float* tile /* wave private, EPI_WAVE_FLOATS */) {
+                                                    int lane, float* tile /* wave private, EPI_WAVE_FLOATS */, float* wg) {
   if constexpr (TN % 2 == 0) {
+    constexpr int BM = WM * TM * 32;
+    const bool emit = STATS && p.stats_out != nullptr;          // uniform: (sum, sum of squares) of the modulated rows for the next LayerNorm
+    float* wg_out = wg + 2 * BM;
+    float ps[4] = {0.f, 0.f, 0.f, 0.f}, pss[4] = {0.f, 0.f, 0.f, 0.f};
     const int m0 = __builtin_amdgcn_readfirstlane(m0_), n0 = __builtin_amdgcn_readfirstlane(n0_);
     const int rows_left = p.M - m0;
     float* __restrict__ Cb = p.C + (int64_t)m0 * p.ldc + n0 / 2;
@@ -287,9 +378,25 @@ __device__ __forceinline__ void gemm_epilogue_adaln(const GemmArgs& p, f32x16 (&
         const f32x4 sh = *reinterpret_cast<const f32x4*>(tile + (rr + 8 * q) * EPI_PITCH + c4) + bh;
         const f32x4 o = res[f & 1][q] * sc[q] + sh;
         if ((int)row < rows_left) *reinterpret_cast<f32x4*>(Cb + row * ldc + ch) = o;
+        if (emit) {
+          if (jp == 0) { ps[q] = 0.f; pss[q] = 0.f; }
+          ps[q] += (o.x + o.y) + (o.z + o.w);
+          pss[q] += __builtin_fmaf(o.x, o.x, o.y * o.y) + __builtin_fmaf(o.z, o.z, o.w * o.w);
+        }
+      }
+      if (emit && jp == TN / 2 - 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float s1 = group_sum<8>(ps[q]), s2 = group_sum<8>(pss[q]);
+          if ((lane & 7) == 0) {
+            float* o = wg_out + 2 * (wn * BM + (wm * TM + i) * 32 + rr + 8 * q);
+            o[0] = s1; o[1] = s2;
+          }
+        }
       }
       if (f + 2 < NP) load_res(f + 2, res[f & 1]);
     }
+    if (emit) stats_flush<WM, WN, TM, TN>(p, wg_out, m0, n0 / 2, p.N / 2, (wm * WN + wn) * 64 + lane, WN * TN * 16);
   } else {
     __builtin_trap();                                    // the launcher only sends G_ADALN to tiles with an even TN
   }

@@ -29,6 +29,7 @@ struct DecPreArgs {
   int B, T, C;
   int strip;                        // rows per wavefront (filled in by the launcher)
   const uint8_t* nbr;               // optional [B*T] neighbour flags: several sequences laid back to back (pyramid)
+  int affine;                       // fusion.xattn_mode == 'affine' (blocks.py:623-626): Xa = q * m, no LayerNorm
 };
 
 struct EncPreArgs {

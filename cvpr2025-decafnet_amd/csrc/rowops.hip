@@ -185,7 +185,7 @@ __device__ __forceinline__ void axpy3(Row<NCH>& out, const Row<NCH>& a, const Ro
 // TransformerDecoder front half (libs/modeling/blocks.py:632-645, :513-516):
 //   q  = x * m
 //   Qc = q_norm( dwconv3( ln_xattn_q(q) * m ) )          -> input of the query projection
-//   Xa = adaln(q * m)  (LayerNorm without affine)          -> modulated later by the xattn output
+//   Xa = adaln(q * m)  (LayerNorm without affine; the identity in xattn_mode 'affine') -> modulated later by the xattn output
 // ------------------------------------------------------------------------------------------
 template <int NCH, bool FULL>
 __global__ __launch_bounds__(256) void k_dec_pre(DecPreArgs p) {
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void k_dec_pre(DecPreArgs p) {
     row_layernorm(q, C, lane, qnw, qnb);
     q.store(p.Qc + (base + t) * (int64_t)C, C, lane);
     Row<NCH> xa = raw_c;                       // already zero where masked
-    row_layernorm(xa, C, lane, none, none);
+    if (!p.affine) row_layernorm(xa, C, lane, none, none);        // 'affine': nn.Identity (blocks.py:625-626)
     xa.store(p.Xa + (base + t) * (int64_t)C, C, lane);
     prev = cur; cur = nxt; raw_c = raw_n;
   };

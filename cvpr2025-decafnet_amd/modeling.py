@@ -131,12 +131,13 @@ class ConvXAttNLayer(nn.Module):
 
 
 class TransformerDecoder(nn.Module):
-    """blocks.py:594-630 (xattn_mode 'adaln')."""
+    """blocks.py:594-630; xattn_mode 'adaln' (the cross-attention output modulates LayerNorm(q)) or 'affine' (it modulates q
+    itself).  Neither mode has parameters of its own: the adaln LayerNorm is affine=False (blocks.py:623-626)."""
 
     def __init__(self, embd_dim, kv_dim, n_heads=4, xattn_mode='adaln'):
         super().__init__()
-        if xattn_mode != 'adaln':
-            raise NotImplementedError("only fusion.xattn_mode == 'adaln' is on the hot path")
+        assert xattn_mode in ('affine', 'adaln')                         # blocks.py:613
+        self.xattn_mode = xattn_mode
         self.xattn = ConvXAttNLayer(embd_dim, kv_dim, embd_dim * 2, n_heads)
         self.ln_xattn_q = LayerNorm(embd_dim)
         self.ln_xattn_kv = LayerNorm(kv_dim)
@@ -480,8 +481,81 @@ class PtTransformerEarlyFusionIterative(nn.Module):
 
     def forward(self, vid, shallow_vid, vid_masks, text, text_cls, text_masks, text_size=None, mv_data=None, eval=False):
         if not eval:
-            raise NotImplementedError('only the eval forward (eval=True) is implemented; training is out of scope')
+            return self._drop_forward(vid, shallow_vid, vid_masks, text, text_cls, text_masks, text_size, mv_data, eval)
         return self._drop_forward_eval(vid, shallow_vid, vid_masks, text, text_cls, text_masks, text_size, mv_data, eval)
+
+    def _drop_forward(self, vid, shallow_vid, vid_masks, text, text_cls, text_masks, text_size=None, mv_data=None, eval=False):
+        """Training-mode forward, FORWARD VALUES ONLY (model.py:567-632): vid / shallow_vid (bs, D, T), vid_masks (bs, T),
+        raw text tokens (sum(text_size), C_t, Lq) -- or padded (bs, max_k, C_t, Lq), model.py:617-622 -- with text_masks
+        (.., 1, Lq) / (.., Lq), text_cls (sum(text_size), D), text_size (bs,) queries per video (None: one per video).
+        Video b is repeated for its text_size[b] queries (model.py:579-582), the text encoder runs inside (model.py:624).
+        Returns what the reference returns: (fpn_logits1, fpn_logits2, fpn_offsets, fpn_masks), tuples over the L levels of
+        (B', T_l) / (B', T_l) / (B', T_l, 2) / (B', T_l) bool with B' = sum(text_size) rows in (video, query) order.
+        There is no backward pass and no random number stream here: every dropout / drop-path probability of ``opt`` must
+        be 0, and the Dropout(0.5) the reference hard-codes into every layer of the refinement TCN (tcn.py:5,13;
+        model.py:424-425 passes no dropout argument) is taken at p = 0 too -- the values are those of the reference's
+        train()-mode forward with that module's dropout disabled.  The outputs carry no autograd graph; the reference's Trainer
+        is out of scope."""
+        assert mv_data is None
+        if self.MODEL_KIND != 0:
+            raise NotImplementedError('the training-mode forward is built for PtTransformerEarlyFusionIterative (model.py:567-632)')
+        mo = self.opt['model'] if isinstance(self.opt, dict) else self.opt.model
+        for part in ('vid_net', 'text_net', 'fusion'):
+            for key in ('attn_pdrop', 'proj_pdrop', 'path_pdrop', 'cdrop'):
+                if float(dict(mo[part]).get(key, 0.0) or 0.0) != 0.0:
+                    raise NotImplementedError(f'training-mode forward: opt.model.{part}.{key} must be 0 (forward values only: no dropout '
+                                              f'random stream, no backward pass)')
+        if not vid.is_cuda:
+            raise RuntimeError('the grounding forward runs on the MI355X only: move the inputs to the GPU')
+        bs, T = vid.size(0), vid.size(-1)
+        sizes = [1] * bs if text_size is None else [int(k) for k in text_size]
+        assert len(sizes) == bs and all(k >= 1 for k in sizes)
+        if text.ndim == 4:                                                    # padded per video, model.py:617-622
+            text = torch.cat([t[:k] for t, k in zip(text, sizes)])
+            if text_masks.ndim == 3:
+                text_masks = torch.cat([t[:k] for t, k in zip(text_masks, sizes)])
+        nq = sum(sizes)
+        assert text.size(0) == nq and text_cls.size(0) == nq, (text.shape, text_cls.shape, sizes)
+        enc, enc_mask = self.encode_text(text, text_masks.reshape(nq, 1, -1))  # (nq, TE, Lk), (nq, 1, Lk)
+        dev = vid.device
+        eng = self._engine
+        lib = eng.lib
+        keep = []
+        vptr, sptr, mptr_v, cptr = ((ctypes.c_void_p * bs)() for _ in range(4))
+        nqs = (ctypes.c_int32 * bs)()
+        tptr, mptr, tlen = (ctypes.c_void_p * nq)(), (ctypes.c_void_p * nq)(), (ctypes.c_int32 * nq)()
+        q = 0
+        for b in range(bs):
+            vc, sc = vid[b].contiguous().float(), shallow_vid[b].contiguous().float()
+            mc = vid_masks[b].reshape(-1).to(torch.bool).contiguous()
+            cc = text_cls[q:q + sizes[b]].contiguous().float()
+            assert sc.shape == vc.shape == (self.D, T) and mc.numel() == T and cc.shape == (sizes[b], self.D)
+            keep += [vc, sc, mc, cc]
+            vptr[b], sptr[b], mptr_v[b], cptr[b], nqs[b] = vc.data_ptr(), sc.data_ptr(), mc.data_ptr(), cc.data_ptr(), sizes[b]
+            for i in range(q, q + sizes[b]):
+                t = enc[i].contiguous().float()
+                m = enc_mask[i].reshape(-1).to(torch.bool).contiguous()
+                keep += [t, m]
+                tptr[i], mptr[i], tlen[i] = t.data_ptr(), m.data_ptr(), t.size(1)
+            q += sizes[b]
+        pe = None
+        if self.vid_net.use_abs_pe:
+            pe = self._position_encoding(T, dev)
+            _lib.check(lib.dcf_model_set_pe(eng.handle, _lib.ptr(pe), T), 'dcf_model_set_pe')
+        S = lib.dcf_points_per_query(eng.handle, T)
+        logits1 = torch.empty(nq, S, device=dev, dtype=torch.float32)
+        logits2 = torch.empty(nq, S, device=dev, dtype=torch.float32)
+        offsets = torch.empty(nq, S, 2, device=dev, dtype=torch.float32)
+        masks = torch.empty(nq, S, device=dev, dtype=torch.bool)
+        _lib.check(lib.dcf_forward_train_videos(eng.handle, bs, vptr, sptr, mptr_v, T, nqs, tptr, mptr, tlen, cptr, _lib.ptr(logits1),
+                                                _lib.ptr(logits2), _lib.ptr(offsets), _lib.ptr(masks), _lib.current_stream()),
+                   'dcf_forward_train_videos')
+        self._last_inputs = (keep, pe, enc, enc_mask)
+        self._last_flat = (logits2, offsets, masks)
+        self._probe_numerics()
+        sizes_l = [T >> l for l in range(self.vid_net.arch[2])]
+        return (tuple(logits1.split(sizes_l, 1)), tuple(logits2.split(sizes_l, 1)), tuple(offsets.split(sizes_l, 1)),
+                tuple(masks.split(sizes_l, 1)))
 
     def numerics_status(self, reset=False):
         """dcf_numerics_status of the engine (blocking): bit 0 = a GEMM of the f16x3 mode produced a non-finite value since
@@ -522,6 +596,7 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         c.use_abs_pe, c.max_batch = int(vn.use_abs_pe), self.max_batch
         c.gemm_mode = self.gemm_mode
         c.model_kind, c.second_fusion = self.MODEL_KIND, int(bool(self.second_fusion))
+        c.xattn_affine = int(len(self.fusion.layers) > 0 and self.fusion.layers[0].xattn_mode == 'affine')
         _text_config(c, self.text_net)
         return c
 

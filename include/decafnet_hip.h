@@ -65,6 +65,9 @@ typedef struct dcf_config {
                            * D is then the sidekick feature dim = 2 * opt.model.vid_net.in_dim; ignored by model_kind 1 */
   int32_t text_kind;      /* 0 = TextTransformer (text_net.py:92-188), 1 = TextIdentity (text_net.py:22-89: optional embd_fc,
                            * optional AttNPool1D token when text_bkgd != 0; text_layers is ignored)  */
+  /* ABI version 5 */
+  int32_t xattn_affine;   /* opt.model.fusion.xattn_mode: 0 = 'adaln' (the decoder modulates LayerNorm(q), blocks.py:623-624,643),
+                           * 1 = 'affine' (it modulates q itself: nn.Identity, blocks.py:625-626)   */
 } dcf_config;
 
 int dcf_model_create(const dcf_config* cfg, dcf_model** out);
@@ -134,6 +137,30 @@ int dcf_forward_eval(dcf_model* m, const float* vid, const float* shallow_vid, c
 int dcf_forward_eval_gated(dcf_model* m, const float* vid, const float* shallow_vid, const uint8_t* vid_mask, int64_t T,
                            int32_t nq, const float* const* text, const uint8_t* const* text_mask, const int32_t* text_len,
                            const float* gate, float* logits_out, float* offsets_out, uint8_t* masks_out, void* stream);
+
+/* Training-mode forward, forward values only (PtTransformerEarlyFusionIterative._drop_forward, libs/modeling/model.py:567-632,
+ * with every dropout / drop-path probability 0): a batch of videos of one padded length, video v repeated for its
+ * text_size[v] = nq_per_video[v] queries (`repeat_interleave`, model.py:579-582), i.e. the rows of the batch are the
+ * (video, query) pairs in video order.  Arguments as dcf_forward_eval_videos; returns, per pair, what fuse_and_predict
+ * returns (model.py:442-471): logits1_out (sum(nq), S) of the first cls_head, logits2_out (sum(nq), S), offsets_out
+ * (sum(nq), S, 2), masks_out (sum(nq), S).  No backward pass.  ABI version 5. */
+int dcf_forward_train_videos(dcf_model* m, int32_t nvid, const float* const* vid, const float* const* shallow_vid,
+                             const uint8_t* const* vid_mask, int64_t T, const int32_t* nq_per_video, const float* const* text,
+                             const uint8_t* const* text_mask, const int32_t* text_len, const float* const* text_cls,
+                             float* logits1_out, float* logits2_out, float* offsets_out, uint8_t* masks_out, void* stream);
+
+/* Point losses, forward values (libs/modeling/loss.py; used by Trainer.forward_backward, libs/worker_v2.py:441-461).
+ *   dcf_sigmoid_focal_loss <- sigmoid_focal_loss(inputs, targets, alpha, gamma, smoothing, reduction)   (loss.py:5-57)
+ *   dcf_ctr_iou_loss       <- ctr_giou_loss / ctr_diou_loss(input_offsets, target_offsets, reduction, eps) (loss.py:60-166)
+ * n elements (rows of 2 offsets for the IoU losses) on the device; `select` (optional, n bytes) keeps the elements with a
+ * non-zero byte -- the boolean-mask indexing `x[fpn_masks]` / `x[pos_masks]` of the caller without a compaction pass.
+ * elem_out (optional, n floats): the per-element loss (reduction 'none'; unselected elements get 0); sum_out (optional,
+ * 1 float) the sum over the selected elements and count_out (optional, 1 int32) their number ('sum' / 'mean'), added up
+ * in a fixed order (deterministic).  kind: 0 = GIoU (reduces to IoU, loss.py:104), 1 = DIoU. */
+int dcf_sigmoid_focal_loss(const float* inputs, const float* targets, const uint8_t* select, int64_t n, float alpha, float gamma,
+                           int32_t smoothing, float* elem_out, float* sum_out, int32_t* count_out, void* stream);
+int dcf_ctr_iou_loss(const float* input_offsets, const float* target_offsets, const uint8_t* select, int64_t n, int32_t kind,
+                     float eps, float* elem_out, float* sum_out, int32_t* count_out, void* stream);
 
 /* Throughput extension: several videos of the SAME padded length T in one forward (the reference evaluates one video per
  * call, model.py:496; videos no longer than opt.model.max_vid_len are all padded to that length, worker_v2.py:969-976).
@@ -220,6 +247,15 @@ int dcf_op_linear_cm(const float* A_cm, const float* W, const float* bias, float
  * the raw product.  Only shapes the engine fuses: N = 256, M >= 28672, K % 32 == 0. */
 int dcf_op_linear_ln(const float* A, const float* W, const float* bias, const float* ln_w, const float* ln_b, float* C, float* Y,
                      int32_t M, int32_t N, int32_t K, int32_t relu, int32_t nterms, void* stream);
+
+/* Two chained 1x1 convolutions with a channel LayerNorm between them, the LayerNorm carried as row statistics instead of a
+ * pass over the rows (how attn.proj -> ln_ffn -> ffn.fc runs, libs/modeling/blocks.py:586-590):
+ *   X = A W1^T + b1 (+ R)            written with (sum, sum of squares) of every row on the side
+ *   Y = act(LayerNorm(X) W2^T + b2)  computed from the RAW X with ln_w folded into W2 and (mean, rstd) applied in the epilogue
+ * act = erf GELU if gelu != 0.  Shapes the engine carries: N1 % 64 == 0, tile-kernel grids (M * N / 4096 > 256). */
+int dcf_op_linear_ln_carry(const float* A, const float* W1, const float* b1, const float* R, const float* ln_w, const float* ln_b,
+                           const float* W2, const float* b2, float* X, float* Y, int32_t M, int32_t N1, int32_t K1, int32_t N2,
+                           int32_t gelu, int32_t nterms, void* stream);
 
 /* same product on the bf16-split matrix-core path (how vid_map runs); needs M % 4 == 0, N % 128 == 0, K % 32 == 0 */
 int dcf_op_linear_cm_split(const float* A_cm, const float* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K,

@@ -495,6 +495,68 @@ def forward_eval(sd: SD, cfg, vid: Tensor, shallow_vid: Tensor, vid_masks: Tenso
     return logits_list, offsets_list, masks_list
 
 
+def forward_train(sd: SD, cfg, vid: Tensor, shallow_vid: Tensor, vid_masks: Tensor, tokens: Tensor, token_masks: Tensor,
+                  text_cls: Tensor, text_size: Sequence[int]):
+    """PtTransformerEarlyFusionIterative._drop_forward (training mode), model.py:567-632, FORWARD VALUES with every dropout
+    / drop-path probability 0 (their modules are then identities: blocks.py:670-684, model.py:421,614), including the
+    Dropout(0.5) hard-coded into the refinement TCN (tcn.py:5,13; model.py:424-425).
+
+    vid, shallow_vid (bs, D, T); vid_masks (bs, T); tokens (sum(text_size), C_t, Lq) raw text features with token_masks
+    (sum(text_size), 1, Lq); text_cls (sum(text_size), D); text_size[b] queries of video b.  The reference repeats video b
+    text_size[b] times (:579-582), gates every row with its own query's scores (:593-606), encodes the text batch (:624) and
+    runs fusion / vid_net / fuse_and_predict on the (video, query) rows; no operation mixes rows, so the rows are computed
+    one at a time here.  Returns (fpn_logits1, fpn_logits2, fpn_offsets, fpn_masks): tuples over the levels of
+    (B', T_l), (B', T_l), (B', T_l, 2), (B', T_l) with B' = sum(text_size)."""
+    n_levels = cfg['vid_net']['arch'][2]
+    rows = [[] for _ in range(4)]
+    q = 0
+    for b, k in enumerate(text_size):
+        v, s, m = vid[b:b + 1], shallow_vid[b:b + 1], vid_masks[b:b + 1]
+        texts, tmasks = [], []
+        for i in range(q, q + k):
+            t, tm = encode_text(sd, cfg, tokens[i:i + 1], token_masks[i:i + 1])
+            texts.append(t)
+            tmasks.append(tm)
+        l2, off, om, inter = forward_eval(sd, cfg, v, s, m, texts, text_cls[q:q + k], tmasks, return_intermediates=True)
+        for i in range(k):
+            rows[0].append(inter['per_query'][i]['logits1'])
+            rows[1].append(l2[i])
+            rows[2].append(off[i])
+            rows[3].append(om[i])
+        q += k
+    return tuple(tuple(torch.cat([r[l] for r in part], 0) for l in range(n_levels)) for part in rows)
+
+
+# ----------------------------------------------------------------------------------
+# point losses (libs/modeling/loss.py), forward values
+# ----------------------------------------------------------------------------------
+def sigmoid_focal_loss(inputs: Tensor, targets: Tensor, alpha: float = -1, gamma: float = 2.0, smoothing: bool = True) -> Tensor:
+    """loss.py:5-57, reduction 'none'."""
+    x, t = inputs.float(), targets.float()
+    pos = (t >= 0.5).float()
+    p = 1.0 / (1.0 + torch.exp(-x))
+    p_t = p * t + (1 - p) * (1 - t) if smoothing else p * pos + (1 - p) * (1 - pos)
+    ce = (1 - t) * x + torch.clamp(-x, min=0) + torch.log1p(torch.exp(-x.abs()))      # BCE with logits, overflow-free form
+    loss = ce * (1 - p_t) ** gamma
+    if alpha >= 0:
+        loss = (alpha * pos + (1 - alpha) * (1 - pos)) * loss
+    return loss
+
+
+def ctr_iou_loss(input_offsets: Tensor, target_offsets: Tensor, kind: str = 'diou', eps: float = 1e-8) -> Tensor:
+    """ctr_giou_loss (loss.py:60-109; reduces to 1 - IoU) / ctr_diou_loss (loss.py:111-166), reduction 'none'."""
+    lp, rp = input_offsets[:, 0].float(), input_offsets[:, 1].float()
+    lg, rg = target_offsets[:, 0].float(), target_offsets[:, 1].float()
+    inter = torch.minimum(rp, rg) + torch.minimum(lp, lg)
+    union = (lp + rp) + (lg + rg) - inter
+    loss = 1.0 - inter / union.clamp(min=eps)
+    if kind == 'diou':
+        len_c = torch.maximum(lp, lg) + torch.maximum(rp, rg)
+        rho = 0.5 * (rp - lp - rg + lg)
+        loss = loss + (rho / len_c.clamp(min=eps)) ** 2
+    return loss
+
+
 def forward_eval_late_fusion(sd: SD, cfg, vid: Tensor, shallow_vid: Tensor, vid_masks: Tensor,
                              text: Sequence[Tensor], text_cls: Tensor, text_masks: Sequence[Tensor]):
     """PtTransformer._drop_forward with eval=True (late fusion), model.py:83-161: the gated, concatenated features go

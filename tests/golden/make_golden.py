@@ -268,6 +268,10 @@ E2E_CASES = {
     'sfonly': dict(opt=dict(D=32, E=64, TE=32, text_in=32, n_levels=3, win=5, n_heads=2, sn=8, sratio=0.4,
                             msf=True, scat=True, sfonly=True, norm=True, max_seq_len=128, text_layers=1, text_max_len=24),
                    feat_dim=64, T=128, vid_len=120, nq=2, lq=4, wseed=81, iseed=82),
+    # opt.model.fusion.xattn_mode = 'affine' (blocks.py:613-626): the cross-attention output modulates q itself, not LayerNorm(q)
+    'affine': dict(opt=dict(D=64, E=64, TE=32, text_in=32, n_levels=4, win=5, n_heads=4, sn=16, sratio=0.3, msf=True, norm=True,
+                            max_seq_len=128, text_layers=1, text_max_len=24, xattn_mode='affine'),
+                   T=256, vid_len=251, nq=2, lq=6, wseed=33, iseed=34),
 }
 ONLY = set(filter(None, os.environ.get('ONLY', '').split(',')))
 
@@ -500,6 +504,75 @@ def gen_postproc_ext():
     save('postproc_ext.npz', out)
 
 
+# ------------------------------------------------------------------ G3b: training-mode forward values + point losses
+@torch.no_grad()
+def gen_train():
+    """PtTransformerEarlyFusionIterative.forward(eval=False) (model.py:567-632) in train() mode with every dropout probability 0,
+    two videos with 2 + 1 queries (padded text batch, text_size), and the reference's loss functions (loss.py) on its outputs with
+    synthetic labels -- the way Trainer.forward_backward combines them (worker_v2.py:441-461)."""
+    from libs.modeling.model import PtTransformerEarlyFusionIterative
+    from libs.modeling.loss import sigmoid_focal_loss, ctr_giou_loss, ctr_diou_loss
+    kw = dict(D=64, E=64, TE=32, text_in=32, n_levels=4, win=5, n_heads=4, sn=8, sratio=0.3, msf=True, norm=True,
+              max_seq_len=256, text_layers=2, text_max_len=24)
+    opt = make_opt(**kw)
+    model = PtTransformerEarlyFusionIterative(opt.clone(), second_fusion=False).train()
+    # the refinement TCN hard-codes nn.Dropout(0.5) in every layer (tcn.py:5,13; built without a dropout argument, model.py:424-425):
+    # the training forward is stochastic whatever opt says.  Forward VALUES are defined with that dropout at p = 0 as well.
+    for mod in model.refine.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    shapes = {k: list(v.shape) for k, v in model.state_dict().items()}
+    sd = synth.make_state_dict(shapes, 901)
+    model.load_state_dict(sd)
+    g = torch.Generator().manual_seed(902)
+    bs, T, lq, sizes = 2, 256, 7, [2, 1]
+    vid = torch.randn(bs, 64, T, generator=g)
+    shallow = torch.randn(bs, 64, T, generator=g)
+    lens = [256, 201]
+    vid_masks = torch.stack([torch.arange(T) < n for n in lens])
+    vid, shallow = vid * vid_masks[:, None], shallow * vid_masks[:, None]
+    tokens = torch.randn(sum(sizes), 32, lq, generator=g)
+    tok_len = [7, 5, 6]
+    token_masks = torch.stack([torch.arange(lq) < n for n in tok_len])[:, None]           # (B', 1, Lq)
+    tokens = tokens * token_masks
+    text_cls = torch.randn(sum(sizes), 64, generator=g)
+    # the padded per-video layout of the training collate (model.py:617-622): (bs, max_k, C, Lq) / (bs, max_k, Lq)
+    mk = max(sizes)
+    text_pad = torch.zeros(bs, mk, 32, lq)
+    mask_pad = torch.zeros(bs, mk, lq, dtype=torch.bool)
+    q = 0
+    for b, k in enumerate(sizes):
+        text_pad[b, :k] = tokens[q:q + k]
+        mask_pad[b, :k] = token_masks[q:q + k, 0]
+        q += k
+    out4 = model(vid, shallow, vid_masks, text_pad, text_cls, mask_pad, text_size=torch.tensor(sizes), eval=False)
+    out = dict(opt_kwargs=kw, meta=dict(bs=bs, T=T, lq=lq, sizes=sizes, wseed=901), shapes=shapes, vid=vid, shallow=shallow,
+               vid_masks=vid_masks, tokens=tokens, token_masks=token_masks, text_cls=text_cls)
+    names = ('logits1', 'logits2', 'offsets', 'masks')
+    for part, name in zip(out4, names):
+        for l, x in enumerate(part):
+            out[f'{name}/l{l}'] = x
+    # losses as the Trainer stitches them (worker_v2.py:431-461)
+    l1, l2 = torch.cat(out4[0], 1), torch.cat(out4[1], 1)
+    off, msk = torch.cat(out4[2], 1), torch.cat(out4[3], 1)
+    gt_labels = torch.rand(l1.shape, generator=g) < 0.08
+    gt_offsets = torch.rand(off.shape, generator=g) * 20
+    pos = torch.logical_and(gt_labels, msk)
+    out['gt_labels'], out['gt_offsets'] = gt_labels, gt_offsets
+    sm, al = 0.2, 0.5
+    lab = gt_labels.float() * (1.0 - sm) + sm / 2
+    out['loss/focal1_sum'] = sigmoid_focal_loss(l1[msk], lab[msk], alpha=al, reduction='sum')
+    out['loss/focal2_sum'] = sigmoid_focal_loss(l2[msk], lab[msk], alpha=al, reduction='sum')
+    out['loss/focal2_none'] = sigmoid_focal_loss(l2, lab, alpha=al, reduction='none')
+    out['loss/focal2_nosmooth_mean'] = sigmoid_focal_loss(l2[msk], gt_labels.float()[msk], alpha=-1.0, gamma=1.5, smoothing=False, reduction='mean')
+    out['loss/diou_sum'] = ctr_diou_loss(off[pos], gt_offsets[pos], reduction='sum')
+    out['loss/giou_sum'] = ctr_giou_loss(off[pos], gt_offsets[pos], reduction='sum')
+    out['loss/diou_none'] = ctr_diou_loss(off.reshape(-1, 2), gt_offsets.reshape(-1, 2), reduction='none')
+    out['loss/giou_mean'] = ctr_giou_loss(off[pos], gt_offsets[pos], reduction='mean')
+    out['loss/n_pos'] = pos.sum()
+    save('train.npz', out)
+
+
 # ------------------------------------------------------------------ G5: NMS known answers
 @torch.no_grad()
 def gen_nms(ext):
@@ -676,6 +749,8 @@ if __name__ == '__main__':
         gen_e2e_variants()
     if 'text_identity' in which or 'e2e' in which:
         gen_text_identity()
+    if 'train' in which:
+        gen_train()
     if 'postproc' in which:
         gen_postproc()
     if 'postproc_ext' in which or 'postproc' in which:

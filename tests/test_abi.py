@@ -104,8 +104,18 @@ def test_unsupported_switches_fail_loudly():
     with pytest.raises(NotImplementedError):
         pkg.modeling.create_model(opt)
     model = pkg.modeling.create_model(pkg.config.make_opt(**kw))
-    with pytest.raises(NotImplementedError):
-        model(torch.zeros(1, 64, 128), torch.zeros(1, 64, 128), torch.ones(1, 128, dtype=torch.bool), (), torch.zeros(0, 64), ())
+    # the training-mode forward computes forward values only: any dropout probability > 0 is refused (no random stream here)
+    opt_d = pkg.config.make_opt(**kw)
+    opt_d.model.vid_net['path_pdrop'] = 0.1
+    with pytest.raises(NotImplementedError, match='path_pdrop'):
+        pkg.modeling.create_model(opt_d)(torch.zeros(1, 64, 128), torch.zeros(1, 64, 128), torch.ones(1, 128, dtype=torch.bool),
+                                         torch.zeros(1, 32, 4), torch.zeros(1, 64), torch.ones(1, 1, 4, dtype=torch.bool))
+    with pytest.raises(RuntimeError, match='GPU'):   # ... and it runs on the MI355X only
+        model(torch.zeros(1, 64, 128), torch.zeros(1, 64, 128), torch.ones(1, 128, dtype=torch.bool), torch.zeros(1, 32, 4), torch.zeros(1, 64),
+              torch.ones(1, 1, 4, dtype=torch.bool))
+    with pytest.raises(NotImplementedError):          # the late-fusion model's training forward is not built
+        pkg.modeling.PtTransformer(pkg.config.make_opt(**kw))(torch.zeros(1, 64, 128), torch.zeros(1, 64, 128), torch.ones(1, 128, dtype=torch.bool),
+                                                            torch.zeros(1, 32, 4), torch.zeros(1, 64), torch.ones(1, 1, 4, dtype=torch.bool))
     with pytest.raises(RuntimeError, match='GPU'):   # CPU tensors: no fallback
         model(torch.zeros(1, 64, 128), torch.zeros(1, 64, 128), torch.ones(1, 128, dtype=torch.bool), (), torch.zeros(0, 64), (), eval=True)
 

@@ -120,6 +120,44 @@ def test_linear_with_fused_layernorm(L, M, K, relu, raw, N, nterms):
         torch.testing.assert_close(C.cpu().double(), v, rtol=2e-5, atol=2e-5)
 
 
+# (M, N1, K1, N2, residual, gelu, nterms, row mean): tile shapes 128x256 (M >= 65536), 64x256, 64x128, 64x64 on the producer side
+# (1 / 1 / 2 / 4 partial-sum slots per row), the last row tile partial; a row mean of 3 sigma checks the one-pass variance
+@pytest.mark.parametrize('M,N1,K1,N2,res,gelu,nterms,shift', [
+    (65600, 256, 256, 1024, 1, 1, 16, 0.0), (28700, 256, 256, 1024, 1, 1, 16, 0.0), (14400, 256, 256, 1024, 0, 1, 16, 3.0),
+    (8200, 256, 128, 256, 1, 0, 16, 0.0), (28700, 512, 256, 512, 0, 1, 6, 0.0), (16500, 128, 64, 512, 0, 0, 16, -2.0)])
+def test_linear_layernorm_carried_as_row_statistics(L, M, N1, K1, N2, res, gelu, nterms, shift):
+    """X = A W1^T + b1 (+ R) with (sum, sum of squares) per row on the side, then act(LayerNorm(X) W2^T + b2) from the raw X
+    with the gain folded into W2 and (mean, rstd) applied in the epilogue -- against fp64 (dcf_op_linear_ln_carry)"""
+    pkg, lib = L
+    g = torch.Generator().manual_seed(M + N1 + N2)
+    A = torch.randn(M, K1, generator=g)
+    W1 = torch.randn(N1, K1, generator=g) / math.sqrt(K1)
+    b1 = torch.randn(N1, generator=g) * 0.3 + shift
+    R = torch.randn(M, N1, generator=g) if res else None
+    lw, lb = torch.rand(N1, generator=g) + 0.5, torch.randn(N1, generator=g) * 0.5
+    W2 = torch.randn(N2, N1, generator=g) / math.sqrt(N1)
+    b2 = torch.randn(N2, generator=g) * 0.3
+    x = A.double() @ W1.double().t() + b1.double()
+    if res:
+        x = x + R.double()
+    mu = x.mean(1, keepdim=True)
+    ln = (x - mu) / torch.sqrt(((x - mu) ** 2).mean(1, keepdim=True) + 1e-5) * lw.double() + lb.double()
+    y = ln @ W2.double().t() + b2.double()
+    if gelu:
+        y = F.gelu(y)
+    X = torch.empty(M, N1, device='cuda')
+    Y = torch.empty(M, N2, device='cuda')
+    d = {k: v.cuda() for k, v in dict(A=A, W1=W1, b1=b1, lw=lw, lb=lb, W2=W2, b2=b2).items()}     # alive until the synchronising .cpu() below
+    Rd = R.cuda() if res else None
+    pkg._lib.check(lib.dcf_op_linear_ln_carry(P(d['A']), P(d['W1']), P(d['b1']), P(Rd) if res else None, P(d['lw']), P(d['lb']),
+                                              P(d['W2']), P(d['b2']), P(X), P(Y), M, N1, K1, N2, gelu, nterms, st()))
+    torch.testing.assert_close(X.cpu().double(), x, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(Y.cpu().double(), y, rtol=2e-5, atol=2e-5)
+    with pytest.raises(RuntimeError, match='k-sliced'):                  # small grids do not carry statistics: refused, not wrong
+        pkg._lib.check(lib.dcf_op_linear_ln_carry(P(d['A']), P(d['W1']), P(d['b1']), None, P(d['lw']), P(d['lb']),
+                                                  P(d['W2']), P(d['b2']), P(X), P(Y), 1024, N1, K1, N2, gelu, nterms, st()))
+
+
 @pytest.mark.parametrize('nterms,tol', [(6, 2e-5), (16, 2e-5)])
 @pytest.mark.parametrize('M,N,K', [(256, 256, 512), (1000, 128, 64), (4096, 256, 1024), (16384, 256, 96), (20, 128, 32)])
 def test_linear_channel_major_split(L, M, N, K, nterms, tol):

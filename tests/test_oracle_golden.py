@@ -126,7 +126,7 @@ def test_gate_cases():
 
 
 # ------------------------------------------------------------------ G3
-@pytest.mark.parametrize('name', ['c1', 'pe', 'nomsf', 'scat', 'sfonly'])
+@pytest.mark.parametrize('name', ['c1', 'pe', 'nomsf', 'scat', 'sfonly', 'affine'])
 def test_end_to_end(name):
     g = Golden(f'e2e_{name}.npz')
     pkg = load_pkg()
@@ -189,6 +189,45 @@ def test_postproc_ext_scores():
                                       [g.t(f'l{l}/mask') for l in range(L)], pre_nms_topk=meta['pre_nms_topk'], ext_scores=g.t('ext'))
     close(segs, g.t('segs'), atol=0, rtol=0)
     close(scores, g.t('scores'), atol=0, rtol=0)
+
+
+# ------------------------------------------------------------------ G3b: training-mode forward values + point losses
+def test_training_forward_and_losses_match_reference():
+    """oracle forward_train (model.py:567-632 with dropout 0) and the loss restatements (loss.py) against the reference's own
+    train()-mode forward and loss functions (tests/golden/train.npz)"""
+    g = Golden('train.npz')
+    meta, kw = g.js('meta'), g.js('opt_kwargs')
+    pkg = load_pkg()
+    sd = pkg.synth.make_state_dict(g.js('shapes'), meta['wseed'])
+    opt = pkg.config.make_opt(**kw)
+    out4 = R.forward_train(sd, opt.model, g.t('vid'), g.t('shallow'), g.t('vid_masks'), g.t('tokens'), g.t('token_masks'),
+                           g.t('text_cls'), meta['sizes'])
+    L = kw['n_levels']
+    for part, name in zip(out4, ('logits1', 'logits2', 'offsets', 'masks')):
+        for l in range(L):
+            want = g.t(f'{name}/l{l}')
+            if name == 'masks':
+                assert torch.equal(part[l], want)
+            else:
+                torch.testing.assert_close(part[l], want, rtol=1e-4, atol=1e-4)
+    l1 = torch.cat([g.t(f'logits1/l{l}') for l in range(L)], 1)
+    l2 = torch.cat([g.t(f'logits2/l{l}') for l in range(L)], 1)
+    off = torch.cat([g.t(f'offsets/l{l}') for l in range(L)], 1)
+    msk = torch.cat([g.t(f'masks/l{l}') for l in range(L)], 1)
+    gt_labels, gt_offsets = g.t('gt_labels'), g.t('gt_offsets')
+    pos = gt_labels & msk
+    assert int(pos.sum()) == int(g.t('loss/n_pos'))
+    lab = gt_labels.float() * 0.8 + 0.1
+    tol = dict(rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(R.sigmoid_focal_loss(l1[msk], lab[msk], alpha=0.5).sum(), g.t('loss/focal1_sum'), **tol)
+    torch.testing.assert_close(R.sigmoid_focal_loss(l2[msk], lab[msk], alpha=0.5).sum(), g.t('loss/focal2_sum'), **tol)
+    torch.testing.assert_close(R.sigmoid_focal_loss(l2, lab, alpha=0.5), g.t('loss/focal2_none'), **tol)
+    torch.testing.assert_close(R.sigmoid_focal_loss(l2[msk], gt_labels.float()[msk], alpha=-1.0, gamma=1.5, smoothing=False).mean(),
+                               g.t('loss/focal2_nosmooth_mean'), **tol)
+    torch.testing.assert_close(R.ctr_iou_loss(off[pos], gt_offsets[pos], 'diou').sum(), g.t('loss/diou_sum'), **tol)
+    torch.testing.assert_close(R.ctr_iou_loss(off[pos], gt_offsets[pos], 'giou').sum(), g.t('loss/giou_sum'), **tol)
+    torch.testing.assert_close(R.ctr_iou_loss(off.reshape(-1, 2), gt_offsets.reshape(-1, 2), 'diou'), g.t('loss/diou_none'), **tol)
+    torch.testing.assert_close(R.ctr_iou_loss(off[pos], gt_offsets[pos], 'giou').mean(), g.t('loss/giou_mean'), **tol)
 
 
 # ------------------------------------------------------------------ G5
