@@ -229,6 +229,7 @@ struct dcf_model {
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   bool capturing = false;
+  int graph_mode = 0;                        // dcf_model_set_graph_mode: 0 auto (by size), 1 always, 2 never
   std::vector<uint64_t> nocapture_key;       // argument set whose capture failed: run it eagerly, do not retry every call
   int last_launch = 0;                       // how the last forward was issued: 0 eager, 1 graph replay, 2 graph capture + launch
   // The legacy default stream (NULL: what torch's default stream is) cannot be captured.  A forward called on it hops to
@@ -738,8 +739,14 @@ static bool can_carry_ln(dcf_model* m, const float* fc_wf, int rows, int n_prod,
 // can this GEMM carry its LayerNorm in the epilogue?  (bf16-split path with planes for W, tile spanning the row)
 // ... and is its K loop long enough to pay for the heavier epilogue (two workgroup-wide reductions on a 64-row tile)?  At
 // K = 256 the fused kernel takes 117 us for 81920 rows against 55 + 39 us for the 128x256 kernel + the LayerNorm kernel (65
-// against 28 + 20 us at 40960 rows); at K = 768 (embedding convolutions) 232 against ~280 us, at K = 1024 a tie.
+// against 28 + 20 us at 40960 rows); at K = 768 (embedding convolutions) 232 against ~280 us, at K = 1024 a tie (81920 rows,
+// round 2: the unfused kernel was the 64x256 tile too).
 static bool can_fuse_ln(dcf_model* m, const float* W, int M, int N, int K, GemmAMode mode) {
+  // ... and only below 64 K rows: from there on the unfused GEMM runs on the 128x256 tile, which beats the 64x256 tile the
+  // fused epilogue needs by more than the LayerNorm pass costs.  Measured at 8 videos per forward (profiles/r03_notes.md):
+  // 131072x256x1024 fused 327 us against 228 + 49 us; the k3 convolutions 261120x256x768 366 against 285 + 53 us and
+  // 131072x256x768 238 against 146 + 53 us (the 128x256 k3 tile reaches 350 - 360 TFLOP/s, 0.43 of the f16x3 peak).
+  if (M >= 65536) return false;
   return m->gemm_terms != 0 && m->wsplit.count(W) && m->wsplit_ldw[W] == K && K >= 512 && gemm_can_fuse_ln(M, N, K, mode);
 }
 
@@ -1359,7 +1366,12 @@ static int forward_maybe_graph(dcf_model* m, const VideoSet& vs, int T0, int nq,
                                const float* const* text, const uint8_t* const* text_mask, const int32_t* text_len,
                                const float* gate, float* lo, float* oo, uint8_t* mo, hipStream_t st) {
   static const bool no_graph = getenv("DCF_NO_GRAPH") != nullptr;
-  const bool eligible = !no_graph && !g_prof_on && !m->keep_debug && nq > 0;
+  // Auto: replay a graph only for forwards of >= 64 K level-0 rows.  Measured on MI355X (profiles/r03_notes.md): the batched
+  // forward runs at the same speed either way (25.36 vs 25.35 ms per 24-video step) and the graph shields it from host
+  // jitter; ONE video per call (~100 launches of 5 - 40 us) is 5 % faster launched eagerly (1.75 vs 1.84 ms: a graph node
+  // costs ~0.9 us more than an in-order launch, and the host needs ~0.5 ms to issue the forward the GPU takes 1.75 ms for).
+  const bool want = m->graph_mode == 1 || (m->graph_mode == 0 && (long long)nq * T0 >= 65536);
+  const bool eligible = want && !no_graph && !g_prof_on && !m->keep_debug && nq > 0;
   if (!eligible) {
     m->last_launch = 0;
     return forward(m, vs, T0, nq, text, text_mask, text_len, gate, lo, oo, mo, st);
@@ -1500,6 +1512,13 @@ int dcf_forward_eval_gated(dcf_model* m, const float* vid, const float* shallow_
 }
 
 int dcf_graph_active(const dcf_model* m) { return m ? m->last_launch : 0; }
+
+int dcf_model_set_graph_mode(dcf_model* m, int32_t mode) {
+  DCF_CHECK(m && mode >= 0 && mode <= 2, "dcf_model_set_graph_mode: mode must be 0 (auto), 1 (always) or 2 (never)");
+  if (mode != m->graph_mode) dcf::drop_graph(m);
+  m->graph_mode = mode;
+  return 0;
+}
 
 int dcf_debug_copy(dcf_model* m, int32_t what, float* dst, int64_t max_floats, void* stream) {
   DCF_CHECK(m && dst, "dcf_debug_copy: null argument");

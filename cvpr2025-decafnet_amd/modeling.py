@@ -341,6 +341,12 @@ class _Engine:
         except Exception:
             pass
 
+    def set_graph_mode(self, mode):
+        code = {'auto': 0, 'always': 1, 'never': 2}[mode]
+        if getattr(self, '_graph_mode', None) != code:
+            _lib.check(self.lib.dcf_model_set_graph_mode(self.handle, code), 'dcf_model_set_graph_mode')
+            self._graph_mode = code
+
     def bind(self, model):
         """(Re)bind the module's parameters if their storage or contents changed.  The walk over the module tree
         (state_dict) costs about as much host time as a whole T = 16384 forward takes on the GPU, so the tensor list is
@@ -356,6 +362,7 @@ class _Engine:
             self.cached_ids = ids
             self.signature = None
         named_tensors = self.cached
+        self.set_graph_mode(getattr(model, 'graph_mode', 'auto'))
         sig = tuple((t.data_ptr(), t._version) for _, t in named_tensors)
         if sig == self.signature:
             return
@@ -472,6 +479,9 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         # graph instead of ~135 kernel launches -- results of call k are overwritten by call k+1.
         self.reuse_output_buffers = False
         self._out_cache = {}
+        # 'auto' (replay a HIP graph for large batched forwards, launch small ones eagerly: dcf_model_set_graph_mode),
+        # 'always' or 'never'
+        self.graph_mode = 'auto'
 
     # -- reference API ---------------------------------------------------------------------
     def encode_text(self, tokens, token_masks):
@@ -831,6 +841,7 @@ class PtTransformer(PtTransformerEarlyFusionIterative):
         self._engine = None
         self.reuse_output_buffers = False
         self._out_cache = {}
+        self.graph_mode = 'auto'
 
 
 def create_model(opt):

@@ -184,6 +184,10 @@ int dcf_debug_copy(dcf_model* m, int32_t what, float* dst, int64_t max_floats, v
  * graph, 2 = the call that captured the graph (and launched it).  A forward called on the NULL (legacy default) stream,
  * which cannot be captured, runs on an engine-owned stream ordered after / before the caller's by events.  ABI version 4. */
 int dcf_graph_active(const dcf_model* m);
+/* HIP-graph policy of the repeated forward: 0 = auto (replay for forwards of >= 65536 level-0 rows, i.e. batched queries /
+ * videos; eager launches for the one-video-per-call pattern, which measures 5 % faster that way), 1 = always capture and
+ * replay, 2 = never.  The environment variable DCF_NO_GRAPH=1 disables graphs whatever the mode.  ABI version 5. */
+int dcf_model_set_graph_mode(dcf_model* m, int32_t mode);
 
 /* --------------------------------------------------------------------------------------------
  * Proposal decoding: replaces Evaluator._collect_segments (libs/worker_v2.py:1131-1187).
