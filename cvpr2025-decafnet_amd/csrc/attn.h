@@ -12,6 +12,10 @@ struct XAttnArgs {
   const uint8_t* kvmask;   // [B*Lk]    1 = valid key
   float* O;                // [B*T][C]  context, heads concatenated along C
   int B, T, Lk, C, heads;
+  // sticky numerics word of the model (bit 0): the MFMA core carries q d^-1/4, k d^-1/4, v as two fp16 planes whatever
+  // opt.model.gemm_mode is, so an operand beyond the fp16 range (|x| > 65504) or a non-finite one is reported here instead of
+  // turning into inf / NaN context rows silently; nullptr = not reported
+  unsigned* status;
 };
 
 struct LocalAttnArgs {

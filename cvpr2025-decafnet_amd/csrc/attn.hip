@@ -150,6 +150,11 @@ __global__ __launch_bounds__(256) void k_xattn_mfma(XAttnArgs p) {
   const int r = lane & 15, g = lane >> 4;
   const float scale = 1.0f / sqrtf(sqrtf((float)D));
 
+  bool nonfinite = false;                // an operand this thread split into fp16 planes was out of range / not finite
+  auto track = [&](const f32x4& x) __attribute__((always_inline)) {
+    const float m4 = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w)));
+    nonfinite |= !(m4 <= 65504.f);       // also true for NaN
+  };
   for (int i = tid; i < (KT16 + REM) * (D / 4); i += 256) {
     const int key = i / (D / 4), c4 = i % (D / 4);
     f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
@@ -157,6 +162,7 @@ __global__ __launch_bounds__(256) void k_xattn_mfma(XAttnArgs p) {
       const size_t off = ((size_t)b * Lk + key) * C + (size_t)head * D + c4 * 4;
       kv = *reinterpret_cast<const f32x4*>(p.K + off) * scale;
       vv = *reinterpret_cast<const f32x4*>(p.V + off);
+      if (key < KT16) { track(kv); track(vv); }
     }
     if (key < KT16) {
       xh4 hi, lo;
@@ -178,7 +184,8 @@ __global__ __launch_bounds__(256) void k_xattn_mfma(XAttnArgs p) {
   const int n_groups = (p.T + ROWS - 1) / ROWS;
   // Q fragments are fetched TWO row groups ahead (two statically indexed register sets, the loop is unrolled by two): a wave
   // has nothing but its own requests in flight to cover the HBM latency with.
-  f32x4 qn_[2][QT][D16];
+  constexpr int QA = 2;                 // row groups of q in flight per wave (3: no faster, 12 more registers)
+  f32x4 qn_[QA][QT][D16];
   auto fetch_q = [&](int grp, f32x4 (&qn)[QT][D16]) __attribute__((always_inline)) {
     if (grp >= n_groups) return;
 #pragma unroll
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(256) void k_xattn_mfma(XAttnArgs p) {
         split4(q[t][c], qh[t][c], ql[t][c]);
       }
     }
-    fetch_q(grp + 2 * (int)gridDim.x, qn);           // this set is free again: request the group after next
+    fetch_q(grp + QA * (int)gridDim.x, qn);          // this set is free again: request the group QA ahead
     // ---- S^T tiles
     f32x4 s[QT][NKT > 0 ? NKT : 1];
 #pragma unroll
@@ -249,6 +256,10 @@ __global__ __launch_bounds__(256) void k_xattn_mfma(XAttnArgs p) {
       for (int kt = 0; kt < NKT; ++kt) {
         const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + 16 * kt + 4 * g);
         s[t][kt] += mk;
+        // a q value beyond the fp16 range (hi plane inf, lo plane NaN) or a non-finite one turns EVERY score of its row into NaN
+        // (a masked key gives -inf, never NaN): one compare per row instead of a range test per operand, which cost 17 % of
+        // this kernel
+        if (kt == 0) nonfinite |= s[t][0].x != s[t][0].x;
         mx = fmaxf(fmaxf(mx, fmaxf(s[t][kt].x, s[t][kt].y)), fmaxf(s[t][kt].z, s[t][kt].w));
       }
       if (NKT > 0) mx = xor32_max(xor16_max(mx));
@@ -294,12 +305,14 @@ __global__ __launch_bounds__(256) void k_xattn_mfma(XAttnArgs p) {
         if (live[t]) *reinterpret_cast<f32x4*>(p.O + row[t] * C + (size_t)head * D + 4 * g + 16 * ct) = o[t];
     }
   };
-  fetch_q(blockIdx.x, qn_[0]);
-  fetch_q(blockIdx.x + gridDim.x, qn_[1]);
-  for (int grp = blockIdx.x; grp < n_groups; grp += 2 * gridDim.x) {
-    process(grp, qn_[0]);
-    if (grp + (int)gridDim.x < n_groups) process(grp + gridDim.x, qn_[1]);
+#pragma unroll
+  for (int a = 0; a < QA; ++a) fetch_q(blockIdx.x + a * gridDim.x, qn_[a]);
+  for (int grp = blockIdx.x; grp < n_groups; grp += QA * gridDim.x) {
+#pragma unroll
+    for (int a = 0; a < QA; ++a)
+      if (grp + a * (int)gridDim.x < n_groups) process(grp + a * gridDim.x, qn_[a]);
   }
+  if (nonfinite && p.status) atomicOr(p.status, 1u);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -451,7 +464,10 @@ static int launch_xattn_mfma(const XAttnArgs& a, hipStream_t st) {
   // enough workgroups to fill the chip, few enough that K/V staging (2*Lk*d floats) is amortised
   int gx = n_groups;
   const int per = a.heads * a.B;
-  const int cap = (1536 + per - 1) / per;
+  // 1024 workgroups = two rounds of the 512 resident ones (186 registers: 2 per CU).  Round 3, interleaved A/B on one box at
+  // BASELINE config 2: 1024 -> 66.3 - 70.7 us cold / 5.14 - 5.26 TB/s warm; 1536 -> 68.8 - 71.0 us / 4.95 - 4.99 TB/s; 512 and
+  // 2048 / 3072 slower; three row groups of q in flight instead of two: no change (profiles/r03_notes.md)
+  const int cap = (1024 + per - 1) / per;
   if (gx > cap) gx = cap;
   dim3 grid(gx, a.heads, a.B);
   constexpr int D = 16 * D16;

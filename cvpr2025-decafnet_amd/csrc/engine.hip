@@ -905,11 +905,11 @@ static int run_fusion(dcf_model* m, Buffers& b, float* X, int64_t ldx, int B, in
     TRY(run_gemm(m, gkv, 2, A_ROWS, st));
     if (lt) {
       for (int l = 0; l < lt->n_levels; ++l) {
-        XAttnArgs xa{b.R[2] + (int64_t)lt->start[l] * E, b.Kt, b.Vt, b.kvmask, b.R[0] + (int64_t)lt->start[l] * E, B, lt->T[l], Lk, E, c.fusion_heads};
+        XAttnArgs xa{b.R[2] + (int64_t)lt->start[l] * E, b.Kt, b.Vt, b.kvmask, b.R[0] + (int64_t)lt->start[l] * E, B, lt->T[l], Lk, E, c.fusion_heads, m->status};
         TRY(launch_xattn(xa, st));
       }
     } else {
-      XAttnArgs xa{b.R[2], b.Kt, b.Vt, b.kvmask, b.R[0], B, T, Lk, E, c.fusion_heads};
+      XAttnArgs xa{b.R[2], b.Kt, b.Vt, b.kvmask, b.R[0], B, T, Lk, E, c.fusion_heads, m->status};
       TRY(launch_xattn(xa, st));
     }
     if (m->gemm_terms != 0 && w.wp_il && m->wsplit.count(w.wp_il) && gemm_can_fuse_adaln(rows, 2 * E, E)) {
@@ -1221,7 +1221,7 @@ static int text_encode(dcf_model* m, const float* tokens, const uint8_t* token_m
       GemmArgs g3[3] = {gemm(X, TE, w.wq, w.bq, Q, TE, Lk, TE, TE), gemm(X, TE, w.wk, w.bk, K, TE, Lk, TE, TE),
                         gemm(X, TE, w.wv, w.bv, V, TE, Lk, TE, TE)};
       TRY(run_gemm(m, g3, 3, A_ROWS, st));
-      XAttnArgs xa{Q, K, V, mask_out, R0, 1, Lk, Lk, TE, c.text_heads};
+      XAttnArgs xa{Q, K, V, mask_out, R0, 1, Lk, Lk, TE, c.text_heads, m->status};
       TRY(launch_xattn(xa, st));
       GemmArgs gp = gemm(R0, TE, w.wp, w.bp, X, TE, 1, TE, TE);                       // only the pooled row is kept
       TRY(run_gemm(m, &gp, 1, A_ROWS, st));
@@ -1236,7 +1236,7 @@ static int text_encode(dcf_model* m, const float* tokens, const uint8_t* token_m
     GemmArgs g3[3] = {gemm(R0, TE, w.wq, w.bq, Q, TE, Lk, TE, TE), gemm(R0, TE, w.wk, w.bk, K, TE, Lk, TE, TE),
                       gemm(R0, TE, w.wv, w.bv, V, TE, Lk, TE, TE)};
     TRY(run_gemm(m, g3, 3, A_ROWS, st));
-    XAttnArgs xa{Q, K, V, mask_out, R0, 1, Lk, Lk, TE, c.text_heads};                   // softmax over the valid tokens
+    XAttnArgs xa{Q, K, V, mask_out, R0, 1, Lk, Lk, TE, c.text_heads, m->status};                   // softmax over the valid tokens
     TRY(launch_xattn(xa, st));
     GemmArgs gp = gemm(R0, TE, w.wp, w.bp, X2, TE, Lk, TE, TE);                        // x = skip * mask + ls * proj(ctx)
     gp.flags = G_RES; gp.R = X; gp.ldr = TE; gp.ls = w.ls_attn;
