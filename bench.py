@@ -516,6 +516,24 @@ def main():
             result['one_video_per_call'] = {'value': vid_len * args.nq / dt, 'unit': 'clips/s', 'ms_per_forward': 1e3 * dt,
                                             'launch': launch_note[model.graph_active()],
                                             'note': 'the reference\'s calling pattern (model.py:496: one video per call), default stream, rank 0 only'}
+            # ... with its own roofline: the same forward under the per-launch HIP-event profiler
+            lib.dcf_profile_enable(1)
+            for _ in range(5):
+                model(vid, shallow, vmask, texts, text_cls, tmasks, eval=True)
+            torch.cuda.synchronize()
+            need = lib.dcf_profile_report(None, 0)
+            buf = ctypes.create_string_buffer(int(need) + 16)
+            lib.dcf_profile_report(buf, len(buf))
+            lib.dcf_profile_enable(0)
+            p1 = json.loads(buf.value.decode())
+            g1 = [k for k in p1 if k.startswith(fam)]
+            d1 = {f: sum(p1[k][f] for k in g1) for f in ('ms', 'flops', 'count')}
+            t1_ms = sum(v['ms'] for v in p1.values())
+            a1 = d1['flops'] / (d1['ms'] * 1e-3) / 1e12
+            result['one_video_per_call']['roofline'] = {
+                'kernel': '%s family, one video per forward (%.0f%% of the forward)' % (fam, 100 * d1['ms'] / t1_ms), 'bound': 'mfma',
+                'achieved': a1, 'peak': peak, 'unit': 'TFLOP/s', 'frac': a1 / peak, 'launches_per_forward': sum(v['count'] for v in p1.values()) / 5,
+                'event_ms_per_forward': t1_ms / 5, 'non_gemm_share': 1.0 - d1['ms'] / t1_ms}
 
         # ---- proposal decode + NMS (reported separately) and the NMS index match
         if extras:

@@ -18,6 +18,7 @@ enum GemmFlags {
   G_RES_MASK = 8,
   G_OUT_MASK = 16,
   G_AMASK = 32,     // A_ROWS: multiply A rows by rowmask on load (MaskedConv1D's x * mask)
+  G_TAPSLAB = 128,  // A_ROWS_TAP3, split kernels: walk K channel slab by channel slab, taps innermost (set by launch_gemm_split)
   G_ADALN = 64,     // the N output columns are blocks of (32 scale columns, 32 shift columns of the same channels) -- weight
                     // rows ordered like that by the caller: C[m][c] = R[m][c] * scale[m][c] + shift[m][c], the AdaLN modulation
                     // of the fusion decoder (blocks.py:643-646); C and R have N / 2 columns.  Split kernel, tiles whose waves

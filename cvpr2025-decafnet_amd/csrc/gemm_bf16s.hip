@@ -210,13 +210,25 @@ __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4 || (NST > 2
   for (int j = 0; j < TN; ++j)
     w_ptr[j] = reinterpret_cast<const bf16x8*>(p.Ws + ((int64_t)(n0 / 32 + wn * TN + j) * KT) * BLK) + lane;
 
+  // k3 convolutions walk K channel slab by channel slab with the three taps innermost (physical K tile = tap * cin / 32 + slab):
+  // the taps read rows m - 1, m, m + 1 of the SAME 128-byte channel slab back to back, so two of the three reads hit L1 / L2.
+  // Tap-major order re-read the whole row tile three times, 9 K tiles apart: the PMC passes showed 3.3x the algorithmic
+  // A bytes on the HBM side of L2 for these kernels (profiles/r03_notes.md).
+  // Interleaved A/B on one box (8 x 16384 rows, us per launch, tap-major -> slab-major): 128x96 pair launch 878 -> 854,
+  // 128x256 tile 261120x256x768 307 -> 303 and 131072x256x768 156.5 -> 153.3.
+  const bool slab_major = AMODE == A_ROWS_TAP3 && (p.flags & G_TAPSLAB);      // uniform
+  const int slabs = slab_major ? p.cin / SBK : 1;
+  auto phys_kt = [&](int kt) __attribute__((always_inline)) -> int {
+    if (slab_major) { const int slab = kt / 3, tap = kt - 3 * slab; return tap * slabs + slab; }
+    return kt;
+  };
   f32x4 araw_[NST][ACH][2];
-  auto load_a = [&](int kt, f32x4 (&araw)[ACH][2]) __attribute__((always_inline)) {
-    const int k0 = kt * SBK;
+  auto load_a = [&](int kt_, f32x4 (&araw)[ACH][2]) __attribute__((always_inline)) {
+    const int k0 = phys_kt(kt_) * SBK;
     int64_t shift = k0;
     unsigned bit = 1u;
     if constexpr (AMODE == A_ROWS_TAP3) {
-      const int tap = k0 / p.cin;
+      const int tap = slab_major ? kt_ % 3 : k0 / p.cin;
       bit = tap == 0 ? 2u : (tap == 1 ? 1u : 4u);
       shift = (int64_t)(tap - 1) * p.lda + (k0 - tap * p.cin);
     }
@@ -267,7 +279,8 @@ __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4 || (NST > 2
   };
   // B fragments of one K tile: [chunk][tile][plane]
   bf16x8 bfr_[NST][2][TN][NPL];
-  auto load_b = [&](int kt, bf16x8 (&bfr)[2][TN][NPL]) __attribute__((always_inline)) {
+  auto load_b = [&](int kt_, bf16x8 (&bfr)[2][TN][NPL]) __attribute__((always_inline)) {
+    const int kt = phys_kt(kt_);
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -658,6 +671,8 @@ int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, 
   DCF_CHECK(nterms == T_F16 || nterms == 6, "launch_gemm_split: nterms must be 16 (f16x3) or 6 (bf16x6)");
   GemmBatch b;
   for (int i = 0; i < 3; ++i) b.g[i] = g[i < count ? i : 0];
+  if (mode == A_ROWS_TAP3)                                  // k3 convolutions walk K slab-major (see gemm_bf16s_kernel)
+    for (int i = 0; i < 3; ++i) b.g[i].flags |= G_TAPSLAB;
   const GemmArgs& p = g[0];
   for (int i = 0; i < count; ++i) {
     DCF_CHECK(g[i].M == p.M && g[i].N == p.N && g[i].K == p.K, "launch_gemm_split: grouped shapes differ");
