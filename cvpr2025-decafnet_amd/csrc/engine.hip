@@ -557,7 +557,7 @@ static int finalize(dcf_model* m, hipStream_t st) {
     m->dec.push_back(w);
   }
   GET("fusion.ln_out.weight", SH(E), m->fus_out_w); GET("fusion.ln_out.bias", SH(E), m->fus_out_b);
-  if (c.model_kind == 0) {
+  if (c.model_kind != 1) {
     GET("vid_net.embd_fc.conv.weight", SH(E, E), m->embd_fc_w); GET("vid_net.embd_fc.conv.bias", SH(E), m->embd_fc_b);
     SPLIT(m->embd_fc_w, E, E);
   }
@@ -583,7 +583,7 @@ static int finalize(dcf_model* m, hipStream_t st) {
     m->branch.push_back(w);
   }
   if (resolve_head(m, "cls_head", "cls_head", E, 1, c.head_layers, st, m->cls1)) return -1;
-  const int EH = c.model_kind == 1 ? E : E + TCN_HID;
+  const int EH = c.model_kind == 0 ? E + TCN_HID : E;      // only the iterative model concatenates the refined logits (model.py:426-428)
   if (c.model_kind == 0 && resolve_head(m, "cls_head2", "cls_head", EH, 1, c.head_layers, st, m->cls2)) return -1;
   if (resolve_head(m, "reg_head", "reg_head", EH, 2, c.head_layers, st, m->reg)) return -1;
   m->reg_scales.assign(L, 1.f);
@@ -1090,14 +1090,14 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
     const TextMeta* dm = &tm;
 
     // ---- early fusion: XAttNFusion on the level-0 sequence (fusion.py:56-66)
-    if (c.model_kind == 0) {
+    if (c.model_kind != 1) {
       TRY(run_fusion(m, b, b.X, E, B, T0, nullptr, mask0, nullptr, dm, Lk, b.R[0], E, st));
       if (m->keep_debug && m->dbg_fused) DCF_HIP(hipMemcpyAsync(m->dbg_fused, b.R[0], (size_t)rows0 * E * 4, hipMemcpyDeviceToDevice, st));
     }
 
     // ---- vid_net: VideoTransformer.forward (video_net.py:123-164)
     {
-      if (c.model_kind == 0) {
+      if (c.model_kind != 1) {
         GemmArgs ge = gemm(b.R[0], E, m->embd_fc_w, m->embd_fc_b, b.X, E, rows0, E, E);
         ge.flags = G_AMASK; ge.rowmask = mask0;
         TRY(run_gemm(m, &ge, 1, A_ROWS, st));
@@ -1148,8 +1148,8 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
     if (c.model_kind == 1 || c.second_fusion)
       TRY(run_fusion(m, b, b.F, E + TCN_HID, B, T0, &lt, b.mask_all, b.nbr_all, dm, Lk, b.F, E + TCN_HID, st));
 
-    if (c.model_kind == 1) {
-      // ---- PtTransformer.fuse_and_predict (model.py:65-69): cls_head / reg_head on the fused pyramid
+    if (c.model_kind != 0) {
+      // ---- PtTransformer / PtTransformerEarlyFusion.fuse_and_predict (model.py:65-69, :204-209): cls_head / reg_head on the pyramid
       TRY(run_head_pair(m, m->cls1, m->reg, b, *pl, E, 1, 0, logits_out + (int64_t)q0 * S, 2, 1, offsets_out + (int64_t)q0 * S * 2, st));
     } else {
     // ---- heads: fuse_and_predict (model.py:442-471)
@@ -1273,7 +1273,7 @@ int dcf_model_create(const dcf_config* cfg, dcf_model** out) {
   DCF_CHECK(cfg->win > 0 && (cfg->win & 1), "mha_win_size=%d must be odd and > 0 (global self-attention over clips is not on the hot path)", cfg->win);
   DCF_CHECK(cfg->fusion_layers >= 0 && cfg->head_layers >= 0 && cfg->n_embd_convs >= 0 && cfg->n_stem >= 0, "negative layer count");
   DCF_CHECK(cfg->sn >= 1, "sn must be >= 1");
-  DCF_CHECK(cfg->model_kind == 0 || cfg->model_kind == 1, "model_kind must be 0 (iterative early fusion) or 1 (late fusion)");
+  DCF_CHECK(cfg->model_kind >= 0 && cfg->model_kind <= 2, "model_kind must be 0 (iterative early fusion), 1 (late fusion) or 2 (early fusion)");
   int ndev = 0;
   DCF_HIP(hipGetDeviceCount(&ndev));
   DCF_CHECK(ndev > 0, "no HIP device");

@@ -508,7 +508,7 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         is out of scope."""
         assert mv_data is None
         if self.MODEL_KIND != 0:
-            raise NotImplementedError('the training-mode forward is built for PtTransformerEarlyFusionIterative (model.py:567-632)')
+            raise NotImplementedError('the training-mode forward is built for PtTransformerEarlyFusionIterative only (model.py:567-632)')
         mo = self.opt['model'] if isinstance(self.opt, dict) else self.opt.model
         for part in ('vid_net', 'text_net', 'fusion'):
             for key in ('attn_pdrop', 'proj_pdrop', 'path_pdrop', 'cdrop'):
@@ -835,6 +835,44 @@ class PtTransformer(PtTransformerEarlyFusionIterative):
         self.cls_head = ConvHead(ch['embd_dim'], 'cls_head', 1, ch.get('n_layers', 2), None, ch.get('prior_prob', 0.0))
         self.reg_head = ConvHead(rh['embd_dim'], 'reg_head', 2, rh.get('n_layers', 2), rh.get('num_fpn_levels', n_levels))
         self.second_fusion = False
+        self.head_layers = ch.get('n_layers', 2)
+        self.max_batch = int(mo.get('max_batch', 0) or 0)
+        self.gemm_mode = GEMM_MODES[mo.get('gemm_mode', 'f16x3')]
+        self._engine = None
+        self.reuse_output_buffers = False
+        self._out_cache = {}
+        self.graph_mode = 'auto'
+
+
+class PtTransformerEarlyFusion(PtTransformerEarlyFusionIterative):
+    """Drop-in for libs/modeling/model.py:163-373: early fusion like the iterative model (vid_map, XAttNFusion on the clip
+    sequence, vid_net, optionally the fusion stack again on every pyramid level) but no refinement stage: ``cls_head`` and
+    ``reg_head`` predict from the E-wide pyramid (model.py:204-209).  Same forward signature; eval forward only."""
+
+    MODEL_KIND = 2
+
+    def __init__(self, opt, second_fusion=True):
+        nn.Module.__init__(self)
+        mo = copy.deepcopy(opt['model'] if isinstance(opt, dict) else opt.model)
+        self.opt = opt
+        vn, tn, fu = dict(mo['vid_net']), dict(mo['text_net']), dict(mo['fusion'])
+        self.sn, self.sratio = int(mo['sn']), float(mo['sratio'])
+        self.msf, self.norm = bool(mo['msf']), bool(mo['norm'])
+        self.scat, self.sfonly = bool(mo.get('scat', False)), False     # model.py:163-373 never reads opt.model.sfonly
+        D, E = int(vn['in_dim']), int(vn['embd_dim'])
+        self.D, self.E = D, E
+        self.text_net = make_text_net(tn)
+        self.vid_map = MaskedConv1D((2 * D if self.msf else D) + int(self.scat), E, 1)      # model.py:175-181
+        vn.pop('name', None)
+        vn['in_dim'] = E
+        self.vid_net = VideoTransformer(**vn)
+        fu.pop('name', None)
+        self.fusion = XAttNFusion(**fu)
+        ch, rh = dict(mo['cls_head']), dict(mo['reg_head'])
+        n_levels = self.vid_net.arch[2]
+        self.cls_head = ConvHead(ch['embd_dim'], 'cls_head', 1, ch.get('n_layers', 2), None, ch.get('prior_prob', 0.0))
+        self.reg_head = ConvHead(rh['embd_dim'], 'reg_head', 2, rh.get('n_layers', 2), rh.get('num_fpn_levels', n_levels))
+        self.second_fusion = second_fusion
         self.head_layers = ch.get('n_layers', 2)
         self.max_batch = int(mo.get('max_batch', 0) or 0)
         self.gemm_mode = GEMM_MODES[mo.get('gemm_mode', 'f16x3')]

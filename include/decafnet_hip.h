@@ -50,7 +50,8 @@ typedef struct dcf_config {
                            * 3 MFMA products, default), 6 = bf16x6 (three bf16 planes, 6 products),
                            * 1 = native fp32 MFMA                                                   */
   int32_t model_kind;     /* 0 = PtTransformerEarlyFusionIterative (libs/modeling/model.py:397),
-                           * 1 = PtTransformer, late fusion (model.py:30)                            */
+                           * 1 = PtTransformer, late fusion (model.py:30),
+                           * 2 = PtTransformerEarlyFusion (model.py:163): kind 0 without the refinement stage    */
   int32_t second_fusion;  /* model_kind 0: also fuse every pyramid level before the heads (model.py:443) */
   /* text_net = TextTransformer (libs/modeling/text_net.py:92-188); text_in = 0 builds the model without it */
   int32_t text_in;        /* opt.model.text_net.in_dim (token feature dim C_t)                     */

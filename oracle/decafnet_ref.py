@@ -495,6 +495,29 @@ def forward_eval(sd: SD, cfg, vid: Tensor, shallow_vid: Tensor, vid_masks: Tenso
     return logits_list, offsets_list, masks_list
 
 
+def forward_eval_early_fusion(sd: SD, cfg, vid: Tensor, shallow_vid: Tensor, vid_masks: Tensor,
+                              text: Sequence[Tensor], text_cls: Tensor, text_masks: Sequence[Tensor], second_fusion: bool = True):
+    """PtTransformerEarlyFusion._drop_forward_eval, model.py:217-288: the iterative model's path (vid_map, fusion, vid_net,
+    optional second fusion) with cls_head / reg_head directly on the pyramid (fuse_and_predict, model.py:204-209)."""
+    assert vid.size(0) == 1
+    correl = sidekick_scores(shallow_vid, text_cls, cfg['norm'])
+    logits_list, offsets_list, masks_list = [], [], []
+    for b, (txt, txt_mask) in enumerate(zip(text, text_masks)):
+        x, masks = gated_video_input(cfg, vid, shallow_vid, vid_masks, correl, b, allow_sfonly=False)
+        m = masks.unsqueeze(1)
+        x, m = masked_conv1d(x, m, sd['vid_map.conv.weight'], sd['vid_map.conv.bias'])
+        fused, fm = xattn_fusion(sd, cfg['fusion'], x, m, txt, txt_mask)
+        fpn, fpn_masks = video_transformer(sd, cfg['vid_net'], fused, fm)
+        if second_fusion:
+            fpn, fpn_masks = xattn_fusion_pyramid(sd, cfg['fusion'], fpn, fpn_masks, txt, txt_mask)
+        logits, _ = cls_head(sd, 'cls_head', fpn, fpn_masks, cfg['cls_head'].get('n_layers', 2))
+        offsets, out_masks = reg_head(sd, 'reg_head', fpn, fpn_masks, cfg['reg_head'].get('n_layers', 2))
+        logits_list.append(logits)
+        offsets_list.append(offsets)
+        masks_list.append(out_masks)
+    return logits_list, offsets_list, masks_list
+
+
 def forward_train(sd: SD, cfg, vid: Tensor, shallow_vid: Tensor, vid_masks: Tensor, tokens: Tensor, token_masks: Tensor,
                   text_cls: Tensor, text_size: Sequence[int]):
     """PtTransformerEarlyFusionIterative._drop_forward (training mode), model.py:567-632, FORWARD VALUES with every dropout

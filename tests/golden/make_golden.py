@@ -288,18 +288,27 @@ E2E_VARIANTS = {
     'late_scat': dict(cls='PtTransformer', opt=dict(D=64, E=64, TE=32, text_in=32, n_levels=3, win=5, n_heads=4, sn=8, sratio=0.5,
                                                     msf=False, scat=True, norm=True, max_seq_len=128, text_layers=1, text_max_len=24),
                       T=128, vid_len=101, nq=2, lq=5, wseed=91, iseed=92),
+    # PtTransformerEarlyFusion (model.py:163-373): early fusion without the refinement stage; second_fusion defaults to True
+    'early': dict(cls='early2', opt=dict(D=64, E=64, TE=32, text_in=32, n_levels=4, win=5, n_heads=4, sn=16, sratio=0.3,
+                                         msf=True, norm=True, max_seq_len=128, text_layers=1, text_max_len=24),
+                  T=256, vid_len=243, nq=2, lq=6, wseed=53, iseed=54),
+    'early_single': dict(cls='early1', opt=dict(D=64, E=64, TE=32, text_in=32, n_levels=3, win=5, n_heads=4, sn=8, sratio=0.5,
+                                                msf=False, scat=True, norm=False, max_seq_len=128, text_layers=1, text_max_len=24),
+                         T=128, vid_len=120, nq=2, lq=5, wseed=55, iseed=56),
 }
 
 
 @torch.no_grad()
 def gen_e2e_variants():
-    from libs.modeling.model import PtTransformerEarlyFusionIterative, PtTransformer
+    from libs.modeling.model import PtTransformerEarlyFusionIterative, PtTransformer, PtTransformerEarlyFusion
     for name, c in E2E_VARIANTS.items():
         if ONLY and name not in ONLY:
             continue
         opt = make_opt(**c['opt'])
         if c['cls'] == 'PtTransformer':
             model = PtTransformer(opt.clone()).eval()
+        elif c['cls'] in ('early1', 'early2'):
+            model = PtTransformerEarlyFusion(opt.clone(), second_fusion=c['cls'] == 'early2').eval()
         else:
             model = PtTransformerEarlyFusionIterative(opt.clone(), second_fusion=True).eval()
         shapes = {k: list(v.shape) for k, v in model.state_dict().items()}

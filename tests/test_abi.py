@@ -49,13 +49,15 @@ def test_config_struct_layout():
     assert fields == [f[0] for f in pkg._lib.DcfConfig._fields_]
 
 
-@pytest.mark.parametrize('name', ['c1', 'pe', 'nomsf', 'scat', 'sfonly', 'late', 'second', 'late_scat'])
+@pytest.mark.parametrize('name', ['c1', 'pe', 'nomsf', 'scat', 'sfonly', 'affine', 'late', 'second', 'late_scat', 'early', 'early_single'])
 def test_parameter_abi_matches_reference(name):
     """state_dict keys and shapes == the reference model's (captured in the fixture)"""
     pkg = load_pkg()
     g = Golden(f'e2e_{name}.npz')
     if name.startswith('late'):
         model = pkg.modeling.PtTransformer(pkg.config.make_opt(**g.js('opt_kwargs')))
+    elif name.startswith('early'):
+        model = pkg.modeling.PtTransformerEarlyFusion(pkg.config.make_opt(**g.js('opt_kwargs')))
     else:
         model = pkg.modeling.create_model(pkg.config.make_opt(**g.js('opt_kwargs')))
     mine = {k: list(v.shape) for k, v in model.state_dict().items()}

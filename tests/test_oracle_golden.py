@@ -286,7 +286,7 @@ def test_nms_vs_compiled_reference_random():
             assert torch.equal(d1[:len(i1)], d2[:len(i2)])
 
 
-@pytest.mark.parametrize('name', ['late', 'second', 'late_scat'])
+@pytest.mark.parametrize('name', ['late', 'second', 'late_scat', 'early', 'early_single'])
 def test_secondary_compositions(name):
     """PtTransformer (late fusion, model.py:30-161) and second_fusion=True (model.py:443-444) restatements"""
     g = Golden(f'e2e_{name}.npz')
@@ -298,6 +298,9 @@ def test_secondary_compositions(name):
     texts, tmasks = zip(*[R.encode_text(sd, opt.model, t[None], torch.ones(1, 1, t.size(-1), dtype=torch.bool)) for t in inp['tokens']])
     if meta['cls'] == 'PtTransformer':
         out = R.forward_eval_late_fusion(sd, opt.model, inp['vid'], inp['shallow_vid'], inp['vid_masks'], list(texts), inp['text_cls'], list(tmasks))
+    elif meta['cls'].startswith('early'):               # PtTransformerEarlyFusion (model.py:163-373)
+        out = R.forward_eval_early_fusion(sd, opt.model, inp['vid'], inp['shallow_vid'], inp['vid_masks'], list(texts), inp['text_cls'],
+                                          list(tmasks), second_fusion=meta['cls'] == 'early2')
     else:
         out = R.forward_eval(sd, opt.model, inp['vid'], inp['shallow_vid'], inp['vid_masks'], list(texts), inp['text_cls'], list(tmasks),
                              second_fusion=True)
