@@ -33,6 +33,7 @@ def install():
     model_mod = types.ModuleType(MODEL_MODULE, 'MI355X drop-in for libs/modeling/model.py (cvpr2025-decafnet_amd.modeling)')
     model_mod.PtTransformerEarlyFusionIterative = modeling.PtTransformerEarlyFusionIterative
     model_mod.PtTransformer = modeling.PtTransformer
+    model_mod.PtTransformerEarlyFusion = modeling.PtTransformerEarlyFusion
     model_mod.PtGenerator = modeling.PtGenerator
     model_mod.__decafnet_hip__ = True
     nms_mod = types.ModuleType(NMS_MODULE, 'MI355X drop-in for libs/nms/nms.py (cvpr2025-decafnet_amd.nms)')
