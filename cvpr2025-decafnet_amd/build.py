@@ -20,10 +20,13 @@ ARCH = 'gfx950'
 FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
 
 
-# per-file flags.  gemm_bf16s.hip: no SLP vectorisation -- it packs adjacent fp32 epilogue operations into v_pk_fma_f32 /
-# v_pk_mul_f32, which are slower than the scalar pair on this part (MI355X_MICROARCH.md, per-instruction constants) and, in the
-# row-statistics epilogue, produced sporadically wrong low halves in lanes 48-63 (tools/dbg_carry.py; scalar code is exact)
-EXTRA = {'gemm_bf16s.hip': ['-fno-slp-vectorize']}
+# No SLP vectorisation: it packs adjacent fp32 operations into v_pk_fma_f32 / v_pk_mul_f32 ... op_sel, which (i) produced
+# sporadically wrong low halves in lanes 48 - 63 in the row-statistics epilogue of gemm_bf16s.hip (profiles/r03_notes.md section 1;
+# the scalar code is exact and deterministic) and (ii) are slower than the scalar pair on this part (MI355X_MICROARCH.md,
+# per-instruction constants: the k3 GEMM kernels got 2 - 5 % faster without them, the other files measured the same).  The
+# pattern is kept out of every kernel file rather than only the one where a test caught it.
+FLAGS.append('-fno-slp-vectorize')
+EXTRA = {}
 
 
 def hipcc():
