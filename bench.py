@@ -152,8 +152,11 @@ def run_sharded(args, pkg, dist, rank, world, dev):
     d = pkg.dist
     L, win = kw['n_levels'], kw['win']
     halo = d.receptive_field(L, win, kw['fusion_layers'])
-    plan = d.shard_plan(T, world, L, win, halo)
-    lo, hi, w_lo, w_hi = plan[rank]
+    # queries first, clips second (dist.shard_plan_2d): with NQ = 1 this is the pure T-shard of BASELINE configs[3]
+    grid = d.shard_plan_2d(T, world, nq, L, win, halo)
+    groups = d.make_grid_groups(grid['t_shards'], grid['q_groups']) if dist is not None else None
+    plan = grid['plan']
+    lo, hi, w_lo, w_hi = plan[rank % grid['t_shards']]
     vid_w = inp['vid'][0][:, w_lo:w_hi].contiguous().to(dev)
     sh_w = inp['shallow_vid'][0][:, w_lo:w_hi].contiguous().to(dev)
     mask_full = inp['vid_masks'][0].to(dev)
@@ -164,7 +167,7 @@ def run_sharded(args, pkg, dist, rank, world, dev):
     def step(timed=False):
         if timed:
             marks.begin()
-        out = d.sharded_forward(be, vid_w, sh_w, mask_full, plan, rank, T, L, texts, cls, tmasks, timings=marks if timed else None)
+        out = d.sharded_forward_2d(be, vid_w, sh_w, mask_full, grid, groups, rank, T, L, texts, cls, tmasks, timings=marks if timed else None)
         if timed:
             marks.end()
         return out
@@ -196,14 +199,16 @@ def run_sharded(args, pkg, dist, rank, world, dev):
         'metric': 'clips/sec (grounding fwd, T=16384 D=1024)', 'value': vid_len * nq * args.steps / elapsed, 'unit': 'clips/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
         'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': f'BASELINE configs[3]: ONE video of T={T} clips (D=1024, probe hyper-parameters, NQ={nq}) clip-chunk sharded over '
-                               f'{world} rank(s): owned chunk + {halo}-clip recompute halo per side, RCCL all-gather of the sidekick scores '
-                               f'(AG-1) and of the packed per-level outputs (AG-2)',
+        'config': {'workload': f'BASELINE configs[3]: ONE video of T={T} clips (D=1024, probe hyper-parameters, NQ={nq}) over {world} rank(s) as '
+                               f'{grid["q_groups"]} query group(s) x {grid["t_shards"]} clip chunk(s): owned chunk + {halo}-clip recompute halo per side, '
+                               f'RCCL all-gather of the sidekick scores (AG-1) and of the packed per-level outputs (AG-2) inside a clip-chunk group, '
+                               f'one more of the full-length outputs across the query groups (AG-3)',
                    'T': T, 'vid_len': vid_len, 'nq': nq, 'window_clips_rank0': plan[0][3] - plan[0][2], 'window_clips_max': max(p[3] - p[2] for p in plan),
-                   'owned_clips': plan[0][1] - plan[0][0], 'halo': halo, 'parallelism': f'T-shard x{world}',
+                   'owned_clips': plan[0][1] - plan[0][0], 'halo': halo, 'parallelism': f'query groups x{grid["q_groups"]}, T-shard x{grid["t_shards"]}',
+                   'rows_per_rank_over_even_share': grid['rows_factor'],
                    'backend': 'gloo (flow check)' if args.debug_gloo_one_gpu else ('nccl = RCCL' if world > 1 else 'single rank')},
         'phases_us_rank0': phases,
-        'collectives_us_rank0': {'ag1_scores': phases.get('ag1'), 'ag2_outputs': phases.get('ag2')},
+        'collectives_us_rank0': {'ag1_scores': phases.get('ag1'), 'ag2_outputs': phases.get('ag2'), 'ag3_query_groups': phases.get('ag3')},
     }
     # the sharded result against the unsharded forward of the same video on rank 0
     if rank == 0:

@@ -20,6 +20,10 @@ Two granularities:
    text, k3 convs, window attention, stride-2 pooling, the TCN) is position-local, so the owned
    outputs equal the unsharded ones up to fp32 round-off of identical per-position operations.
 
+3. **Both at once** -- ``shard_plan_2d`` / ``sharded_forward_2d``: the queries of the video are dealt to query groups first
+   (no recompute at all along that axis), only the remaining factor of the world size cuts the clip axis; one more
+   static-size all-gather collects the other groups' outputs.
+
 The compute is injected through a small backend object so the same orchestration runs on the
 HIP model (``HipBackend``) and, in the CPU tests, on any callable with the same contract.
 """
@@ -98,6 +102,42 @@ def shard_plan(T: int, world: int, n_levels: int, win: int, halo: int) -> List[T
     return plan
 
 
+def shard_plan_2d(T: int, world: int, nq: int, n_levels: int, win: int, halo: int):
+    """Queries first, clips second.  The (video, query) pairs of ONE video are independent after the (query-independent)
+    vid_map products, so the ranks form a grid of ``q_groups`` query groups x ``t_shards`` clip chunks: rank r = qg * t_shards + t
+    computes the window of clip chunk t for the queries of group qg.  Overlap-recompute costs rows only along the clip axis:
+    with NQ = 8 queries on 8 ranks nothing is cut at all (1.00x the rows of an even share), NQ = 4 cuts T in two (1.16x at
+    T = 65 536), NQ = 1 is the pure T-shard (1.625x).  Returns the dict of the plan with the smallest number of rows per rank
+    (ties: fewer clip chunks):
+      t_shards, q_groups, plan (``shard_plan`` of the clip axis), queries (per group: (q_lo, q_hi)), rows_factor.
+    Everything is a function of (T, world, nq, L, w): nothing is negotiated at run time."""
+    best = None
+    for ts in range(1, world + 1):
+        if world % ts:
+            continue
+        qs = world // ts
+        if qs > nq:
+            continue
+        plan = shard_plan(T, ts, n_levels, win, halo) if ts > 1 else [(0, T, 0, T)]
+        per = [(nq * g // qs, nq * (g + 1) // qs) for g in range(qs)]
+        rows = max(p[3] - p[2] for p in plan) * max(b - a for a, b in per)
+        cand = dict(t_shards=ts, q_groups=qs, plan=plan, queries=per, rows_factor=rows / (T * nq / world))
+        if best is None or rows < best[0] or (rows == best[0] and ts < best[1]['t_shards']):
+            best = (rows, cand)
+    assert best is not None, f'no (query, clip) grid for world={world}, nq={nq}'
+    return best[1]
+
+
+def make_grid_groups(t_shards: int, q_groups: int):
+    """The process groups of ``sharded_forward_2d``; every rank of the world calls this with the same arguments (groups are
+    created collectively).  Returns (t_groups, q_groups_): t_groups[qg] = the ranks that share query group qg (one clip chunk
+    each), q_groups_[t] = the ranks that share clip chunk t (one query group each)."""
+    import torch.distributed as dist
+    tg = [dist.new_group([g * t_shards + t for t in range(t_shards)]) for g in range(q_groups)]
+    qg = [dist.new_group([g * t_shards + t for g in range(q_groups)]) for t in range(t_shards)]
+    return tg, qg
+
+
 class HipBackend:
     """Compute steps of ``sharded_forward`` on the MI355X model (cvpr2025-decafnet_amd.modeling)."""
 
@@ -154,6 +194,55 @@ def _gather_static(x: torch.Tensor, sizes: Sequence[int], group=None) -> List[to
     dist.all_gather_into_tensor(out, buf, group=group)
     out = out.view((world, mx) + tuple(x.shape[1:])).to(dev)
     return [out[r, :sizes[r]] for r in range(world)]
+
+
+def sharded_forward_2d(backend, vid_w, shallow_w, mask_full, grid, groups, rank, T, n_levels, texts, text_cls, tmasks, timings=None):
+    """One video on a (query group) x (clip chunk) grid of ranks (``shard_plan_2d`` / ``make_grid_groups``).
+
+    vid_w, shallow_w : this rank's window of the features (the whole video when the plan does not cut T)
+    texts, text_cls, tmasks : ALL queries of the video (replicated, KB-sized); the rank takes its group's slice
+    Returns the outputs of ALL queries on every rank, like ``model(..., eval=True)``.
+    Collectives: AG-1 / AG-2 of ``sharded_forward`` inside the rank's clip-chunk group (skipped when T is not cut), then ONE
+    all-gather of the packed full-length outputs across the query groups (static sizes: sum_l T_l rows x queries per group)."""
+    ts, qs = grid['t_shards'], grid['q_groups']
+    qg, t = rank // ts, rank % ts
+    q_lo, q_hi = grid['queries'][qg]
+    tg, qgs = groups if groups is not None else ([None] * qs, [None] * ts)
+    mark = timings.mark if timings is not None else (lambda name: None)
+    sub_t, sub_m, sub_c = list(texts[q_lo:q_hi]), list(tmasks[q_lo:q_hi]), text_cls[q_lo:q_hi]
+    if ts > 1:
+        lg, of, mk = sharded_forward(backend, vid_w, shallow_w, mask_full, grid['plan'], t, T, n_levels, sub_t, sub_c, sub_m,
+                                     group=tg[qg], timings=timings)
+    else:
+        mark('scores')
+        correl = backend.scores(shallow_w, sub_c)
+        mark('gate')
+        gate = backend.gate(correl, mask_full)
+        mark('forward')
+        logits, offsets, masks = backend.forward_window(vid_w, shallow_w, mask_full, sub_t, sub_m, gate, T, 0)
+        sizes = [T >> l for l in range(n_levels)]
+        lg = [tuple(x[None] for x in logits[q].split(sizes)) for q in range(q_hi - q_lo)]
+        of = [tuple(x[None] for x in offsets[q].split(sizes)) for q in range(q_hi - q_lo)]
+        mk = [tuple(x[None] for x in masks[q].split(sizes)) for q in range(q_hi - q_lo)]
+    if qs == 1:
+        mark('done')
+        return lg, of, mk
+    # AG-3: the full-length outputs of this group's queries, packed (S, nq_g, 4), across the query groups
+    mark('ag3')
+    cat = lambda parts: torch.cat([torch.stack([parts[q][l][0] for q in range(len(parts))], 1) for l in range(n_levels)], 0)  # noqa: E731
+    packed = torch.cat((cat(lg).unsqueeze(-1), cat(of), cat(mk).unsqueeze(-1).to(lg[0][0].dtype)), -1)      # (S, nq_g, 4)
+    per = [b - a for a, b in grid['queries']]
+    S = packed.shape[0]
+    pieces = _gather_static(packed.transpose(0, 1).contiguous(), per, qgs[t])                 # (nq_g, S, 4) per group
+    mark('unpack')
+    full = torch.cat(pieces, 0)                                                               # (nq, S, 4)
+    sizes = [T >> l for l in range(n_levels)]
+    assert full.shape[1] == S == sum(sizes)
+    out_l = [tuple(x[None] for x in full[q, :, 0].split(sizes)) for q in range(full.shape[0])]
+    out_o = [tuple(x[None] for x in full[q, :, 1:3].split(sizes)) for q in range(full.shape[0])]
+    out_m = [tuple(x[None] for x in (full[q, :, 3] != 0).split(sizes)) for q in range(full.shape[0])]
+    mark('done')
+    return out_l, out_o, out_m
 
 
 def sharded_forward(backend, vid_w, shallow_w, mask_full, plan, rank, T, n_levels, texts, text_cls, tmasks, group=None,
