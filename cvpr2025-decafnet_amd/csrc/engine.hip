@@ -203,6 +203,7 @@ struct dcf_model {
   std::vector<DecW> dec;
   const float *fus_out_w = nullptr, *fus_out_b = nullptr;
   const float *embd_fc_w = nullptr, *embd_fc_b = nullptr;
+  const float *embd_fc_wf = nullptr, *embd_fc_s = nullptr, *embd_fc_c = nullptr;   // vid_net.embd_fc with fusion.ln_out folded in
   std::vector<const float*> embd_conv, embd_ln_w, embd_ln_b;
   std::vector<EncW> stem, branch;
   HeadW cls1, cls2, reg;
@@ -560,6 +561,9 @@ static int finalize(dcf_model* m, hipStream_t st) {
   if (c.model_kind != 1) {
     GET("vid_net.embd_fc.conv.weight", SH(E, E), m->embd_fc_w); GET("vid_net.embd_fc.conv.bias", SH(E), m->embd_fc_b);
     SPLIT(m->embd_fc_w, E, E);
+    m->embd_fc_wf = m->embd_fc_s = m->embd_fc_c = nullptr;
+    if (m->gemm_terms != 0 && E % 64 == 0 && c.fusion_layers > 0 &&
+        fold_ln(m, m->embd_fc_w, m->embd_fc_b, m->fus_out_w, m->fus_out_b, E, E, st, &m->embd_fc_wf, &m->embd_fc_s, &m->embd_fc_c)) return -1;
   }
   for (int i = 0; i < c.n_embd_convs; ++i) {
     const std::string s = std::to_string(i);
@@ -729,9 +733,12 @@ static int run_ffn(dcf_model* m, const float* X, const float* fc_w, const float*
 }
 
 // can the LayerNorm between a producer GEMM (rows x n_prod, K = k_prod) and the ffn.fc that consumes it ride as row statistics?
-static bool can_carry_ln(dcf_model* m, const float* fc_wf, int rows, int n_prod, int k_prod, int E) {
+static bool g_no_carry() {
   static const bool off = getenv("DCF_NO_LN_CARRY") != nullptr;      // developer switch: standalone LayerNorm launches instead
-  if (off || !fc_wf || m->gemm_terms == 0 || !m->wsplit.count(fc_wf)) return false;
+  return off;
+}
+static bool can_carry_ln(dcf_model* m, const float* fc_wf, int rows, int n_prod, int k_prod, int E) {
+  if (g_no_carry() || !fc_wf || m->gemm_terms == 0 || !m->wsplit.count(fc_wf)) return false;
   const int terms = m->wsplit_terms[fc_wf];
   return gemm_can_carry_stats(rows, n_prod, k_prod, 1, terms) && gemm_can_carry_stats(rows, 4 * E, E, 1, terms);
 }
@@ -885,8 +892,12 @@ static int run_head_pair(dcf_model* m, const HeadW& h1, const HeadW& h2, Buffers
 // X [rows][ldx] is updated in place; the final ln_out goes to out [rows][ld_out].  Either one level of B sequences
 // of T rows (lt == nullptr) or the whole pyramid (lt != nullptr: rows ordered [level][b][t], neighbour flags `nbr`
 // delimit the sequences for the depthwise conv, the attention core is launched per level).
+// carry_out != nullptr: the caller can take fusion.ln_out as row statistics (b.stats of the raw stream left in X) instead of
+// the normalised rows in `out`; *carry_out says which of the two happened.
 static int run_fusion(dcf_model* m, Buffers& b, float* X, int64_t ldx, int B, int T, const LevelTable* lt, const uint8_t* mask,
-                      const uint8_t* nbr, const TextMeta* dm, int Lk, float* out, int64_t ld_out, hipStream_t st) {
+                      const uint8_t* nbr, const TextMeta* dm, int Lk, float* out, int64_t ld_out, hipStream_t st,
+                      bool* carry_out = nullptr) {
+  if (carry_out) *carry_out = false;
   const dcf_config& c = m->cfg;
   const int E = c.E;
   const int rows = lt ? lt->start[lt->n_levels] : B * T;
@@ -941,6 +952,20 @@ static int run_fusion(dcf_model* m, Buffers& b, float* X, int64_t ldx, int B, in
       TRY(run_gemm(m, &gf, 1, A_ROWS, st));
       go.C = nullptr; go.ln_w = m->fus_out_w; go.ln_b = m->fus_out_b; go.Y = out; go.ldy = ld_out;
       TRY(run_gemm(m, &go, 1, A_ROWS, st));
+      return 0;
+    }
+    if (li + 1 == m->dec.size() && carry_out && m->fus_out_w && ldx == E &&
+        m->embd_fc_wf && m->wsplit.count(m->embd_fc_wf) && !g_no_carry() &&
+        gemm_can_carry_stats(rows, E, 4 * E, 1, m->wsplit_terms[m->embd_fc_wf]) && gemm_can_carry_stats(rows, E, E, 1, m->wsplit_terms[m->embd_fc_wf])) {
+      // last layer: ffn.proj leaves the raw stream in X together with its row statistics, vid_net.embd_fc (ln_out folded into its
+      // weights) applies them: ln_out(x) is neither written nor read (fusion.py:64-66 -> video_net.py:131)
+      GemmArgs gf = gemm(fc_in, E, fc_w, fc_b, b.HID, 4 * E, rows, 4 * E, E);
+      gf.flags = G_GELU;
+      if (carry) { gf.stats_in = b.stats; gf.ln_s = w.fc_s; gf.stats_slots = E / STATS_W; gf.stats_w = STATS_W; }
+      TRY(run_gemm(m, &gf, 1, A_ROWS, st));              // (reads b.stats before ffn.proj below overwrites it: stream order)
+      go.stats_out = b.stats; go.stats_w = STATS_W;
+      TRY(run_gemm(m, &go, 1, A_ROWS, st));
+      *carry_out = true;
       return 0;
     }
     TRY(run_ffn(m, fc_in, fc_w, fc_b, go, b.HID, rows, E, st, carry ? b.stats : nullptr, w.fc_s));
@@ -1090,14 +1115,24 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
     const TextMeta* dm = &tm;
 
     // ---- early fusion: XAttNFusion on the level-0 sequence (fusion.py:56-66)
+    bool fused_as_stats = false;                  // fusion.ln_out carried into vid_net.embd_fc as row statistics
     if (c.model_kind != 1) {
-      TRY(run_fusion(m, b, b.X, E, B, T0, nullptr, mask0, nullptr, dm, Lk, b.R[0], E, st));
-      if (m->keep_debug && m->dbg_fused) DCF_HIP(hipMemcpyAsync(m->dbg_fused, b.R[0], (size_t)rows0 * E * 4, hipMemcpyDeviceToDevice, st));
+      const bool tap = m->keep_debug && m->dbg_fused;    // the `fused` debug tap wants the normalised rows themselves
+      TRY(run_fusion(m, b, b.X, E, B, T0, nullptr, mask0, nullptr, dm, Lk, b.R[0], E, st, tap ? nullptr : &fused_as_stats));
+      if (tap) DCF_HIP(hipMemcpyAsync(m->dbg_fused, b.R[0], (size_t)rows0 * E * 4, hipMemcpyDeviceToDevice, st));
     }
 
     // ---- vid_net: VideoTransformer.forward (video_net.py:123-164)
     {
-      if (c.model_kind != 1) {
+      if (c.model_kind != 1 && fused_as_stats) {
+        // embd_fc(ln_out(x) * mask) from the raw x in b.X: padded rows come out as finite garbage instead of the bias, and every
+        // consumer masks its input rows (blocks.py:98-99).  Not in place: column tiles of other workgroups still read b.X.
+        GemmArgs ge = gemm(b.X, E, m->embd_fc_wf, m->embd_fc_c, b.R[3], E, rows0, E, E);
+        ge.flags = G_AMASK; ge.rowmask = mask0;
+        ge.stats_in = b.stats; ge.ln_s = m->embd_fc_s; ge.stats_slots = E / STATS_W; ge.stats_w = STATS_W;
+        TRY(run_gemm(m, &ge, 1, A_ROWS, st));
+        std::swap(b.X, b.R[3]);
+      } else if (c.model_kind != 1) {
         GemmArgs ge = gemm(b.R[0], E, m->embd_fc_w, m->embd_fc_b, b.X, E, rows0, E, E);
         ge.flags = G_AMASK; ge.rowmask = mask0;
         TRY(run_gemm(m, &ge, 1, A_ROWS, st));
