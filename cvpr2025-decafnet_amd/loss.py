@@ -58,8 +58,10 @@ def _ctr_iou(input_offsets, target_offsets, reduction, eps, kind, select):
     count = torch.zeros(1, device=a.device, dtype=torch.int32) if reduction == 'mean' else None
     _lib.check(lib.dcf_ctr_iou_loss(_lib.ptr(a), _lib.ptr(b), _lib.ptr(sel), n, kind, float(eps), _lib.ptr(elem), _lib.ptr(total),
                                     _lib.ptr(count), _lib.current_stream()), 'dcf_ctr_iou_loss')
-    if reduction == 'mean' and n == 0:
-        return torch.zeros((), device=a.device)                          # `0.0 * loss.sum()` (loss.py:106,163)
+    if reduction == 'mean':                                              # empty selection: `0.0 * loss.sum()` (loss.py:106,163)
+        if n == 0:
+            return torch.zeros((), device=a.device)
+        return torch.where(count[0] > 0, total[0] / count[0].clamp(min=1).to(torch.float32), total.new_zeros(()))
     return _reduce(elem, total, count, reduction, a.shape[:-1])
 
 
