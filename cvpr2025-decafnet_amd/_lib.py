@@ -67,6 +67,7 @@ SIGNATURES = {
     'dcf_op_linear_cm': (i32, [c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, vp]),
     'dcf_op_linear_ln': (i32, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, i32, i32, vp]),
     'dcf_op_linear_ln_carry': (i32, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, i32, i32, i32, vp]),
+    'dcf_op_ffn': (i32, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, c_f32p, c_f32p, i32, i32, i32, vp]),
     'dcf_op_linear_cm_split': (i32, [c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, i32, vp]),
     'dcf_op_conv3': (i32, [c_f32p, c_u8p, c_f32p, c_f32p, i32, i32, i32, i32, vp]),
     'dcf_op_conv3_split': (i32, [c_f32p, c_u8p, c_f32p, c_f32p, i32, i32, i32, i32, i32, vp]),

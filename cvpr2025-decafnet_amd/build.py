@@ -8,6 +8,7 @@ object that exports the C ABI of include/decafnet_hip.h.  The .so stays in the s
 (git-ignored) so that it travels with the working copy to the GPU machine.
 """
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -15,7 +16,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libdecafnet_hip.so')
-SOURCES = ['engine.hip', 'gemm.hip', 'gemm_bf16s.hip', 'rowops.hip', 'attn.hip', 'score.hip', 'heads.hip', 'postproc.hip', 'loss.hip']
+SOURCES = ['engine.hip', 'gemm.hip', 'gemm_bf16s.hip', 'ffn_chain.hip', 'rowops.hip', 'attn.hip', 'score.hip', 'heads.hip', 'postproc.hip', 'loss.hip']
 ARCH = 'gfx950'
 FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
 
@@ -43,9 +44,22 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _includes(src, seen=None):
+    """the project headers a source file includes, transitively (quoted includes, looked up in csrc/ and include/)"""
+    seen = set() if seen is None else seen
+    inc_dir = os.path.join(os.path.dirname(HERE), 'include')
+    with open(src) as f:
+        names = re.findall(r'^\s*#\s*include\s+"([^"]+)"', f.read(), re.M)
+    for n in names:
+        for d in (CSRC, inc_dir):
+            h = os.path.normpath(os.path.join(d, n))
+            if os.path.exists(h) and h not in seen:
+                seen.add(h)
+                _includes(h, seen)
+    return seen
+
+
 def build(force=False, verbose=False):
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
-    headers.append(os.path.join(os.path.dirname(HERE), 'include', 'decafnet_hip.h'))
     objdir = os.path.join(HERE, 'build')
     os.makedirs(objdir, exist_ok=True)
     cc = hipcc()
@@ -53,7 +67,7 @@ def build(force=False, verbose=False):
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace('.hip', '.o'))
-        if force or _stale(obj, [src] + headers):
+        if force or _stale(obj, [src] + sorted(_includes(src))):
             jobs.append([cc] + FLAGS + EXTRA.get(s, []) + ['-c', src, '-o', obj])
 
     def run(cmd):

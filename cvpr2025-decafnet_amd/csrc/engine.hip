@@ -24,6 +24,7 @@
 #include "../../include/decafnet_hip.h"
 #include "attn.h"
 #include "common.h"
+#include "ffn_chain.h"
 #include "gemm.h"
 #include "heads.h"
 #include "postproc.h"
@@ -633,6 +634,7 @@ struct Buffers {
   uint8_t *mask_all, *nbr_all, *kvmask, *maskv;
   float *X, *R[7], *H2, *HID, *F, *HA, *HB, *HC, *HD, *logits1, *tcnA, *tcnB, *kvn, *Kt, *Vt;
   float* stats;                               // [rows][E / 64] (sum, sum of squares): row statistics carried between GEMMs
+  float* hstats[2];                           // the same for the k3 trunks (heads over the whole pyramid, embedding convolutions)
 };
 
 static void carve(Arena& a, const dcf_config& c, int T0, int B, int nq, int S, int Lk, int nvid, Buffers& b) {
@@ -652,6 +654,7 @@ static void carve(Arena& a, const dcf_config& c, int T0, int B, int nq, int S, i
   b.X = a.take<float>(rows0 * E);
   for (int i = 0; i < 7; ++i) b.R[i] = a.take<float>((i < 3 ? rowsF : rows0) * E);
   b.stats = a.take<float>(rowsF * (size_t)((E + 63) / 64) * 2);
+  for (int i = 0; i < 2; ++i) b.hstats[i] = a.take<float>(rowsAll * (size_t)((EH + 63) / 64) * 2);
   b.H2 = a.take<float>(rowsF * 2 * E);
   b.HID = a.take<float>(rowsF * 4 * E);
   b.F = a.take<float>(rowsAll * EH);
@@ -723,8 +726,35 @@ static int run_gemm(dcf_model* m, GemmArgs* g, int count, GemmAMode mode, hipStr
 constexpr int STATS_W = 64;
 // stats != nullptr: X holds the RAW rows, fc_w / fc_b are the LayerNorm-folded weight and bias and ln_s its row sums; the row
 // statistics come from the GEMM that produced X (GemmArgs::stats_in)
+// E = 256 in the f16x3 mode, from FFN_CHAIN_MIN_ROWS rows on: fc, GELU and proj as ONE kernel whose hidden activations stay in
+// registers (ffn_chain.hip; 4 KiB per row neither written nor read back).  Below that the 128-row tiles leave CUs idle and
+// the GEMM pair on 64-row tiles is faster.
+constexpr int FFN_CHAIN_MIN_ROWS = 32768;
+static bool g_no_ffn_chain() {
+  static const bool off = getenv("DCF_NO_FFN_CHAIN") != nullptr;     // developer switch: always the GEMM pair
+  return off;
+}
+static bool can_chain_ffn(dcf_model* m, const float* fc_w, const GemmArgs& go, int rows, int E) {
+  if (g_no_ffn_chain() || E != 256 || rows < FFN_CHAIN_MIN_ROWS || m->gemm_terms != GEMM_F16X3) return false;
+  if (!m->wsplit.count(fc_w) || !m->wsplit.count(go.W) || m->wsplit_terms[fc_w] != GEMM_F16X3 || m->wsplit_terms[go.W] != GEMM_F16X3) return false;
+  if (m->wsplit_ldw[fc_w] != E || m->wsplit_ldw[go.W] != 4 * E) return false;
+  if (go.ln_w || !(go.flags & G_RES) || (go.flags & ~(G_RES | G_OUT_MASK)) || !go.R || !go.bias || go.a_scale > 0.f) return false;
+  return true;
+}
+static int run_ffn_chain(dcf_model* m, const float* X, const float* fc_w, const float* fc_b, const GemmArgs& go, int rows, int E,
+                         hipStream_t st, const float* stats, const float* ln_s) {
+  FfnChainArgs a{};
+  a.X = X; a.ldx = E; a.W1s = m->wsplit[fc_w]; a.b1 = fc_b; a.ln_s = ln_s; a.stats = stats; a.stats_slots = E / 64;
+  a.W2s = m->wsplit[go.W]; a.b2 = go.bias; a.ls = go.ls; a.R = go.R; a.ldr = go.ldr;
+  a.rowmask = (go.flags & G_OUT_MASK) ? go.rowmask : nullptr; a.C = go.C; a.ldc = go.ldc;
+  a.stats_out = go.stats_out; a.stats_w = go.stats_w; a.status = m->status; a.M = rows;
+  ProfScope prof("gemm_f16x3<ffn_chain>", st, 2.0 * rows * E * 4.0 * E * 2.0, (double)rows * E * 4.0 * 3.0);
+  return launch_ffn_chain(a, st);
+}
+
 static int run_ffn(dcf_model* m, const float* X, const float* fc_w, const float* fc_b, GemmArgs go, float* HID, int rows, int E,
                    hipStream_t st, const float* stats = nullptr, const float* ln_s = nullptr) {
+  if (can_chain_ffn(m, fc_w, go, rows, E)) return run_ffn_chain(m, X, fc_w, fc_b, go, rows, E, st, stats, ln_s);
   GemmArgs gf = gemm(X, E, fc_w, fc_b, HID, 4 * E, rows, 4 * E, E);
   gf.flags = G_GELU;
   if (stats) { gf.stats_in = stats; gf.ln_s = ln_s; gf.stats_slots = E / STATS_W; gf.stats_w = STATS_W; }
@@ -755,6 +785,17 @@ static bool can_fuse_ln(dcf_model* m, const float* W, int M, int N, int K, GemmA
   // 131072x256x768 238 against 146 + 53 us (the 128x256 k3 tile reaches 350 - 360 TFLOP/s, 0.43 of the f16x3 peak).
   if (M >= 65536) return false;
   return m->gemm_terms != 0 && m->wsplit.count(W) && m->wsplit_ldw[W] == K && K >= 512 && gemm_can_fuse_ln(M, N, K, mode);
+}
+
+// conv -> LayerNorm -> ReLU -> conv (head / embedding trunks): can the LayerNorm + ReLU ride in the second convolution's A
+// staging, fed by row statistics from the first one's epilogue?  (both on a tile kernel that has the two instantiations)
+static bool can_norm_a(dcf_model* m, const float* W1, const float* W2, int M, int C, int* stats_w) {
+  if (g_no_carry() || m->gemm_terms == 0 || !m->wsplit.count(W1) || !m->wsplit.count(W2)) return false;
+  const int t1 = m->wsplit_terms[W1], t2 = m->wsplit_terms[W2];
+  return t1 == t2 && gemm_can_norm_a(M, C, 3 * C, t1, stats_w) && !can_fuse_ln(m, W1, M, C, 3 * C, A_ROWS_TAP3);
+}
+static void norm_a(GemmArgs& g, const float* stats, int C, int stats_w, const float* ln_g, const float* ln_b) {
+  g.a_stats = stats; g.a_stats_slots = C / stats_w; g.a_ln_g = ln_g; g.a_ln_b = ln_b;
 }
 
 // TransformerEncoder (vid_net) at one level.  Xin: [B*T_in][ldx]; output rows [B*T_out] at Xout (ld ldo).
@@ -811,13 +852,21 @@ static int run_head(dcf_model* m, const HeadW& h, Buffers& b, const Plan& pl, in
   float* HB = b.HB + (int64_t)row0 * Cin;
   const uint8_t* nbr = b.nbr_all + row0;
   const float *last_ln_w = nullptr, *last_ln_b = nullptr;
+  float* hst = b.hstats[0] + (int64_t)row0 * ((Cin + 63) / 64) * 2;
+  int pending = -1, pend_w = 0;                                  // layer whose LayerNorm + ReLU the next convolution applies on load
   for (size_t i = 0; i < h.conv.size(); ++i) {
     GemmArgs g = gemm(in, ldin, h.conv[i], nullptr, HA, Cin, rowsAll, Cin, 3 * Cin);
     g.cin = Cin; g.nbr = nbr;
     float* outp = (in == HB) ? HA : HB;                          // ping-pong between the two trunk buffers
-    if (can_fuse_ln(m, h.conv[i], rowsAll, Cin, 3 * Cin, A_ROWS_TAP3)) {
+    if (pending >= 0) { norm_a(g, hst, Cin, pend_w, h.ln_w[pending], h.ln_b[pending]); pending = -1; }
+    int sw = 0;
+    if (can_fuse_ln(m, h.conv[i], rowsAll, Cin, 3 * Cin, A_ROWS_TAP3) && !g.a_stats) {
       g.C = nullptr; g.ln_w = h.ln_w[i]; g.ln_b = h.ln_b[i]; g.Y = outp; g.ldy = Cin; g.ln_relu = 1;
       TRY(run_gemm(m, &g, 1, A_ROWS_TAP3, st));
+    } else if (i + 1 < h.conv.size() && !g.a_stats && can_norm_a(m, h.conv[i], h.conv[i + 1], rowsAll, Cin, &sw)) {
+      g.C = outp; g.stats_out = hst; g.stats_w = sw;             // raw output + row statistics: the next convolution normalises it
+      TRY(run_gemm(m, &g, 1, A_ROWS_TAP3, st));
+      pending = (int)i; pend_w = sw;
     } else {
       g.C = outp;                                                // raw conv output, normalised in place ...
       TRY(run_gemm(m, &g, 1, A_ROWS_TAP3, st));
@@ -858,16 +907,27 @@ static int run_head_pair(dcf_model* m, const HeadW& h1, const HeadW& h2, Buffers
   int64_t ldin = ldf;
   float* buf[2][2] = {{b.HA, b.HB}, {b.HC, b.HD}};
   const HeadW* hs[2] = {&h1, &h2};
+  int pending = -1, pend_w = 0;
   for (size_t i = 0; i < h1.conv.size(); ++i) {
     float* outp[2] = {buf[0][i & 1], buf[1][i & 1]};
     GemmArgs g[2];
     for (int k = 0; k < 2; ++k) {
       g[k] = gemm(in[k], ldin, hs[k]->conv[i], nullptr, outp[k], Cin, rowsAll, Cin, 3 * Cin);
       g[k].cin = Cin; g[k].nbr = b.nbr_all;
+      if (pending >= 0) norm_a(g[k], b.hstats[k], Cin, pend_w, hs[k]->ln_w[pending], hs[k]->ln_b[pending]);
     }
+    const bool was_pending = pending >= 0;
+    pending = -1;
+    int sw = 0;
+    // the LayerNorm + ReLU between two layers rides in the next layer's A staging when both run on a kernel that can
+    const bool carry = !was_pending && i + 1 < h1.conv.size() && can_norm_a(m, h1.conv[i], h1.conv[i + 1], rowsAll, Cin, &sw) &&
+                       can_norm_a(m, h2.conv[i], h2.conv[i + 1], rowsAll, Cin, &sw);
+    if (carry)
+      for (int k = 0; k < 2; ++k) { g[k].stats_out = b.hstats[k]; g[k].stats_w = sw; }
     TRY(run_gemm(m, g, 2, A_ROWS_TAP3, st));
+    if (carry) { pending = (int)i; pend_w = sw; }
     for (int k = 0; k < 2; ++k) {
-      if (i + 1 < h1.conv.size()) {                              // the last layer is normalised by the output convolution on load
+      if (i + 1 < h1.conv.size() && !carry) {                    // the last layer is normalised by the output convolution on load
         LnArgs ln{}; ln.X = outp[k]; ln.ldx = Cin; ln.Y = outp[k]; ln.ldy = Cin; ln.w = hs[k]->ln_w[i]; ln.b = hs[k]->ln_b[i];
         ln.rows = rowsAll; ln.C = Cin; ln.relu = 1;
         TRY(launch_ln(ln, st));
@@ -959,12 +1019,10 @@ static int run_fusion(dcf_model* m, Buffers& b, float* X, int64_t ldx, int B, in
         gemm_can_carry_stats(rows, E, 4 * E, 1, m->wsplit_terms[m->embd_fc_wf]) && gemm_can_carry_stats(rows, E, E, 1, m->wsplit_terms[m->embd_fc_wf])) {
       // last layer: ffn.proj leaves the raw stream in X together with its row statistics, vid_net.embd_fc (ln_out folded into its
       // weights) applies them: ln_out(x) is neither written nor read (fusion.py:64-66 -> video_net.py:131)
-      GemmArgs gf = gemm(fc_in, E, fc_w, fc_b, b.HID, 4 * E, rows, 4 * E, E);
-      gf.flags = G_GELU;
-      if (carry) { gf.stats_in = b.stats; gf.ln_s = w.fc_s; gf.stats_slots = E / STATS_W; gf.stats_w = STATS_W; }
-      TRY(run_gemm(m, &gf, 1, A_ROWS, st));              // (reads b.stats before ffn.proj below overwrites it: stream order)
       go.stats_out = b.stats; go.stats_w = STATS_W;
-      TRY(run_gemm(m, &go, 1, A_ROWS, st));
+      // (the fc half reads b.stats before the proj half overwrites it: stream order in the GEMM pair; in the one-kernel form a
+      // wave reads the statistics of its own rows at its start and writes them at its end)
+      TRY(run_ffn(m, fc_in, fc_w, fc_b, go, b.HID, rows, E, st, carry ? b.stats : nullptr, w.fc_s));
       *carry_out = true;
       return 0;
     }
@@ -1137,10 +1195,28 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
         ge.flags = G_AMASK; ge.rowmask = mask0;
         TRY(run_gemm(m, &ge, 1, A_ROWS, st));
       }   // late fusion (PtTransformer): b.X already IS embd_fc([gate*vid ; shallow] * mask), model.py:132-140
+      int epend = -1, epend_w = 0;                  // embedding layer whose LayerNorm + ReLU the next convolution applies on load
       for (int i = 0; i < c.n_embd_convs; ++i) {
         GemmArgs g = gemm(b.X, E, m->embd_conv[i], nullptr, b.R[0], E, rows0, E, 3 * E);
         g.cin = E; g.nbr = b.nbr_all;
         const bool with_pe = c.use_abs_pe && i == c.n_embd_convs - 1;
+        int sw = 0;
+        if (epend >= 0) {
+          // A = the RAW output of the previous convolution (in R[0]); this one writes to R[3], then R[0] <-> R[3] swap roles
+          g.A = b.R[0]; g.C = b.R[3];
+          norm_a(g, b.hstats[0], E, epend_w, m->embd_ln_w[epend], m->embd_ln_b[epend]);
+          epend = -1;
+          TRY(run_gemm(m, &g, 1, A_ROWS_TAP3, st));
+          std::swap(b.R[0], b.R[3]);
+          LnArgs ln{}; ln.X = b.R[0]; ln.ldx = E; ln.Y = b.X; ln.ldy = E; ln.w = m->embd_ln_w[i]; ln.b = m->embd_ln_b[i];
+          ln.rows = rows0; ln.C = E; ln.relu = 1;
+          if (with_pe) { ln.pe = m->pe; ln.mask = mask0; ln.T = T0; }
+          TRY(launch_ln(ln, st));
+        } else if (i + 1 < c.n_embd_convs && i + 2 == c.n_embd_convs && can_norm_a(m, m->embd_conv[i], m->embd_conv[i + 1], rows0, E, &sw)) {
+          g.stats_out = b.hstats[0]; g.stats_w = sw;                 // raw output (R[0]) + row statistics; no LayerNorm launch
+          TRY(run_gemm(m, &g, 1, A_ROWS_TAP3, st));
+          epend = i; epend_w = sw;
+        } else
         if (can_fuse_ln(m, m->embd_conv[i], rows0, E, 3 * E, A_ROWS_TAP3)) {
           // conv -> LN -> ReLU (+ pe * mask) in one kernel; the result goes to R[3] (same size as X) because the k3
           // taps of other workgroups still read X, then X and R[3] swap roles
@@ -1750,6 +1826,59 @@ int dcf_op_linear_ln_carry(const float* A, const float* W1, const float* b1, con
     rc = dcf::launch_gemm_split(&g, 1, dcf::A_ROWS, nterms, st);
   }
   DCF_HIP(hipFreeAsync(p1, st)); DCF_HIP(hipFreeAsync(p2, st)); DCF_HIP(hipFreeAsync(wf, st)); DCF_HIP(hipFreeAsync(stats, st));
+  return rc;
+}
+
+int dcf_op_ffn(const float* X, const float* ln_w, const float* ln_b, const float* W1, const float* b1, const float* W2, const float* b2,
+               const float* ls, const uint8_t* mask, float* C, float* stats_out, int32_t M, int32_t E, int32_t chain, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DCF_CHECK(X && W1 && b1 && W2 && b2 && C && M > 0 && E % 64 == 0, "dcf_op_ffn: bad argument");
+  DCF_CHECK(!chain || E == 256, "dcf_op_ffn: the one-kernel form exists for E = 256 only");
+  DCF_CHECK(!stats_out || chain || dcf::gemm_can_carry_stats(M, E, 4 * E, 1, dcf::GEMM_F16X3), "dcf_op_ffn: %d rows run on a kernel without row statistics", M);
+  const int H = 4 * E, nterms = dcf::GEMM_F16X3;
+  unsigned short *p1 = nullptr, *p2 = nullptr;
+  float *wf = nullptr, *stats = nullptr, *xn = nullptr, *hid = nullptr;
+  DCF_HIP(hipMallocAsync((void**)&p1, (size_t)3 * H * E * sizeof(unsigned short), st));
+  DCF_HIP(hipMallocAsync((void**)&p2, (size_t)3 * H * E * sizeof(unsigned short), st));
+  const float *fc_w = W1, *fc_b = b1, *fc_s = nullptr, *fc_in = X;
+  int rc = 0;
+  if (ln_w && chain) {           // the LayerNorm rides as row statistics, its gain folded into the fc weight (GemmArgs::stats_in)
+    DCF_HIP(hipMallocAsync((void**)&wf, ((size_t)H * E + 2 * (size_t)H) * sizeof(float), st));
+    DCF_HIP(hipMallocAsync((void**)&stats, (size_t)M * (E / 64) * 2 * sizeof(float), st));
+    float* sv = wf + (size_t)H * E;
+    hipLaunchKernelGGL(dcf::k_fold_ln, dim3(H), dim3(64), 0, st, W1, b1, ln_w, ln_b, wf, sv, sv + H, E);
+    rc = dcf::launch_row_stats(X, E, stats, M, E, 64, st);
+    fc_w = wf; fc_s = sv; fc_b = sv + H;
+  } else if (ln_w) {
+    DCF_HIP(hipMallocAsync((void**)&xn, (size_t)M * E * sizeof(float), st));
+    dcf::LnArgs ln{}; ln.X = X; ln.ldx = E; ln.Y = xn; ln.ldy = E; ln.w = ln_w; ln.b = ln_b; ln.rows = M; ln.C = E;
+    rc = dcf::launch_ln(ln, st);
+    fc_in = xn;
+  }
+  if (rc == 0) rc = dcf::launch_split_planes(fc_w, p1, H, E, E, st, nterms);
+  if (rc == 0) rc = dcf::launch_split_planes(W2, p2, E, H, H, st, nterms);
+  if (rc == 0 && chain) {
+    dcf::FfnChainArgs a{};
+    a.X = X; a.ldx = E; a.W1s = p1; a.b1 = fc_b; a.ln_s = fc_s; a.stats = stats; a.stats_slots = E / 64; a.W2s = p2; a.b2 = b2; a.ls = ls;
+    a.R = X; a.ldr = E; a.rowmask = mask; a.C = C; a.ldc = E; a.stats_out = stats_out; a.stats_w = 64; a.M = M;
+    rc = dcf::launch_ffn_chain(a, st);
+  } else if (rc == 0) {
+    DCF_HIP(hipMallocAsync((void**)&hid, (size_t)M * H * sizeof(float), st));
+    dcf::GemmArgs gf = dcf::gemm(fc_in, E, fc_w, fc_b, hid, H, M, H, E);
+    gf.Ws = p1; gf.flags = dcf::G_GELU;
+    rc = dcf::launch_gemm_split(&gf, 1, dcf::A_ROWS, nterms, st);
+    if (rc == 0) {
+      dcf::GemmArgs go = dcf::gemm(hid, H, W2, b2, C, E, M, E, H);
+      go.Ws = p2; go.flags = dcf::G_RES | (mask ? dcf::G_OUT_MASK : 0); go.rowmask = mask; go.ls = ls; go.R = X; go.ldr = E;
+      if (stats_out) { go.stats_out = stats_out; go.stats_w = 64; }
+      rc = dcf::launch_gemm_split(&go, 1, dcf::A_ROWS, nterms, st);
+    }
+  }
+  DCF_HIP(hipFreeAsync(p1, st)); DCF_HIP(hipFreeAsync(p2, st));
+  if (wf) DCF_HIP(hipFreeAsync(wf, st));
+  if (stats) DCF_HIP(hipFreeAsync(stats, st));
+  if (xn) DCF_HIP(hipFreeAsync(xn, st));
+  if (hid) DCF_HIP(hipFreeAsync(hid, st));
   return rc;
 }
 

@@ -66,6 +66,15 @@ struct GemmArgs {
   const float* stats_in;   // [M][stats_slots] float2
   const float* ln_s;       // [N]
   int stats_slots;
+  // A_ROWS_TAP3 consumer of a LayerNorm + ReLU (head / embedding trunks: conv -> LN -> ReLU -> conv, head.py:56-58): A holds the RAW
+  // output rows of the previous convolution, a_stats [M][a_stats_slots] float2 their (sum, sum of squares) slots written by
+  // that GEMM's stats_out, a_ln_g / a_ln_b [cin] the LayerNorm parameters; the rows are normalised, scaled and rectified while
+  // they are staged into LDS (3 vector operations per element before the operand split), so the LayerNorm pass over the rows
+  // -- a read and a write of every row -- does not exist.  The split 128x256 tile kernel only (gemm_can_norm_a).
+  const float* a_stats;
+  int a_stats_slots;
+  const float* a_ln_g;
+  const float* a_ln_b;
   // f16x3 mode: sticky device word, bit 0 is set when an accumulator leaves the finite range (an operand overflowed the
   // fp16 range, or the inputs already held inf / NaN); nullptr = not reported
   unsigned* status;
@@ -93,5 +102,9 @@ bool gemm_can_fuse_adaln(int M, int N, int K);
 // true if launch_gemm_split runs `count` A_ROWS GEMMs of this shape in mode `nterms` with a tile kernel whose epilogue can
 // write (stats_out) / consume (stats_in) row statistics: not the k-sliced kernel, tile width a multiple of 64 columns
 bool gemm_can_carry_stats(int M, int N, int K, int count, int nterms);
+// true if launch_gemm_split runs an A_ROWS_TAP3 GEMM of this shape on a tile kernel that can write row statistics (stats_out)
+// and apply a LayerNorm + ReLU to its A rows while staging them (a_stats): the 128x256 tile (N % 256 == 0, M >= 65536);
+// *stats_w receives the slot width the producer must use
+bool gemm_can_norm_a(int M, int N, int K, int nterms, int* stats_w);
 
 }  // namespace dcf

@@ -150,7 +150,8 @@ int launch_split_planes(const float* W, unsigned short* out, int N, int K, int64
 // Infinity Cache hit takes ~1000 and HBM ~2000+, and at T = 16384 most grids give one wave per SIMD, so nothing but
 // the prefetch distance hides that latency.  Buffers are indexed statically (steps unrolled in groups of NST).
 // STATS = true: the instantiation whose epilogue writes / consumes row statistics (GemmArgs::stats_out / stats_in)
-template <int WM, int WN, int TM, int TN, int AMODE, int NTERMS, bool LN = false, int NST = 3, bool STATS = false>
+// ALN = true (A_ROWS_TAP3): the A rows get LayerNorm + ReLU while they are staged (GemmArgs::a_stats)
+template <int WM, int WN, int TM, int TN, int AMODE, int NTERMS, bool LN = false, int NST = 3, bool STATS = false, bool ALN = false>
 __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4 || (NST > 2 && TM * TN >= 4)) ? 2 : 3)) void gemm_bf16s_kernel(GemmBatch batch) {
   constexpr int NT = WM * WN * 64;                    // 4 or 8 wavefronts
   constexpr int BM = WM * TM * 32;
@@ -179,6 +180,27 @@ __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4 || (NST > 2
   const int KT = K / SBK;
   const float sa = a_scale_of(p);
   if constexpr (STATS) { if (p.stats_in) stats_load<BM, NT>(p, wg_stats, m0, tid); }     // uniform
+  // ALN: per-row (rstd, -mean * rstd) of the A rows m0 - 1 .. m0 + BM (the k3 taps reach one row beyond the tile on both
+  // sides) and the LayerNorm parameters of the cin channels, in LDS behind the statistics block; written here, read from
+  // the first store_a on, which is behind the first barrier of the K loop
+  float* aln_row = wg_stats + stats_lds_floats<WM, WN, TM>();
+  float* aln_g = aln_row + 2 * (BM + 2);
+  if constexpr (ALN) {
+    static_assert(AMODE == A_ROWS_TAP3, "ALN is a k3-convolution mode");
+    const float inv = 1.0f / (float)p.cin;
+    for (int t = tid; t < BM + 2; t += NT) {
+      int row = m0 - 1 + t;
+      row = row < 0 ? 0 : (row < M ? row : M - 1);
+      const float* sp = p.a_stats + (int64_t)row * p.a_stats_slots * 2;
+      float s1 = 0.f, s2 = 0.f;
+      for (int k = 0; k < p.a_stats_slots; ++k) { s1 += sp[2 * k]; s2 += sp[2 * k + 1]; }
+      const float mean = s1 * inv;
+      const float rstd = 1.0f / sqrtf(fmaxf(__builtin_fmaf(-mean, mean, s2 * inv), 0.f) + 1e-5f);
+      aln_row[2 * t] = rstd;
+      aln_row[2 * t + 1] = -mean * rstd;
+    }
+    for (int c = tid; c < p.cin; c += NT) { aln_g[c] = p.a_ln_g[c]; aln_g[p.cin + c] = p.a_ln_b[c]; }
+  }
 
   // K-invariant addressing (see gemm.hip: nothing but 16-byte loads inside the K loop)
   // A_ROWS / TAP3: thread -> (row, 8-float piece); A_CHANMAJOR (A[m][k] = X[k*lda + m]): thread -> (k pair p, 4 rows)
@@ -245,7 +267,38 @@ __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4 || (NST > 2
       araw[i][1] = v1;
     }
   };
-  auto store_a = [&](const f32x4 (&araw)[ACH][2]) __attribute__((always_inline)) {
+  auto store_a = [&](const f32x4 (&araw_in)[ACH][2], int kt_) __attribute__((always_inline)) {
+    f32x4 araw[ACH][2];
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) { araw[i][0] = araw_in[i][0]; araw[i][1] = araw_in[i][1]; }
+    if constexpr (ALN) {
+      // y = relu((x - mean) rstd g + beta) on the rows that exist (a masked / out-of-sequence tap stays 0: the convolution sees
+      // relu(LN(x)) * mask, blocks.py:98-99); explicit fmaf: the same bits in every tile instantiation
+      const int slab = slab_major ? kt_ / 3 : (kt_ * SBK % p.cin) / SBK;
+      const int tap = slab_major ? kt_ - 3 * slab : kt_ * SBK / p.cin;
+      const unsigned bit = tap == 0 ? 2u : (tap == 1 ? 1u : 4u);
+      const int c0 = slab * SBK + (tid & 3) * 8;             // id & 3 == tid & 3: NT is a multiple of 4
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(aln_g + c0), g1 = *reinterpret_cast<const f32x4*>(aln_g + c0 + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(aln_g + p.cin + c0), b1 = *reinterpret_cast<const f32x4*>(aln_g + p.cin + c0 + 4);
+#pragma unroll
+      for (int i = 0; i < ACH; ++i) {
+        const int id = i * NT + tid;
+        if (APART && id >= BM * 4) continue;
+        if (!(a_flag[i] & bit)) continue;
+        const int row = id >> 2;
+        const float rs = aln_row[2 * (row + tap)], sh = aln_row[2 * (row + tap) + 1];
+        f32x4 x0 = araw[i][0], x1 = araw[i][1];
+        x0.x = fmaxf(__builtin_fmaf(__builtin_fmaf(x0.x, rs, sh), g0.x, b0.x), 0.f);
+        x0.y = fmaxf(__builtin_fmaf(__builtin_fmaf(x0.y, rs, sh), g0.y, b0.y), 0.f);
+        x0.z = fmaxf(__builtin_fmaf(__builtin_fmaf(x0.z, rs, sh), g0.z, b0.z), 0.f);
+        x0.w = fmaxf(__builtin_fmaf(__builtin_fmaf(x0.w, rs, sh), g0.w, b0.w), 0.f);
+        x1.x = fmaxf(__builtin_fmaf(__builtin_fmaf(x1.x, rs, sh), g1.x, b1.x), 0.f);
+        x1.y = fmaxf(__builtin_fmaf(__builtin_fmaf(x1.y, rs, sh), g1.y, b1.y), 0.f);
+        x1.z = fmaxf(__builtin_fmaf(__builtin_fmaf(x1.z, rs, sh), g1.z, b1.z), 0.f);
+        x1.w = fmaxf(__builtin_fmaf(__builtin_fmaf(x1.w, rs, sh), g1.w, b1.w), 0.f);
+        araw[i][0] = x0; araw[i][1] = x1;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
       const int id = i * NT + tid;
@@ -303,7 +356,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4 || (NST > 2
     constexpr int S = decltype(stage)::value;
     constexpr int SN = (S + NST - 1) % NST;
     __syncthreads();                    // every wave finished reading As (tile kt-1)
-    store_a(araw_[S]);
+    store_a(araw_[S], kt);
     __syncthreads();
     const int kn = kt + NST - 1 < KT ? kt + NST - 1 : KT - 1;
     load_a(kn, araw_[SN]);
@@ -552,7 +605,7 @@ static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterm
     lds += stats_lds_floats<WM, WN, TM>() * sizeof(float);
   }
   if (p.stats_out || p.stats_in) {
-    DCF_CHECK(mode == A_ROWS && !p.ln_w && p.stats_w > 0, "launch_gemm_split: row statistics need A_ROWS, no fused LayerNorm and stats_w > 0");
+    DCF_CHECK((mode == A_ROWS || (mode == A_ROWS_TAP3 && !p.stats_in)) && !p.ln_w && p.stats_w > 0, "launch_gemm_split: row statistics need A_ROWS (or a k3 producer), no fused LayerNorm and stats_w > 0");
     if (p.stats_out) DCF_CHECK((((p.flags & G_ADALN) ? BN / 2 : BN) % p.stats_w) == 0, "launch_gemm_split: tile width %d is not a multiple of stats_w = %d", BN, p.stats_w);
     if (p.stats_in) DCF_CHECK(p.ln_s && p.stats_slots >= 1, "launch_gemm_split: stats_in needs ln_s and stats_slots");
   }
@@ -574,8 +627,33 @@ static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterm
   } while (0)
 #define LS(MODE_, NT_) LSK(MODE_, NT_, false)
 #define LSN(MODE_, NT_) LSK(MODE_, NT_, true)
-  bool want_stats = false;
-  for (int i = 0; i < count; ++i) want_stats = want_stats || b.g[i].stats_out || b.g[i].stats_in;
+  bool want_stats = false, want_aln = false;
+  for (int i = 0; i < count; ++i) {
+    want_stats = want_stats || b.g[i].stats_out || b.g[i].stats_in;
+    want_aln = want_aln || b.g[i].a_stats;
+  }
+  if (mode == A_ROWS_TAP3 && (want_stats || want_aln)) {
+    // k3 convolutions of a trunk: the producer writes row statistics (STATS), the consumer normalises its A rows (ALN); the two
+    // tiles such a GEMM is dispatched to (gemm_can_norm_a)
+    if constexpr (WM == 1 && WN == 4 && TM == 4 && TN == 2) {
+      DCF_CHECK(!(want_stats && want_aln), "launch_gemm_split: a k3 GEMM either writes row statistics or normalises its A rows, not both");
+      for (int i = 0; i < count; ++i) {
+        DCF_CHECK(!b.g[i].stats_in, "launch_gemm_split: stats_in is an A_ROWS feature");
+        if (want_aln) DCF_CHECK(b.g[i].a_stats && b.g[i].a_ln_g && b.g[i].a_ln_b && b.g[i].a_stats_slots >= 1 && b.g[i].cin % 8 == 0 &&
+                                (reinterpret_cast<uintptr_t>(b.g[i].a_ln_g) & 3) == 0, "launch_gemm_split: incomplete a_stats arguments");
+      }
+      const size_t lds_aln = lds + (want_aln ? ((size_t)2 * (BM + 2) + 2 * (size_t)p.cin) * sizeof(float) : 0);
+      if (want_aln) {
+        if (nterms == 6) hipLaunchKernelGGL((gemm_bf16s_kernel<WM, WN, TM, TN, A_ROWS_TAP3, 6, false, 2, false, true>), grid, dim3(WM * WN * 64), lds_aln, stream, b);
+        else hipLaunchKernelGGL((gemm_bf16s_kernel<WM, WN, TM, TN, A_ROWS_TAP3, T_F16, false, 2, false, true>), grid, dim3(WM * WN * 64), lds_aln, stream, b);
+      } else {
+        if (nterms == 6) hipLaunchKernelGGL((gemm_bf16s_kernel<WM, WN, TM, TN, A_ROWS_TAP3, 6, false, 2, true, false>), grid, dim3(WM * WN * 64), lds, stream, b);
+        else hipLaunchKernelGGL((gemm_bf16s_kernel<WM, WN, TM, TN, A_ROWS_TAP3, T_F16, false, 2, true, false>), grid, dim3(WM * WN * 64), lds, stream, b);
+      }
+    } else {
+      DCF_CHECK(false, "launch_gemm_split: no row-statistics / A-normalising k3 kernel for %dx%d tiles", BM, BN);
+    }
+  } else
   if (want_stats) {
     // only the tiles an A_ROWS GEMM with N % 64 == 0 is dispatched to have the statistics instantiation
     if constexpr (BN % 64 == 0 && !(WM == 2 && TM == 2)) {
@@ -657,6 +735,17 @@ bool gemm_can_carry_stats(int M, int N, int K, int count, int nterms) {
   return true;
 }
 
+// mirrors the A_ROWS_TAP3 dispatch below (no forced tile, no fused LayerNorm)
+bool gemm_can_norm_a(int M, int N, int K, int nterms, int* stats_w) {
+  if (nterms == 0 || K % SBK != 0 || M <= 0) return false;
+  // the 128x256 tile only.  On the three-wave 128x96 tile (reg_head trunks, N = 288) the normalisation in the A staging made
+  // the consumer 1.7x slower (two GEMMs per launch: 0.82 -> 1.42 ms at 261120 rows) for 0.12 ms of LayerNorm launches saved:
+  // three waves stage the 128 rows that four stage on the wide tile, and that kernel's staging is already its critical path
+  if (N % 256 == 0 && M >= 65536) { if (stats_w) *stats_w = 64; return true; }
+  (void)nterms;
+  return false;
+}
+
 bool gemm_can_fuse_ln(int M, int N, int K, GemmAMode mode) {
   // The fused kernel needs a 64 x N tile, i.e. M / 64 workgroups.  Measured at T = 16384 (rocprofv3): with 256
   // workgroups (M = 16384, one per CU) conv + LN fused 64 us vs 40 + 8 us as two kernels on 64x128 tiles; with 510
@@ -684,7 +773,10 @@ int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, 
     if (g[i].flags & G_RES) DCF_CHECK(g[i].R, "launch_gemm_split: residual missing");
     if (g[i].stats_out || g[i].stats_in) {
       // the 16-byte epilogue carries them (gemm_wide_ok), and only the tile kernels have it
-      DCF_CHECK(mode == A_ROWS && gemm_can_carry_stats(g[i].M, g[i].N, g[i].K, count, nterms), "launch_gemm_split: row statistics: %dx%dx%d (x%d) runs on the k-sliced kernel", g[i].M, g[i].N, g[i].K, count);
+      int sw_ = 0;
+      DCF_CHECK((mode == A_ROWS && gemm_can_carry_stats(g[i].M, g[i].N, g[i].K, count, nterms)) ||
+                (mode == A_ROWS_TAP3 && !g[i].stats_in && gemm_can_norm_a(g[i].M, g[i].N, g[i].K, nterms, &sw_) && sw_ == g[i].stats_w),
+                "launch_gemm_split: row statistics: %dx%dx%d (x%d) runs on a kernel without them", g[i].M, g[i].N, g[i].K, count);
       DCF_CHECK(g[i].ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(g[i].C) & 15) == 0 && (!g[i].bias || (reinterpret_cast<uintptr_t>(g[i].bias) & 15) == 0) &&
                 (!(g[i].flags & G_RES) || (g[i].ldr % 4 == 0 && (reinterpret_cast<uintptr_t>(g[i].R) & 15) == 0 && (!g[i].ls || (reinterpret_cast<uintptr_t>(g[i].ls) & 15) == 0))) &&
                 (!g[i].stats_in || (g[i].ln_s && (reinterpret_cast<uintptr_t>(g[i].ln_s) & 15) == 0 && g[i].stats_slots >= 1)) && g[i].stats_w > 0 && !g[i].ln_w,

@@ -262,6 +262,14 @@ int dcf_op_linear_ln_carry(const float* A, const float* W1, const float* b1, con
                            const float* W2, const float* b2, float* X, float* Y, int32_t M, int32_t N1, int32_t K1, int32_t N2,
                            int32_t gelu, int32_t nterms, void* stream);
 
+/* The FFN half of a transformer block (libs/modeling/blocks.py:535-538 with the residual of :589-590):
+ *   C = X + ls * ((GELU(LN(X) W1^T + b1) W2^T + b2) * mask),   W1 (4E, E), W2 (E, 4E), hidden width 4E
+ * ln_w / ln_b NULL = no LayerNorm in front; ls NULL = 1; mask NULL = all rows valid; stats_out (optional, (M, E / 64, 2)):
+ * (sum, sum of squares) of every row written to C.  f16x3 operand split.  chain = 0: two GEMMs with the hidden activations in
+ * memory; chain = 1 (E = 256 only): one kernel, the hidden activations stay in registers (csrc/ffn_chain.hip). */
+int dcf_op_ffn(const float* X, const float* ln_w, const float* ln_b, const float* W1, const float* b1, const float* W2, const float* b2,
+               const float* ls, const uint8_t* mask, float* C, float* stats_out, int32_t M, int32_t E, int32_t chain, void* stream);
+
 /* same product on the bf16-split matrix-core path (how vid_map runs); needs M % 4 == 0, N % 128 == 0, K % 32 == 0 */
 int dcf_op_linear_cm_split(const float* A_cm, const float* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K,
                            int32_t nterms, void* stream);

@@ -158,6 +158,60 @@ def test_linear_layernorm_carried_as_row_statistics(L, M, N1, K1, N2, res, gelu,
                                                   P(d['W2']), P(d['b2']), P(X), P(Y), 1024, N1, K1, N2, gelu, nterms, st()))
 
 
+# (M, LayerNorm in front, LayerScale, row mask, row statistics out, row mean): a partial last tile, fewer rows than one tile,
+# one tile per CU and several rounds of tiles
+@pytest.mark.parametrize('M,with_ln,with_ls,with_mask,with_stats,shift', [
+    (128, 0, 0, 0, 0, 0.0), (200, 1, 1, 1, 0, 0.0), (33000, 1, 1, 1, 1, 0.0), (70000, 0, 1, 0, 1, 2.0), (40, 1, 0, 1, 0, -1.5)])
+def test_ffn_chain_vs_fp64(L, M, with_ln, with_ls, with_mask, with_stats, shift):
+    """FFN in one kernel (csrc/ffn_chain.hip: both products transposed, the hidden activations in registers) against fp64
+    and against the GEMM pair it replaces (blocks.py:535-538, 589-590)"""
+    pkg, lib = L
+    E = 256
+    g = torch.Generator().manual_seed(M + with_ln)
+    X = torch.randn(M, E, generator=g) + shift
+    lw, lb = torch.rand(E, generator=g) + 0.5, torch.randn(E, generator=g) * 0.5
+    W1 = torch.randn(4 * E, E, generator=g) / math.sqrt(E)
+    b1 = torch.randn(4 * E, generator=g) * 0.3
+    W2 = torch.randn(E, 4 * E, generator=g) / math.sqrt(4 * E)
+    b2 = torch.randn(E, generator=g) * 0.3
+    ls = torch.randn(E, generator=g)
+    mask = torch.rand(M, generator=g) > 0.2
+    x = X.double()
+    xin = x
+    if with_ln:
+        mu = x.mean(1, keepdim=True)
+        xin = (x - mu) / torch.sqrt(((x - mu) ** 2).mean(1, keepdim=True) + 1e-5) * lw.double() + lb.double()
+    y = F.gelu(xin @ W1.double().t() + b1.double()) @ W2.double().t() + b2.double()
+    if with_mask:
+        y = y * mask[:, None].double()
+    if with_ls:
+        y = y * ls.double()
+    ref = x + y
+    d = {k: v.cuda() for k, v in dict(X=X, lw=lw, lb=lb, W1=W1, b1=b1, W2=W2, b2=b2, ls=ls, mask=mask.to(torch.uint8)).items()}
+    out = {}
+    for chain in (1, 0):
+        if chain == 0 and with_stats and M < 8192:
+            continue
+        C = torch.full((M + 1, E), float('nan'), device='cuda')          # one guard row behind the last one
+        S = torch.full((M, E // 64, 2), float('nan'), device='cuda') if with_stats else None
+        pkg._lib.check(lib.dcf_op_ffn(P(d['X']), P(d['lw']) if with_ln else None, P(d['lb']) if with_ln else None, P(d['W1']), P(d['b1']),
+                                      P(d['W2']), P(d['b2']), P(d['ls']) if with_ls else None, P(d['mask']) if with_mask else None,
+                                      P(C), P(S) if with_stats else None, M, E, chain, st()))
+        Cc = C.cpu()
+        assert torch.isnan(Cc[M]).all(), 'wrote beyond the last row'
+        torch.testing.assert_close(Cc[:M].double(), ref, rtol=2e-5, atol=2e-5)
+        out[chain] = Cc[:M]
+        if with_stats:
+            Sc = S.cpu().double().sum(1)
+            torch.testing.assert_close(Sc[:, 0], ref.sum(1), rtol=1e-4, atol=2e-3)
+            torch.testing.assert_close(Sc[:, 1], (ref * ref).sum(1), rtol=1e-4, atol=2e-3)
+    if 0 in out:
+        tol = 1e-5 if with_ln else 2e-6      # without the LayerNorm fold: same products, same order, a few ulps at most
+        torch.testing.assert_close(out[1], out[0], rtol=tol, atol=tol)
+    with pytest.raises(RuntimeError, match='E = 256'):
+        pkg._lib.check(lib.dcf_op_ffn(P(d['X']), None, None, P(d['W1']), P(d['b1']), P(d['W2']), P(d['b2']), None, None, P(C), None, 8, 128, 1, st()))
+
+
 @pytest.mark.parametrize('nterms,tol', [(6, 2e-5), (16, 2e-5)])
 @pytest.mark.parametrize('M,N,K', [(256, 256, 512), (1000, 128, 64), (4096, 256, 1024), (16384, 256, 96), (20, 128, 32)])
 def test_linear_channel_major_split(L, M, N, K, nterms, tol):
