@@ -69,6 +69,7 @@ SIGNATURES = {
     'dcf_op_linear_ln_carry': (i32, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, i32, i32, i32, vp]),
     'dcf_op_ffn': (i32, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, c_f32p, c_f32p, i32, i32, i32, vp]),
     'dcf_op_linear_cm_split': (i32, [c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, i32, vp]),
+    'dcf_op_head': (i32, [c_f32p, c_u8p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, i32, f32, i32, vp]),
     'dcf_op_conv3': (i32, [c_f32p, c_u8p, c_f32p, c_f32p, i32, i32, i32, i32, vp]),
     'dcf_op_conv3_split': (i32, [c_f32p, c_u8p, c_f32p, c_f32p, i32, i32, i32, i32, i32, vp]),
     'dcf_op_layernorm': (i32, [c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, i32, vp]),

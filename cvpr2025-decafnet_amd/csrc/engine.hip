@@ -26,6 +26,7 @@
 #include "common.h"
 #include "ffn_chain.h"
 #include "gemm.h"
+#include "head_chain.h"
 #include "heads.h"
 #include "postproc.h"
 #include "rowops.h"
@@ -170,6 +171,7 @@ struct HeadW {
   std::vector<const float*> ln_w, ln_b;
   const float* out_w;                        // packed [NO][3][Cin]
   const float* out_b;
+  const unsigned short* chain[2] = {nullptr, nullptr};   // chain images of the two trunk convolutions (head_chain.hip) or nullptr
 };
 
 struct Plan {    // geometry for one (T0, B)
@@ -450,6 +452,16 @@ static int resolve_head(dcf_model* m, const std::string& p, const std::string& o
   GET(p + "." + out_name + ".conv.weight", SH(NO, C, 3), t);
   if (pack3(m, t, NO, C, 3, 0, 2, 1, st, &h.out_w)) return -1;
   GET(p + "." + out_name + ".conv.bias", SH(NO), h.out_b);
+  h.chain[0] = h.chain[1] = nullptr;
+  if (m->gemm_terms == GEMM_F16X3 && layers == 2 && head_chain_supports(C, NO)) {      // the whole head as one kernel (head_chain.hip)
+    for (int i = 0; i < 2; ++i) {
+      unsigned short* img = nullptr;
+      DCF_HIP(hipMalloc(&img, head_chain_image_halfs(C) * sizeof(unsigned short)));
+      m->owned.push_back(reinterpret_cast<float*>(img));
+      if (launch_split_chain3(h.conv[i], img, C, st, nullptr)) return -1;   // (range: the same weights passed split_weight above)
+      h.chain[i] = img;
+    }
+  }
   return 0;
 }
 
@@ -840,10 +852,44 @@ static int run_encoder(dcf_model* m, const EncW& w, Buffers& b, const float* Xin
   return 0;
 }
 
+// From HEAD_CHAIN_MIN_ROWS pyramid rows on, in the f16x3 mode: trunk and output convolution of a head as ONE kernel, the trunk
+// activations in registers (head_chain.hip).  Below that the 104-row tiles do not fill the chip and the GEMM launches win.
+constexpr int HEAD_CHAIN_MIN_ROWS = 65536;
+// OFF unless DCF_HEAD_CHAIN is set: measured on the eight-video forward the kernel takes 2.89 ms for the three heads against
+// 2.66 ms for the launches it replaces (profiles/r03_notes.md section 9: 19 % of its rows are halo, the LDS-DMA requests of the
+// weight stream cost a wave ~86 cycles each beside the MFMAs, and at one workgroup per CU nothing of another stream's forward
+// runs beside it).  Kept as a tested operator (dcf_op_head, chain = 1).
+static bool g_no_head_chain() {
+  static const bool off = getenv("DCF_HEAD_CHAIN") == nullptr;
+  return off;
+}
+static bool can_chain_head(dcf_model* m, const HeadW& h, int rows, int Cin, int NO) {
+  if (g_no_head_chain() || rows < HEAD_CHAIN_MIN_ROWS || m->gemm_terms != GEMM_F16X3 || !h.chain[0] || !h.chain[1]) return false;
+  if (h.conv.size() != 2 || !head_chain_supports(Cin, NO)) return false;
+  for (int i = 0; i < 2; ++i)
+    if (!m->wsplit.count(h.conv[i]) || m->wsplit_terms[h.conv[i]] != GEMM_F16X3) return false;
+  return true;
+}
+static int run_head_chain(dcf_model* m, const HeadW& h, Buffers& b, const Plan& pl, int Cin, int NO, int mode, int query_major,
+                          float* out, hipStream_t st) {
+  const int rowsAll = pl.B * pl.lt.S;
+  HeadChainArgs a{};
+  a.X = b.F; a.ldx = m->cfg.E + TCN_HID; a.nbr = b.nbr_all; a.W1c = h.chain[0]; a.W2c = h.chain[1];
+  a.ln1_w = h.ln_w[0]; a.ln1_b = h.ln_b[0]; a.ln2_w = h.ln_w[1]; a.ln2_b = h.ln_b[1];
+  a.Wout = h.out_w; a.bout = h.out_b; a.lt = pl.d_lt; a.out = out; a.rows = rowsAll; a.NO = NO; a.mode = mode;
+  a.query_major = query_major; a.status = m->status;
+  // algorithmic work of the launches it replaces: two k3 convolutions (C x 3C) and the output convolution; bytes: the input
+  // rows once, the outputs once
+  ProfScope prof("gemm_f16x3<head_chain>", st, 2.0 * rowsAll * Cin * 3.0 * Cin * 2.0 + 2.0 * rowsAll * 3.0 * Cin * NO,
+                 (double)rowsAll * (Cin + NO) * 4.0);
+  return launch_head_chain(a, Cin, st);
+}
+
 // one head trunk (n x [k3 conv, LN, ReLU]) + output conv over the whole pyramid
 // rows [row0, row0 + rows) of the pyramid (a whole pyramid, or one level)
 static int run_head(dcf_model* m, const HeadW& h, Buffers& b, const Plan& pl, int Cin, int NO, int mode, int query_major,
                     float* out, hipStream_t st, int row0 = 0, int rows = -1) {
+  if (row0 == 0 && rows < 0 && can_chain_head(m, h, pl.B * pl.lt.S, Cin, NO)) return run_head_chain(m, h, b, pl, Cin, NO, mode, query_major, out, st);
   const int rowsAll = rows >= 0 ? rows : pl.B * pl.lt.S;
   const int ldf = m->cfg.E + TCN_HID;
   const float* in = b.F + (int64_t)row0 * ldf;
@@ -895,6 +941,10 @@ static int run_head(dcf_model* m, const HeadW& h, Buffers& b, const Plan& pl, in
 static int run_head_pair(dcf_model* m, const HeadW& h1, const HeadW& h2, Buffers& b, const Plan& pl, int Cin, int NO1, int mode1,
                          float* out1, int NO2, int mode2, float* out2, hipStream_t st) {
   const int rowsAll = pl.B * pl.lt.S;
+  if (can_chain_head(m, h1, rowsAll, Cin, NO1) && can_chain_head(m, h2, rowsAll, Cin, NO2)) {
+    TRY(run_head_chain(m, h1, b, pl, Cin, NO1, mode1, 1, out1, st));
+    return run_head_chain(m, h2, b, pl, Cin, NO2, mode2, 1, out2, st);
+  }
   bool pair = h1.conv.size() == h2.conv.size() && !h1.conv.empty() && m->gemm_terms != 0;
   for (size_t i = 0; pair && i < h1.conv.size(); ++i)
     pair = !can_fuse_ln(m, h1.conv[i], rowsAll, Cin, 3 * Cin, A_ROWS_TAP3) && m->wsplit.count(h1.conv[i]) && m->wsplit.count(h2.conv[i]);
@@ -1940,6 +1990,74 @@ int dcf_op_conv3_split(const float* X, const uint8_t* mask, const float* W_ock, 
   DCF_HIP(hipFreeAsync(wp, st));
   DCF_HIP(hipFreeAsync(nbr, st));
   DCF_HIP(hipFreeAsync(planes, st));
+  return rc;
+}
+
+int dcf_op_head(const float* X, const uint8_t* mask, const float* W1, const float* ln1_w, const float* ln1_b, const float* W2,
+                const float* ln2_w, const float* ln2_b, const float* Wout, const float* bout, float* out, int32_t B, int32_t T,
+                int32_t C, int32_t NO, float scale, int32_t chain, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DCF_CHECK(X && mask && W1 && ln1_w && ln1_b && W2 && ln2_w && ln2_b && Wout && bout && out && B > 0 && T > 0, "dcf_op_head: null argument");
+  DCF_CHECK((NO == 1 || NO == 2) && C % 32 == 0, "dcf_op_head: NO = %d, C = %d", NO, C);
+  DCF_CHECK(!chain || dcf::head_chain_supports(C, NO), "dcf_op_head: the one-kernel form exists for C = 256 / 288 only");
+  const int rows = B * T, nterms = dcf::GEMM_F16X3;
+  float *wp[2] = {nullptr, nullptr}, *wo = nullptr, *ha = nullptr, *hb = nullptr;
+  uint8_t* nbr = nullptr;
+  unsigned short* img[2] = {nullptr, nullptr};
+  dcf::LevelTable lt{}, *d_lt = nullptr;
+  lt.n_levels = 1; lt.B = B; lt.S = T; lt.T[0] = T; lt.start[0] = 0; lt.start[1] = rows; lt.off[0] = 0; lt.scale[0] = scale;
+  DCF_HIP(hipMallocAsync((void**)&d_lt, sizeof(lt), st));
+  DCF_HIP(hipMemcpyAsync(d_lt, &lt, sizeof(lt), hipMemcpyHostToDevice, st));
+  DCF_HIP(hipStreamSynchronize(st));                        // (lt is a stack object)
+  DCF_HIP(hipMallocAsync((void**)&nbr, (size_t)rows, st));
+  DCF_HIP(hipMallocAsync((void**)&wo, (size_t)NO * C * 3 * sizeof(float), st));
+  const size_t img_halfs = chain ? dcf::head_chain_image_halfs(C) : (size_t)3 * C * C * 3;
+  const float* Ws[2] = {W1, W2};
+  int rc = dcf::launch_rowflags(mask, nbr, T, rows, st);
+  for (int i = 0; i < 2 && rc == 0; ++i) {
+    DCF_HIP(hipMallocAsync((void**)&wp[i], (size_t)C * C * 3 * sizeof(float), st));
+    DCF_HIP(hipMallocAsync((void**)&img[i], img_halfs * sizeof(unsigned short), st));
+    const int n = C * C * 3;
+    hipLaunchKernelGGL(dcf::k_permute3, dim3((n + 255) / 256), dim3(256), 0, st, Ws[i], wp[i], C, C, 3, 0, 2, 1);
+    rc = chain ? dcf::launch_split_chain3(wp[i], img[i], C, st) : dcf::launch_split_planes(wp[i], img[i], C, 3 * C, 3 * C, st, nterms);
+  }
+  {
+    const int n = NO * C * 3;
+    hipLaunchKernelGGL(dcf::k_permute3, dim3((n + 255) / 256), dim3(256), 0, st, Wout, wo, NO, C, 3, 0, 2, 1);
+  }
+  const int mode = scale != 0.f ? 1 : 0;                    // scale = 0: raw logits (ClsHead); otherwise relu(scale * y) (RegHead)
+  if (rc == 0 && chain) {
+    dcf::HeadChainArgs a{};
+    a.X = X; a.ldx = C; a.nbr = nbr; a.W1c = img[0]; a.W2c = img[1]; a.ln1_w = ln1_w; a.ln1_b = ln1_b; a.ln2_w = ln2_w; a.ln2_b = ln2_b;
+    a.Wout = wo; a.bout = bout; a.lt = d_lt; a.out = out; a.rows = rows; a.NO = NO; a.mode = mode; a.query_major = 0;
+    rc = dcf::launch_head_chain(a, C, st);
+  } else if (rc == 0) {
+    DCF_HIP(hipMallocAsync((void**)&ha, (size_t)rows * C * sizeof(float), st));
+    DCF_HIP(hipMallocAsync((void**)&hb, (size_t)rows * C * sizeof(float), st));
+    const float* in = X;
+    float* bufs[2] = {ha, hb};
+    const float *lw[2] = {ln1_w, ln2_w}, *lb[2] = {ln1_b, ln2_b};
+    for (int i = 0; i < 2 && rc == 0; ++i) {
+      dcf::GemmArgs g = dcf::gemm(in, C, wp[i], nullptr, bufs[i], C, rows, C, 3 * C);
+      g.cin = C; g.nbr = nbr; g.Ws = img[i];
+      rc = dcf::launch_gemm_split(&g, 1, dcf::A_ROWS_TAP3, nterms, st);
+      if (rc == 0) {
+        dcf::LnArgs ln{}; ln.X = bufs[i]; ln.ldx = C; ln.Y = bufs[i]; ln.ldy = C; ln.w = lw[i]; ln.b = lb[i]; ln.rows = rows; ln.C = C; ln.relu = 1;
+        rc = dcf::launch_ln(ln, st);
+      }
+      in = bufs[i];
+    }
+    if (rc == 0) {
+      dcf::ConvOutArgs co{};
+      co.X = in; co.ldx = C; co.nbr = nbr; co.W = wo; co.bias = bout; co.lt = d_lt; co.out = out; co.rows = rows; co.C = C; co.NO = NO;
+      co.row0 = 0; co.mode = mode; co.query_major = 0;
+      rc = dcf::launch_conv_out(co, st);
+    }
+  }
+  for (int i = 0; i < 2; ++i) { if (wp[i]) DCF_HIP(hipFreeAsync(wp[i], st)); if (img[i]) DCF_HIP(hipFreeAsync(img[i], st)); }
+  if (ha) DCF_HIP(hipFreeAsync(ha, st));
+  if (hb) DCF_HIP(hipFreeAsync(hb, st));
+  DCF_HIP(hipFreeAsync(wo, st)); DCF_HIP(hipFreeAsync(nbr, st)); DCF_HIP(hipFreeAsync(d_lt, st));
   return rc;
 }
 

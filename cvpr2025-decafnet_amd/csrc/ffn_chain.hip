@@ -282,6 +282,29 @@ __global__ __launch_bounds__(256, 1) void k_ffn_chain(FfnChainArgs p) {
           }
         }
       };
+      if constexpr (DA && DC) {
+        // K step s of H^T = W1 X^T and (output tile s >> 1, K step s & 1) of Y^T += W2 H^T, alternating: consecutive MFMAs feed
+        // different accumulators (a row of MFMAs into ONE accumulator issues at about half rate: head_chain.hip measured 63
+        // cycles per MFMA for 27 in a row against 32)
+        Hn = mma(fa[set][1], xh[s], Hn);
+        stage(0);
+        DCF_PIN(Hn, fc[set][1], v, z);
+        Y[s >> 1] = mma(fc[set][1], bh[s & 1], Y[s >> 1]);
+        stage(1);
+        DCF_PIN(Y[s >> 1], fa[set][0], tt, ex);
+        Hn = mma(fa[set][0], xl[s], Hn);
+        stage(2);
+        DCF_PIN(Hn, fc[set][0], pl, tt);
+        Y[s >> 1] = mma(fc[set][0], bl[s & 1], Y[s >> 1]);
+        stage(3);
+        DCF_PIN(Y[s >> 1], fa[set][0], gg, g_prev);
+        Hn = mma(fa[set][0], xh[s], Hn);
+        stage(4);
+        DCF_PIN(Hn, fc[set][0], d0, d1);
+        Y[s >> 1] = mma(fc[set][0], bh[s & 1], Y[s >> 1]);
+        stage(5);
+        DCF_PIN_MEM(Y[s >> 1], hi, lo);
+      } else {
       if constexpr (DA) {                                   // K step s of H^T = W1 X^T
         Hn = mma(fa[set][1], xh[s], Hn);
         stage(0);
@@ -308,6 +331,7 @@ __global__ __launch_bounds__(256, 1) void k_ffn_chain(FfnChainArgs p) {
         DCF_PIN_MEM(Y[s >> 1], hi, lo);
       } else {
         stage(3); stage(4); stage(5);
+      }
       }
     }
 #undef DCF_PIN

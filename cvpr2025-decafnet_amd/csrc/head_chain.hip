@@ -1,0 +1,406 @@
+// A prediction head as one kernel: [MaskedConv1D(k3) -> LayerNorm -> ReLU] x 2 -> MaskedConv1D(k3, 1 or 2 outputs), head.py:53-64,
+// :95-103, over all rows of the pyramid.  The trunk activations (two round trips of C floats per row and layer through HBM with
+// the GEMM + LayerNorm launches this replaces) stay in registers.
+//
+// As in ffn_chain.hip the products run transposed, Y^T = W X^T, so that a lane owns a ROW of the sequence: a wave holds a window
+// of 32 consecutive pyramid rows, X^T as fp16 hi / lo planes in registers (the B operand of v_mfma_f32_32x32x16_f16), and the
+// weights stream through LDS as A fragments (LDS-DMA, two-buffer ring, one barrier per stage).  A k3 convolution is three such
+// products with the same B operand, Z_tap = W_tap X^T; the taps are put together on the OUTPUT side, where moving a row is moving
+// a lane: y[r] = Z_0[r - 1] + Z_1[r] + Z_2[r + 1] with wave_shr:1 / wave_shl:1 DPP moves, each term under the neighbour flag of
+// row r (MaskedConv1D masks its input; rows of different sequences lie back to back in the pyramid).  The 32 x C outputs of a
+// layer stay in the accumulator layout -- lane (r, h) holds channels 32 ot + 8 g + 4 h .. + 3 of row r in Y[ot][4 g .. 4 g + 3] --
+// LayerNorm is a per-lane sum plus one exchange between the two lane halves, and after ReLU and the fp16 split the registers
+// Y[ot][8 q .. 8 q + 7] ARE the B operand of K step 2 ot + q of the next layer, provided the weight fragments enumerate the 16
+// channels of a K step in that order (k = 16 kk + 8 (j >> 2) + 4 h + (j & 3) for half j of lane half h): the "chain image" of
+// launch_split_chain3.  The first layer reads its input rows from memory in the same channel order.
+// Every wave computes its window on its own: a row needs its two neighbours per layer, so of the 32 rows 26 (3 .. 28) come out
+// valid after two trunk layers and the output convolution; windows of consecutive waves overlap by 6 rows.  The out-of-window
+// neighbours of rows 0 and 31 read whatever the wave shift brings (finite values of other lanes): only halo rows see them.
+#include "head_chain.h"
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace dcf {
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float SA = 16.f, SW = 256.f, UNSCALE = 1.f / 4096.f;     // the f16x3 scaling of gemm_bf16s.hip
+constexpr int VALID = 26, HALO = 3;                                // valid rows per 32-row window, halo on each side
+
+template <int C>
+struct Geo {
+  static constexpr int KS = C / 16;              // K steps (16 channels) per tap
+  static constexpr int KH = KS / 2;              // K steps per stage: a stage = (output tile, half of K, three taps)
+  static constexpr int NT = C / 32;              // 32-channel output tiles
+  static constexpr int PIECES = 3 * KH * 2;      // 1 KiB pieces per stage: (tap, K step, plane)
+  static constexpr int STAGE = PIECES * 1024;
+  static constexpr int SPL = 2 * NT;             // stages per layer (even: the ring buffer of a stage is its K half)
+  static constexpr int NPW = (PIECES + 3) / 4;   // pieces a wave requests per stage
+  static_assert(C % 32 == 0 && KS % 2 == 0, "C must be a multiple of 32");
+};
+
+__device__ __forceinline__ void split2_f16(float x0, float x1, float s, unsigned& hi, unsigned& lo) {
+  const f16x2 h = __builtin_convertvector(f32x2{x0 * s, x1 * s}, f16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  const float r0 = __builtin_fmaf(x0, s, -(float)h[0]), r1 = __builtin_fmaf(x1, s, -(float)h[1]);
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, f16x2));
+}
+
+// one 1 KiB LDS-DMA piece (ffn_chain.hip): lane l copies the 16 bytes at sbase + voff to LDS byte lds_dst + 16 l
+__device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+
+#ifdef DCF_HC_STAMP
+// diagnostic build only (tools/hc_stamp.sh): cycles wave 0 of workgroup 0 spends in the segments of the kernel
+__device__ unsigned long long dcf_hc_stamps[8];
+__device__ __forceinline__ unsigned long long hc_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define STAMP(i) do { const unsigned long long t_ = hc_stamp(); acc_[i] += t_ - last_; last_ = t_; } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
+__device__ __forceinline__ f32x16 mma(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+// lane i <- lane i - 1 / lane i + 1 of the wave (lanes without a source read 0)
+__device__ __forceinline__ float from_prev(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true)); }
+__device__ __forceinline__ float from_next(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true)); }
+
+__device__ __forceinline__ int find_level_hc(const LevelTable* lt, int r) {
+  int l = 0;
+  while (l + 1 < lt->n_levels && r >= lt->start[l + 1]) ++l;
+  return l;
+}
+
+}  // namespace
+
+// Wp [C][3][C] fp32 -> chain image: stage (ot, hf), piece (tap, kq, plane), lane (h, r'), half j:
+//   W[32 ot + r'][tap][16 (hf KH + kq) + 8 (j >> 2) + 4 h + (j & 3)] * 2^8 as fp16 hi (plane 0) / lo (plane 1)
+template <int C>
+__global__ void k_split_chain3(const float* __restrict__ Wp, unsigned short* __restrict__ img, unsigned* __restrict__ overflow) {
+  using G = Geo<C>;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (n, tap, k pair)
+  if (i >= C * 3 * (C / 2)) return;
+  const int n = i / (3 * (C / 2)), rem = i - n * (3 * (C / 2)), tap = rem / (C / 2), k = (rem - tap * (C / 2)) * 2;
+  const float w0 = Wp[((size_t)n * 3 + tap) * C + k], w1 = Wp[((size_t)n * 3 + tap) * C + k + 1];
+  unsigned hi, lo;
+  split2_f16(w0, w1, SW, hi, lo);
+  if (!(__builtin_fabsf(w0) * SW <= 65504.f) || !(__builtin_fabsf(w1) * SW <= 65504.f)) {
+    if (overflow) atomicOr(overflow, 1u);
+  }
+  const int ot = n >> 5, rr = n & 31, kk = k >> 4, hf = kk / G::KH, kq = kk - hf * G::KH, kr = k & 15;
+  const int a = kr >> 3, h = (kr >> 2) & 1, ii = kr & 3, j = 4 * a + ii;
+  const size_t piece = (size_t)(ot * 2 + hf) * G::PIECES + (size_t)(tap * G::KH + kq) * 2;
+  const size_t o = (piece * 64 + h * 32 + rr) * 8 + j;
+  *reinterpret_cast<unsigned*>(img + o) = hi;
+  *reinterpret_cast<unsigned*>(img + o + 64 * 8) = lo;
+}
+
+template <int C, int NO>
+__global__ __launch_bounds__(256, 1) void k_head_chain(HeadChainArgs p) {
+  using G = Geo<C>;
+  constexpr int KS = G::KS, KH = G::KH, NT = G::NT, STAGE = G::STAGE, PIECES = G::PIECES, NPW = G::NPW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  float* lds_ln = reinterpret_cast<float*>(lds + 2 * STAGE);      // ln1_w, ln1_b, ln2_w, ln2_b: 4 x [C]
+  float* lds_wo = lds_ln + 4 * C;                                  // [NO][3][C]
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const int row = (int)blockIdx.x * (4 * VALID) + w * VALID - HALO + r;          // this lane's pyramid row
+  const bool inr = row >= 0 && row < p.rows;
+  const int row_c = row < 0 ? 0 : (row < p.rows ? row : p.rows - 1);
+  const unsigned fl = inr ? p.nbr[row_c] : 0u;
+  const float sfl = (fl & 1u) ? 1.f : 0.f, lfl = (fl & 2u) ? 1.f : 0.f, rfl = (fl & 4u) ? 1.f : 0.f;
+
+  // weight stream: stage g = layer * SPL + 2 ot + hf; wave w requests pieces w, w + 4, ... (the last one twice where PIECES is
+  // not a multiple of 4: the same bytes to the same place)
+  auto issue_piece = [&](const unsigned short* img, int sl, int parity, int i) __attribute__((always_inline)) {
+    int pc = w + 4 * i;
+    pc = pc < PIECES ? pc : PIECES - 1;
+#ifndef DCF_HC_NO_DMA       // (ablation builds of tools/hc_stamp.sh: timing only, results are garbage)
+    glds16(img + ((size_t)sl * PIECES + pc) * 512, lane16, (unsigned)parity * STAGE + (unsigned)pc * 1024u);
+#endif
+  };
+#ifdef DCF_HC_STAMP
+  unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = hc_stamp();
+#endif
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) issue_piece(p.W1c, 0, 0, i);
+
+  for (int i = tid; i < C; i += 256) {
+    lds_ln[i] = p.ln1_w[i]; lds_ln[C + i] = p.ln1_b[i]; lds_ln[2 * C + i] = p.ln2_w[i]; lds_ln[3 * C + i] = p.ln2_b[i];
+  }
+  for (int i = tid; i < NO * 3 * C; i += 256) lds_wo[i] = p.Wout[i];
+
+  // Register budget: X planes 8 KS, Y 16 NT, Z 48, fragments 48.  Y and Z live in accumulation registers (192 of 256 at C = 288);
+  // the planes of the first XA K steps join them there (MFMA operands may), which leaves the ordinary registers room for two
+  // fragment sets beside the rest of the planes
+  constexpr int XA = (256 - 16 * NT - 48) / 8 - 1;
+  // the window's rows as B operands in chain order: K step kk, lane (r, h): channels 16 kk + 4 h .. + 3 and 16 kk + 8 + 4 h .. + 3
+  f16x8 xh[KS], xl[KS];
+  {
+    const float* px = p.X + (int64_t)row_c * p.ldx + 4 * h;
+    const bool use = (fl & 1u) != 0;                       // MaskedConv1D multiplies its input by the mask
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      f32x4 v0 = *reinterpret_cast<const f32x4*>(px + 16 * kk), v1 = *reinterpret_cast<const f32x4*>(px + 16 * kk + 8);
+      if (!use) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
+      unsigned hi[4], lo[4];
+      split2_f16(v0.x, v0.y, SA, hi[0], lo[0]);
+      split2_f16(v0.z, v0.w, SA, hi[1], lo[1]);
+      split2_f16(v1.x, v1.y, SA, hi[2], lo[2]);
+      split2_f16(v1.z, v1.w, SA, hi[3], lo[3]);
+      xh[kk] = __builtin_bit_cast(f16x8, u32x4{hi[0], hi[1], hi[2], hi[3]});
+      xl[kk] = __builtin_bit_cast(f16x8, u32x4{lo[0], lo[1], lo[2], lo[3]});
+      if (kk < XA) { asm volatile("" : "+a"(xh[kk])); asm volatile("" : "+a"(xl[kk])); }
+    }
+  }
+
+  STAMP(5);
+  f32x16 Y[NT], Z[3];
+  bool bad = false;
+
+  // one stage: the three taps of output tile OT over K half HF; after the second half the taps are put together into Y[OT]
+  auto stage = [&](auto ot_, auto hf_, int layer) __attribute__((always_inline)) {
+    constexpr int OT = decltype(ot_)::value, HF = decltype(hf_)::value;
+    STAMP(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of the stage have landed ...
+    STAMP(0);
+    __syncthreads();                                       // ... everybody's have, and nobody reads the other buffer any more
+    STAMP(1);
+    // SPL is even: stage parity = K half.  The base is made opaque per stage: hoisted out of the layer loop, every fragment
+    // address became a register of its own (54 of them, and spills); this way they are immediate offsets of one register
+    unsigned ab = lane16 + HF * STAGE;
+    asm volatile("" : "+v"(ab));
+    const unsigned char* buf = lds + ab;
+    // the next stage: same layer, or the first one of layer 2, or none
+    constexpr bool LAST = OT == NT - 1 && HF == 1;
+    const unsigned short* nimg = LAST ? p.W2c : (layer ? p.W2c : p.W1c);
+    const int nsl = LAST ? 0 : 2 * OT + HF + 1;
+    const bool has_next = !LAST || layer == 0;             // wave uniform
+    if constexpr (HF == 0) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Z[t][e] = 0.f;
+    }
+    // A group = one K step of all three taps: six fragments, nine MFMAs issued so that consecutive ones feed different
+    // accumulators (27 MFMAs in a row into one accumulator ran at 63 cycles each instead of 32: the chain Z[tap] += ... is a
+    // dependence the matrix unit does not forward at full rate).  Per accumulator the order stays lo x hi, hi x lo, hi x hi with
+    // K ascending.  Fragments are read one group (nine MFMAs, ~290 cycles) ahead.
+    f16x8 fa[2][3][2];
+    auto frags = [&](int kq, int set) __attribute__((always_inline)) {
+#pragma unroll
+      for (int tap = 0; tap < 3; ++tap) {
+#ifndef DCF_HC_NO_LDS
+        fa[set][tap][0] = *reinterpret_cast<const f16x8*>(buf + (2 * (tap * KH + kq)) * 1024);
+        fa[set][tap][1] = *reinterpret_cast<const f16x8*>(buf + (2 * (tap * KH + kq) + 1) * 1024);
+#else
+        fa[set][tap][0] = xh[(kq + tap) % KS]; fa[set][tap][1] = xl[(kq + 2 * tap) % KS];
+#endif
+      }
+    };
+    frags(0, 0);
+    constexpr int PPG = (NPW + KH - 2) / (KH - 1);          // pieces of the next stage requested per group (none in the last one)
+#pragma unroll
+    for (int kq = 0; kq < KH; ++kq) {
+      const int set = kq & 1, kk = HF * KH + kq;
+      if (kq + 1 < KH) frags(kq + 1, set ^ 1);
+#pragma unroll
+      for (int j = 0; j < PPG; ++j) {
+        const int i = kq * PPG + j;
+        if (kq + 1 < KH && i < NPW) {
+          if constexpr (LAST) { if (has_next) issue_piece(nimg, nsl, HF ^ 1, i); }
+          else issue_piece(nimg, nsl, HF ^ 1, i);
+        }
+      }
+#pragma unroll
+      for (int tap = 0; tap < 3; ++tap) Z[tap] = mma(fa[set][tap][1], xh[kk], Z[tap]);
+#pragma unroll
+      for (int tap = 0; tap < 3; ++tap) Z[tap] = mma(fa[set][tap][0], xl[kk], Z[tap]);
+#pragma unroll
+      for (int tap = 0; tap < 3; ++tap) Z[tap] = mma(fa[set][tap][0], xh[kk], Z[tap]);
+      // nothing moves across a group's end: the compiler's own order read every fragment right before its MFMA (no prefetch)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (HF == 1) {
+      STAMP(2);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float z0 = Z[0][e] * UNSCALE, z1 = Z[1][e] * UNSCALE, z2 = Z[2][e] * UNSCALE;
+        const float y = __builtin_fmaf(from_prev(z0), lfl, __builtin_fmaf(from_next(z2), rfl, z1 * sfl));
+        bad |= !(__builtin_fabsf(z1) <= 3.4028234664e38f);
+        Y[OT][e] = y;
+      }
+      // park the tile in accumulation registers until the LayerNorm: left to itself the compiler keeps all of Y beside the X planes
+      // in the 256 ordinary registers (288 wanted) and spills the shifted taps to scratch, with 64 accumulation registers idle
+      asm volatile("" : "+a"(Y[OT]));
+      STAMP(3);
+    }
+  };
+
+  // LayerNorm over the C channels of the lane's row + ReLU, in place on Y (blocks.py:125-131: mean, then the mean of squared
+  // deviations); g / b: the layer's parameters in LDS
+  auto ln_relu = [&](const float* g, const float* b) __attribute__((always_inline)) {
+    float s = 0.f;
+#pragma unroll
+    for (int ot = 0; ot < NT; ++ot)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s += Y[ot][e];
+    const float mean = xor32_sum(s) * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int ot = 0; ot < NT; ++ot)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { const float d = Y[ot][e] - mean; q = __builtin_fmaf(d, d, q); }
+    const float rstd = 1.0f / sqrtf(xor32_sum(q) * (1.0f / C) + 1e-5f);
+#pragma unroll
+    for (int ot = 0; ot < NT; ++ot)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 gw = *reinterpret_cast<const f32x4*>(g + 32 * ot + 8 * g4 + 4 * h), gb = *reinterpret_cast<const f32x4*>(b + 32 * ot + 8 * g4 + 4 * h);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Y[ot][4 * g4 + i] = fmaxf(__builtin_fmaf((Y[ot][4 * g4 + i] - mean) * rstd, gw[i], gb[i]), 0.f);
+      }
+  };
+
+  for (int layer = 0; layer < 2; ++layer) {
+    // (a compile-time walk over the output tiles: Y[OT] must be a register)
+    auto tiles = [&](auto self, auto ot_) __attribute__((always_inline)) -> void {
+      constexpr int OT = decltype(ot_)::value;
+      if constexpr (OT < NT) {
+        stage(ot_, std::integral_constant<int, 0>{}, layer);
+        stage(ot_, std::integral_constant<int, 1>{}, layer);
+        self(self, std::integral_constant<int, OT + 1>{});
+      }
+    };
+    tiles(tiles, std::integral_constant<int, 0>{});
+    STAMP(2);
+    ln_relu(lds_ln + 2 * C * layer, lds_ln + 2 * C * layer + C);
+    if (layer == 0) {                                      // the next layer's B operand: Y[ot][8 q .. 8 q + 7] = K step 2 ot + q
+#pragma unroll
+      for (int ot = 0; ot < NT; ++ot)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          unsigned hi[4], lo[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) split2_f16(Y[ot][8 * q + 2 * i], Y[ot][8 * q + 2 * i + 1], SA, hi[i], lo[i]);
+          xh[2 * ot + q] = __builtin_bit_cast(f16x8, u32x4{hi[0], hi[1], hi[2], hi[3]});
+          xl[2 * ot + q] = __builtin_bit_cast(f16x8, u32x4{lo[0], lo[1], lo[2], lo[3]});
+          if (2 * ot + q < XA) { asm volatile("" : "+a"(xh[2 * ot + q])); asm volatile("" : "+a"(xl[2 * ot + q])); }
+        }
+    }
+  }
+
+  STAMP(4);
+  // output convolution (head.py:60, :99): per-lane tap partials over the lane's channels, the two lane halves added, the taps
+  // put together across rows as above
+  float pt[3][NO];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int o = 0; o < NO; ++o) pt[t][o] = 0.f;
+#pragma unroll
+  for (int ot = 0; ot < NT; ++ot)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+      for (int o = 0; o < NO; ++o)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(lds_wo + (o * 3 + t) * C + 32 * ot + 8 * g4 + 4 * h);
+          pt[t][o] += (Y[ot][4 * g4] * wv.x + Y[ot][4 * g4 + 1] * wv.y) + (Y[ot][4 * g4 + 2] * wv.z + Y[ot][4 * g4 + 3] * wv.w);
+        }
+  float yo[NO];
+#pragma unroll
+  for (int o = 0; o < NO; ++o) {
+    const float d0 = xor32_sum(pt[0][o]), d1 = xor32_sum(pt[1][o]), d2 = xor32_sum(pt[2][o]);
+    yo[o] = __builtin_fmaf(from_prev(d0), lfl, __builtin_fmaf(from_next(d2), rfl, d1 * sfl)) + p.bout[o];
+  }
+  if (h == 0 && r >= HALO && r < HALO + VALID && inr) {
+    const LevelTable* lt = p.lt;
+    const int l = find_level_hc(lt, row);
+    int64_t dst = row;
+    if (p.query_major) {
+      const int rel = row - lt->start[l];
+      const int b = rel / lt->T[l], t = rel - b * lt->T[l];
+      dst = (int64_t)b * lt->S + lt->off[l] + t;
+    }
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      float y = yo[o];
+      if (p.mode == 1) y = fmaxf(y * lt->scale[l], 0.f);
+      p.out[dst * NO + o] = y;
+    }
+  }
+  if (bad && p.status) atomicOr(p.status, 1u);
+#ifdef DCF_HC_STAMP
+  STAMP(6);
+  if (blockIdx.x == 1 && tid == 0)
+    for (int i = 0; i < 8; ++i) dcf_hc_stamps[i] = acc_[i];
+#endif
+}
+
+#ifdef DCF_HC_STAMP
+}  // namespace dcf
+extern "C" int dcf_debug_hc_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(dcf::dcf_hc_stamps), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+namespace dcf {
+#endif
+
+bool head_chain_supports(int C, int NO) { return (C == 256 || C == 288) && (NO == 1 || NO == 2); }
+
+size_t head_chain_image_halfs(int C) { return (size_t)(C / 32) * 2 * (3 * (C / 32) * 2) * 512; }
+
+int launch_split_chain3(const float* Wp, unsigned short* img, int C, hipStream_t stream, unsigned* overflow) {
+  DCF_CHECK(C == 256 || C == 288, "launch_split_chain3: C = %d (256 or 288)", C);
+  const int n = C * 3 * (C / 2);
+  if (C == 256) hipLaunchKernelGGL(k_split_chain3<256>, dim3((n + 255) / 256), dim3(256), 0, stream, Wp, img, overflow);
+  else hipLaunchKernelGGL(k_split_chain3<288>, dim3((n + 255) / 256), dim3(256), 0, stream, Wp, img, overflow);
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int C, int NO>
+static int launch_hc(const HeadChainArgs& a, hipStream_t stream) {
+  constexpr int bytes = 2 * Geo<C>::STAGE + (4 * C + NO * 3 * C) * (int)sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    DCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head_chain<C, NO>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    attr_set = true;
+  }
+  const unsigned grid = (unsigned)((a.rows + 4 * VALID - 1) / (4 * VALID));
+  hipLaunchKernelGGL((k_head_chain<C, NO>), dim3(grid), dim3(256), bytes, stream, a);
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_head_chain(const HeadChainArgs& a, int C, hipStream_t stream) {
+  DCF_CHECK(head_chain_supports(C, a.NO), "launch_head_chain: C = %d, NO = %d (C 256 / 288, NO 1 / 2)", C, a.NO);
+  DCF_CHECK(a.rows > 0 && a.X && a.nbr && a.W1c && a.W2c && a.ln1_w && a.ln1_b && a.ln2_w && a.ln2_b && a.Wout && a.bout && a.lt && a.out,
+            "launch_head_chain: null argument");
+  DCF_CHECK((reinterpret_cast<uintptr_t>(a.X) & 15) == 0 && a.ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(a.W1c) & 15) == 0 &&
+                (reinterpret_cast<uintptr_t>(a.W2c) & 15) == 0, "launch_head_chain: X / weight images must be 16-byte aligned");
+  if (C == 256) return a.NO == 1 ? launch_hc<256, 1>(a, stream) : launch_hc<256, 2>(a, stream);
+  return a.NO == 1 ? launch_hc<288, 1>(a, stream) : launch_hc<288, 2>(a, stream);
+}
+
+}  // namespace dcf

@@ -273,6 +273,15 @@ int dcf_op_ffn(const float* X, const float* ln_w, const float* ln_b, const float
 /* same product on the bf16-split matrix-core path (how vid_map runs); needs M % 4 == 0, N % 128 == 0, K % 32 == 0 */
 int dcf_op_linear_cm_split(const float* A_cm, const float* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K,
                            int32_t nterms, void* stream);
+/* A prediction head (libs/modeling/head.py:53-64 ClsHead, :95-103 RegHead) on B sequences of T token-major rows (B*T, C):
+ *   x = relu(LayerNorm(MaskedConv1D_k3(x, mask)))  twice (W1 / ln1, W2 / ln2: PyTorch (C, C, 3) weights, no bias), then
+ *   out (B*T, NO) = MaskedConv1D_k3(x, mask) with Wout (NO, C, 3) and bout; scale != 0: relu(scale * out) (RegHead's Scale + ReLU).
+ * f16x3 operand split.  chain = 0: GEMM, LayerNorm and output-convolution launches with the trunk activations in memory;
+ * chain = 1 (C = 256 / 288): one kernel, the trunk activations stay in registers (csrc/head_chain.hip). */
+int dcf_op_head(const float* X, const uint8_t* mask, const float* W1, const float* ln1_w, const float* ln1_b, const float* W2,
+                const float* ln2_w, const float* ln2_b, const float* Wout, const float* bout, float* out, int32_t B, int32_t T,
+                int32_t C, int32_t NO, float scale, int32_t chain, void* stream);
+
 /* MaskedConv1D(k=3, pad=1, no bias) on token-major (B*T, Cin) rows; W is the PyTorch (N, Cin, 3) weight. */
 int dcf_op_conv3(const float* X, const uint8_t* mask, const float* W_ock, float* Y, int32_t B, int32_t T, int32_t Cin,
                  int32_t N, void* stream);

@@ -158,6 +158,58 @@ def test_linear_layernorm_carried_as_row_statistics(L, M, N1, K1, N2, res, gelu,
                                                   P(d['W2']), P(d['b2']), P(X), P(Y), 1024, N1, K1, N2, gelu, nterms, st()))
 
 
+# (B, T, C, NO, scale): both widths, both output counts, sequences shorter and longer than a 104-row tile, ragged masks with
+# holes, several sequences back to back (their ends must not see each other)
+@pytest.mark.parametrize('B,T,C,NO,scale', [(3, 100, 256, 1, 0.0), (2, 333, 288, 2, 1.7), (5, 64, 288, 1, 0.0), (1, 4000, 256, 2, 0.6)])
+def test_head_chain_vs_fp64(L, B, T, C, NO, scale):
+    """a whole head in one kernel (csrc/head_chain.hip: two k3 trunk layers with LayerNorm + ReLU and the output convolution,
+    activations in registers) against fp64 torch and against the launches it replaces (head.py:53-64, :95-103)"""
+    pkg, lib = L
+    g = torch.Generator().manual_seed(B * 1000 + T + C + NO)
+    X = torch.randn(B * T, C, generator=g)
+    mask = torch.ones(B, T, dtype=torch.bool)
+    for b in range(B):
+        n = int(torch.randint(T // 2, T + 1, (1,), generator=g))
+        mask[b, n:] = False
+        if T > 40:
+            mask[b, 17] = False                                  # a hole inside the valid part
+    W1 = torch.randn(C, C, 3, generator=g) / math.sqrt(3 * C)
+    W2 = torch.randn(C, C, 3, generator=g) / math.sqrt(3 * C)
+    l1w, l1b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    l2w, l2b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    Wo = torch.randn(NO, C, 3, generator=g) / math.sqrt(3 * C)
+    bo = torch.randn(NO, generator=g)
+    mf = mask[:, None, :].double()
+    x = X.double().view(B, T, C).transpose(1, 2)                 # (B, C, T)
+
+    def ln(v, w, b):
+        mu = v.mean(1, keepdim=True)
+        return (v - mu) / torch.sqrt(((v - mu) ** 2).mean(1, keepdim=True) + 1e-5) * w.double()[None, :, None] + b.double()[None, :, None]
+
+    y = torch.relu(ln(F.conv1d(x * mf, W1.double(), padding=1), l1w, l1b))
+    y = torch.relu(ln(F.conv1d(y * mf, W2.double(), padding=1), l2w, l2b))
+    o = F.conv1d(y * mf, Wo.double(), bo.double(), padding=1)
+    if scale != 0.0:
+        o = torch.relu(o * scale)
+    ref = o.transpose(1, 2).reshape(B * T, NO)
+    valid = mask.view(-1)
+    d = {k: v.cuda() for k, v in dict(X=X, mask=mask.to(torch.uint8), W1=W1, W2=W2, l1w=l1w, l1b=l1b, l2w=l2w, l2b=l2b, Wo=Wo, bo=bo).items()}
+    outs = {}
+    for chain in (1, 0):
+        out = torch.full((B * T + 1, NO), float('nan'), device='cuda')
+        pkg._lib.check(lib.dcf_op_head(P(d['X']), P(d['mask']), P(d['W1']), P(d['l1w']), P(d['l1b']), P(d['W2']), P(d['l2w']), P(d['l2b']),
+                                       P(d['Wo']), P(d['bo']), P(out), B, T, C, NO, scale, chain, st()))
+        oc = out.cpu()
+        assert torch.isnan(oc[B * T]).all(), 'wrote beyond the last row'
+        assert torch.isfinite(oc[:B * T]).all()
+        torch.testing.assert_close(oc[:B * T][valid].double(), ref[valid], rtol=3e-5, atol=3e-5)
+        outs[chain] = oc[:B * T]
+    torch.testing.assert_close(outs[1][valid], outs[0][valid], rtol=2e-5, atol=2e-5)
+    with pytest.raises(RuntimeError, match='256 / 288'):
+        pkg._lib.check(lib.dcf_op_head(P(d['X']), P(d['mask']), P(d['W1']), P(d['l1w']), P(d['l1b']), P(d['W2']), P(d['l2w']), P(d['l2b']),
+                                       P(d['Wo']), P(d['bo']), P(out), 1, 8, 128, NO, scale, 1, st()))
+
+
 # (M, LayerNorm in front, LayerScale, row mask, row statistics out, row mean): a partial last tile, fewer rows than one tile,
 # one tile per CU and several rounds of tiles
 @pytest.mark.parametrize('M,with_ln,with_ls,with_mask,with_stats,shift', [
