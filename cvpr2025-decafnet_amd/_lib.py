@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, 'libdecafnet_hip.so')
+# DCF_LIB_PATH: developer switch for A/B runs of two builds inside one GPU call (tools/); the product path is the in-tree build
+SO_PATH = os.environ.get('DCF_LIB_PATH') or os.path.join(_HERE, 'libdecafnet_hip.so')
 _LIB = None
 
 c_f32p = ctypes.c_void_p      # device pointers are passed as raw addresses

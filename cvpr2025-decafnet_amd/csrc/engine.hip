@@ -740,8 +740,9 @@ constexpr int STATS_W = 64;
 // statistics come from the GEMM that produced X (GemmArgs::stats_in)
 // E = 256 in the f16x3 mode, from FFN_CHAIN_MIN_ROWS rows on: fc, GELU and proj as ONE kernel whose hidden activations stay in
 // registers (ffn_chain.hip; 4 KiB per row neither written nor read back).  Below that the 128-row tiles leave CUs idle and
-// the GEMM pair on 64-row tiles is faster.
-constexpr int FFN_CHAIN_MIN_ROWS = 32768;
+// the GEMM pair on 64-row tiles is faster (16 384 rows = 128 tiles, half the chip: 78 - 86 us against 63 + 40 for the pair;
+// 8 192 rows: the same 80 us against 31 + 29).
+constexpr int FFN_CHAIN_MIN_ROWS = 16384;
 static bool g_no_ffn_chain() {
   static const bool off = getenv("DCF_NO_FFN_CHAIN") != nullptr;     // developer switch: always the GEMM pair
   return off;
