@@ -853,44 +853,52 @@ static int run_encoder(dcf_model* m, const EncW& w, Buffers& b, const float* Xin
   return 0;
 }
 
-// From HEAD_CHAIN_MIN_ROWS pyramid rows on, in the f16x3 mode: trunk and output convolution of a head as ONE kernel, the trunk
-// activations in registers (head_chain.hip).  Below that the 104-row tiles do not fill the chip and the GEMM launches win.
-constexpr int HEAD_CHAIN_MIN_ROWS = 65536;
-// OFF unless DCF_HEAD_CHAIN is set: measured on the eight-video forward the kernel takes 2.89 ms for the three heads against
-// 2.66 ms for the launches it replaces (profiles/r03_notes.md section 9: 19 % of its rows are halo, the LDS-DMA requests of the
-// weight stream cost a wave ~86 cycles each beside the MFMAs, and at one workgroup per CU nothing of another stream's forward
-// runs beside it).  Kept as a tested operator (dcf_op_head, chain = 1).
+// From two videos' pyramids on (60 000 rows), in the f16x3 mode: trunk and output convolution of a head as ONE kernel, the trunk
+// activations in registers (head_chain.hip).  One video (32 640 rows = 268 tiles of 122 rows: one round and a sliver) is 2.6 %
+// slower that way (1.784 against 1.739 ms per forward); two videos per forward are 6 % faster (16.26 against 15.34 M clips/s).
+static int head_chain_min_rows() {
+  static const int v = getenv("DCF_HEAD_CHAIN_MIN_ROWS") ? atoi(getenv("DCF_HEAD_CHAIN_MIN_ROWS")) : 60000;     // developer switch
+  return v;
+}
 static bool g_no_head_chain() {
-  static const bool off = getenv("DCF_HEAD_CHAIN") == nullptr;
+  static const bool off = getenv("DCF_NO_HEAD_CHAIN") != nullptr;     // developer switch: GEMM + LayerNorm + output-convolution launches
   return off;
 }
 static bool can_chain_head(dcf_model* m, const HeadW& h, int rows, int Cin, int NO) {
-  if (g_no_head_chain() || rows < HEAD_CHAIN_MIN_ROWS || m->gemm_terms != GEMM_F16X3 || !h.chain[0] || !h.chain[1]) return false;
+  if (g_no_head_chain() || rows < head_chain_min_rows() || m->gemm_terms != GEMM_F16X3 || !h.chain[0] || !h.chain[1]) return false;
   if (h.conv.size() != 2 || !head_chain_supports(Cin, NO)) return false;
   for (int i = 0; i < 2; ++i)
     if (!m->wsplit.count(h.conv[i]) || m->wsplit_terms[h.conv[i]] != GEMM_F16X3) return false;
   return true;
 }
-static int run_head_chain(dcf_model* m, const HeadW& h, Buffers& b, const Plan& pl, int Cin, int NO, int mode, int query_major,
-                          float* out, hipStream_t st) {
-  const int rowsAll = pl.B * pl.lt.S;
+static HeadChainArgs head_chain_args(dcf_model* m, const HeadW& h, Buffers& b, const Plan& pl, int NO, int mode, int query_major, float* out) {
   HeadChainArgs a{};
   a.X = b.F; a.ldx = m->cfg.E + TCN_HID; a.nbr = b.nbr_all; a.W1c = h.chain[0]; a.W2c = h.chain[1];
   a.ln1_w = h.ln_w[0]; a.ln1_b = h.ln_b[0]; a.ln2_w = h.ln_w[1]; a.ln2_b = h.ln_b[1];
-  a.Wout = h.out_w; a.bout = h.out_b; a.lt = pl.d_lt; a.out = out; a.rows = rowsAll; a.NO = NO; a.mode = mode;
+  a.Wout = h.out_w; a.bout = h.out_b; a.lt = pl.d_lt; a.out = out; a.rows = pl.B * pl.lt.S; a.NO = NO; a.mode = mode;
   a.query_major = query_major; a.status = m->status;
-  // algorithmic work of the launches it replaces: two k3 convolutions (C x 3C) and the output convolution; bytes: the input
-  // rows once, the outputs once
-  ProfScope prof("gemm_f16x3<head_chain>", st, 2.0 * rowsAll * Cin * 3.0 * Cin * 2.0 + 2.0 * rowsAll * 3.0 * Cin * NO,
-                 (double)rowsAll * (Cin + NO) * 4.0);
-  return launch_head_chain(a, Cin, st);
+  return a;
+}
+// algorithmic work of the launches a head kernel replaces: two k3 convolutions (C x 3C) and the output convolution; bytes: the
+// input rows once, the outputs once
+static int run_head_chain(dcf_model* m, const HeadChainArgs* a, int count, int Cin, hipStream_t st) {
+  double flops = 0., bytes = 0.;
+  for (int i = 0; i < count; ++i) {
+    flops += 2.0 * a[i].rows * Cin * 3.0 * Cin * 2.0 + 2.0 * a[i].rows * 3.0 * Cin * a[i].NO;
+    bytes += (double)a[i].rows * (Cin + a[i].NO) * 4.0;
+  }
+  ProfScope prof("gemm_f16x3<head_chain>", st, flops, bytes);
+  return launch_head_chain(a, count, Cin, st);
 }
 
 // one head trunk (n x [k3 conv, LN, ReLU]) + output conv over the whole pyramid
 // rows [row0, row0 + rows) of the pyramid (a whole pyramid, or one level)
 static int run_head(dcf_model* m, const HeadW& h, Buffers& b, const Plan& pl, int Cin, int NO, int mode, int query_major,
                     float* out, hipStream_t st, int row0 = 0, int rows = -1) {
-  if (row0 == 0 && rows < 0 && can_chain_head(m, h, pl.B * pl.lt.S, Cin, NO)) return run_head_chain(m, h, b, pl, Cin, NO, mode, query_major, out, st);
+  if (row0 == 0 && rows < 0 && can_chain_head(m, h, pl.B * pl.lt.S, Cin, NO)) {
+    const HeadChainArgs a = head_chain_args(m, h, b, pl, NO, mode, query_major, out);
+    return run_head_chain(m, &a, 1, Cin, st);
+  }
   const int rowsAll = rows >= 0 ? rows : pl.B * pl.lt.S;
   const int ldf = m->cfg.E + TCN_HID;
   const float* in = b.F + (int64_t)row0 * ldf;
@@ -943,8 +951,8 @@ static int run_head_pair(dcf_model* m, const HeadW& h1, const HeadW& h2, Buffers
                          float* out1, int NO2, int mode2, float* out2, hipStream_t st) {
   const int rowsAll = pl.B * pl.lt.S;
   if (can_chain_head(m, h1, rowsAll, Cin, NO1) && can_chain_head(m, h2, rowsAll, Cin, NO2)) {
-    TRY(run_head_chain(m, h1, b, pl, Cin, NO1, mode1, 1, out1, st));
-    return run_head_chain(m, h2, b, pl, Cin, NO2, mode2, 1, out2, st);
+    const HeadChainArgs a[2] = {head_chain_args(m, h1, b, pl, NO1, mode1, 1, out1), head_chain_args(m, h2, b, pl, NO2, mode2, 1, out2)};
+    return run_head_chain(m, a, 2, Cin, st);      // one grid for the two heads
   }
   bool pair = h1.conv.size() == h2.conv.size() && !h1.conv.empty() && m->gemm_terms != 0;
   for (size_t i = 0; pair && i < h1.conv.size(); ++i)
@@ -1100,6 +1108,12 @@ struct VideoSet {
   float* logits1_out = nullptr;               // optional (nq, S): the logits of the first cls_head (fpn_logits1, model.py:445,471)
 };
 
+struct MaskPtrs { const uint8_t* p[DCF_MAX_VIDEOS]; };
+__global__ void k_gather_masks(MaskPtrs mp, uint8_t* __restrict__ dst, int T0) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < T0) dst[(size_t)blockIdx.y * T0 + t] = mp.p[blockIdx.y][t];
+}
+
 static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
                    const float* const* text, const uint8_t* const* text_mask, const int32_t* text_len,
                    const float* gate_override, float* logits_out, float* offsets_out,
@@ -1178,9 +1192,14 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
     for (int v = 0; v < nvid; ++v) {
       if (m->vid_w1) { g[ng++] = gemm(vs.vid[v], T0, m->vid_w1, nullptr, b.P1 + (size_t)v * T0 * E, E, T0, E, D); if (ng == 3) TRY(flush()); }
       if (m->vid_w2) { g[ng++] = gemm(vs.shallow[v], T0, m->vid_w2, nullptr, b.P2 + (size_t)v * T0 * E, E, T0, E, D); if (ng == 3) TRY(flush()); }
-      if (nvid > 1) DCF_HIP(hipMemcpyAsync(b.maskv + (size_t)v * T0, vs.mask[v], (size_t)T0, hipMemcpyDeviceToDevice, st));
     }
     TRY(flush());
+    if (nvid > 1) {                               // the videos' masks side by side: one launch (it was one copy node per video)
+      MaskPtrs mp{};
+      for (int v = 0; v < nvid; ++v) mp.p[v] = vs.mask[v];
+      hipLaunchKernelGGL(k_gather_masks, dim3((unsigned)((T0 + 255) / 256), (unsigned)nvid), dim3(256), 0, st, mp, b.maskv, T0);
+      DCF_HIP(hipGetLastError());
+    }
   }
   if (nvid > 1) vid_mask = b.maskv;
 
@@ -2031,7 +2050,7 @@ int dcf_op_head(const float* X, const uint8_t* mask, const float* W1, const floa
     dcf::HeadChainArgs a{};
     a.X = X; a.ldx = C; a.nbr = nbr; a.W1c = img[0]; a.W2c = img[1]; a.ln1_w = ln1_w; a.ln1_b = ln1_b; a.ln2_w = ln2_w; a.ln2_b = ln2_b;
     a.Wout = wo; a.bout = bout; a.lt = d_lt; a.out = out; a.rows = rows; a.NO = NO; a.mode = mode; a.query_major = 0;
-    rc = dcf::launch_head_chain(a, C, st);
+    rc = dcf::launch_head_chain(&a, 1, C, st);
   } else if (rc == 0) {
     DCF_HIP(hipMallocAsync((void**)&ha, (size_t)rows * C * sizeof(float), st));
     DCF_HIP(hipMallocAsync((void**)&hb, (size_t)rows * C * sizeof(float), st));

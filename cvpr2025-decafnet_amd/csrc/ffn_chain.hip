@@ -160,10 +160,10 @@ __global__ __launch_bounds__(256, 1) void k_ffn_chain(FfnChainArgs p) {
   for (int ot = 0; ot < 8; ++ot)
 #pragma unroll
     for (int e = 0; e < 16; ++e) Y[ot][e] = 0.f;
-  f32x16 Hc, Hn;
+  f32x16 H0, H1;                   // first-product accumulators of even / odd chunks: iteration t fills one while the GELU reads the other
   f16x8 bh[2], bl[2];              // GELU(H) of chunk t - 2 as the B operands of its two K steps
 #pragma unroll
-  for (int e = 0; e < 16; ++e) { Hc[e] = 0.f; Hn[e] = 0.f; }
+  for (int e = 0; e < 16; ++e) { H0[e] = 0.f; H1[e] = 0.f; }
 #pragma unroll
   for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, 1) void k_ffn_chain(FfnChainArgs p) {
 
   // iteration t: [A] first product of chunk t -> Hn; [B] GELU + split of chunk t - 1 (Hc) -> bhn / bln; [C] second product of
   // chunk t - 2 (bh / bl) -> Y.  The three are independent of each other inside an iteration.
-  auto iter = [&](int t, auto do_a, auto do_b, auto do_c, auto pre) __attribute__((always_inline)) {
+  auto iter = [&](int t, auto do_a, auto do_b, auto do_c, auto pre, f32x16& Hn, const f32x16& Hc) __attribute__((always_inline)) {
     constexpr bool DA = decltype(do_a)::value, DB = decltype(do_b)::value, DC = decltype(do_c)::value;
     STAMP(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of stage t have landed ...
@@ -235,6 +235,8 @@ __global__ __launch_bounds__(256, 1) void k_ffn_chain(FfnChainArgs p) {
     // them transcendental: what a 32-cycle MFMA hides) between two such statements.
 #define DCF_PIN(acc, fnext, x0, x1) asm volatile("" : "+a"(acc), "+v"(fnext), "+v"(x0), "+v"(x1))
 #define DCF_PIN_MEM(acc, x0, x1) asm volatile("" : "+a"(acc), "+v"(x0), "+v"(x1) : : "memory")
+#define DCF_PIN0(acc, fnext) asm volatile("" : "+a"(acc), "+v"(fnext))           // (slots whose GELU stage is empty)
+#define DCF_PIN0_MEM(acc) asm volatile("" : "+a"(acc) : : "memory")
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int set = s & 1;
@@ -300,10 +302,12 @@ __global__ __launch_bounds__(256, 1) void k_ffn_chain(FfnChainArgs p) {
         DCF_PIN(Y[s >> 1], fa[set][0], gg, g_prev);
         Hn = mma(fa[set][0], xh[s], Hn);
         stage(4);
-        DCF_PIN(Hn, fc[set][0], d0, d1);
+        if (s & 1) DCF_PIN(Hn, fc[set][0], d0, d1);
+        else DCF_PIN0(Hn, fc[set][0]);
         Y[s >> 1] = mma(fc[set][0], bh[s & 1], Y[s >> 1]);
         stage(5);
-        DCF_PIN_MEM(Y[s >> 1], hi, lo);
+        if (s & 1) DCF_PIN_MEM(Y[s >> 1], hi, lo);
+        else DCF_PIN0_MEM(Y[s >> 1]);
       } else {
       if constexpr (DA) {                                   // K step s of H^T = W1 X^T
         Hn = mma(fa[set][1], xh[s], Hn);
@@ -336,19 +340,23 @@ __global__ __launch_bounds__(256, 1) void k_ffn_chain(FfnChainArgs p) {
     }
 #undef DCF_PIN
 #undef DCF_PIN_MEM
+#undef DCF_PIN0
+#undef DCF_PIN0_MEM
     if constexpr (DB) {
       bh[0] = __builtin_bit_cast(f16x8, nh[0]); bh[1] = __builtin_bit_cast(f16x8, nh[1]);
       bl[0] = __builtin_bit_cast(f16x8, nl[0]); bl[1] = __builtin_bit_cast(f16x8, nl[1]);
     }
-    if constexpr (DA) Hc = Hn;
   };
   using T_ = std::true_type;
   using F_ = std::false_type;
-  iter(0, T_{}, F_{}, F_{}, F_{});
-  iter(1, T_{}, T_{}, F_{}, F_{});
-  for (int t = 2; t < NCHUNK; ++t) iter(t, T_{}, T_{}, T_{}, F_{});
-  iter(NCHUNK, F_{}, T_{}, T_{}, F_{});
-  iter(NCHUNK + 1, F_{}, F_{}, T_{}, T_{});
+  iter(0, T_{}, F_{}, F_{}, F_{}, H0, H1);
+  iter(1, T_{}, T_{}, F_{}, F_{}, H1, H0);
+  for (int t = 2; t < NCHUNK; t += 2) {                    // (two iterations per trip: the accumulators swap roles without a copy)
+    iter(t, T_{}, T_{}, T_{}, F_{}, H0, H1);
+    iter(t + 1, T_{}, T_{}, T_{}, F_{}, H1, H0);
+  }
+  iter(NCHUNK, F_{}, T_{}, T_{}, F_{}, H0, H1);
+  iter(NCHUNK + 1, F_{}, F_{}, T_{}, T_{}, H1, H0);
 
   // epilogue: lane (r, h) holds, of row r, the output columns 32 ot + 8 g + 4 h .. + 3 in Y[ot][4 g .. 4 g + 3].  The residual
   // rows were requested at the start of the last iteration (32 loads of 16 bytes per lane into the registers the X planes no

@@ -25,9 +25,10 @@ struct HeadChainArgs {
   unsigned* status;             // sticky numerics word (GemmArgs::status)
 };
 
-// C = 256 or 288, NO = 1 or 2; every launch covers rows [0, rows) of the pyramid
+// C = 256 or 288, NO = 1 or 2; every launch covers rows [0, rows) of the pyramid; count = 1, or 2 heads of the same width on the
+// same rows in one grid
 bool head_chain_supports(int C, int NO);
-int launch_head_chain(const HeadChainArgs& a, int C, hipStream_t stream);
+int launch_head_chain(const HeadChainArgs* a, int count, int C, hipStream_t stream);
 // halfs in the chain image of a (C, 3, C) k3 weight
 size_t head_chain_image_halfs(int C);
 // Wp: the packed fp32 weight [C out][3 taps][C in] (engine.hip pack3) -> img: fp16 hi / lo fragments in the order the kernel

@@ -13,9 +13,10 @@
 // Y[ot][8 q .. 8 q + 7] ARE the B operand of K step 2 ot + q of the next layer, provided the weight fragments enumerate the 16
 // channels of a K step in that order (k = 16 kk + 8 (j >> 2) + 4 h + (j & 3) for half j of lane half h): the "chain image" of
 // launch_split_chain3.  The first layer reads its input rows from memory in the same channel order.
-// Every wave computes its window on its own: a row needs its two neighbours per layer, so of the 32 rows 26 (3 .. 28) come out
-// valid after two trunk layers and the output convolution; windows of consecutive waves overlap by 6 rows.  The out-of-window
-// neighbours of rows 0 and 31 read whatever the wave shift brings (finite values of other lanes): only halo rows see them.
+// A workgroup's four waves hold 128 consecutive rows.  A row needs its two neighbours per layer: inside a wave they are the
+// neighbouring lanes, across a wave boundary the two products concerned (tap 0 of the last row, tap 2 of the first) go through
+// LDS and are added after the next barrier; the window's outer rows have nobody to ask, so of the 128 rows the inner 122 come out
+// valid after two trunk layers and the output convolution (windows of consecutive workgroups overlap by 6 rows).
 #include "head_chain.h"
 
 #include <type_traits>
@@ -32,7 +33,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr float SA = 16.f, SW = 256.f, UNSCALE = 1.f / 4096.f;     // the f16x3 scaling of gemm_bf16s.hip
-constexpr int VALID = 26, HALO = 3;                                // valid rows per 32-row window, halo on each side
+constexpr int HALO = 3, WGROWS = 128, VALID = WGROWS - 2 * HALO;   // a workgroup's window of consecutive rows, of which the inner 122 come out valid
 
 template <int C>
 struct Geo {
@@ -113,21 +114,37 @@ __global__ void k_split_chain3(const float* __restrict__ Wp, unsigned short* __r
   *reinterpret_cast<unsigned*>(img + o + 64 * 8) = lo;
 }
 
-template <int C, int NO>
-__global__ __launch_bounds__(256, 1) void k_head_chain(HeadChainArgs p) {
+// NO = 2 is the compiled width of the output convolution; a head with one output leaves the second one's weights zero in LDS.
+// blockIdx.y picks the head: two heads of the same width on the same rows (cls_head2 and reg_head) share a grid, so the partly
+// filled last round of workgroups is paid once, not twice.
+struct HeadChainBatch { HeadChainArgs a[2]; };
+template <int C>
+__global__ __launch_bounds__(256, 1) void k_head_chain(HeadChainBatch batch) {
+  constexpr int NO = 2;
+  const HeadChainArgs& p = batch.a[blockIdx.y];
   using G = Geo<C>;
   constexpr int KS = G::KS, KH = G::KH, NT = G::NT, STAGE = G::STAGE, PIECES = G::PIECES, NPW = G::NPW;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   float* lds_ln = reinterpret_cast<float*>(lds + 2 * STAGE);      // ln1_w, ln1_b, ln2_w, ln2_b: 4 x [C]
   float* lds_wo = lds_ln + 4 * C;                                  // [NO][3][C]
+  // boundary rows of the waves: xch[parity][wave][0: last row's tap-0 product, 1: first row's tap-2 product][lane half][16]
+  float* lds_x = lds_wo + NO * 3 * C;
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned lane16 = (unsigned)lane * 16u;
-  const int row = (int)blockIdx.x * (4 * VALID) + w * VALID - HALO + r;          // this lane's pyramid row
+  auto xch = [&](int par, int wave, int dir) __attribute__((always_inline)) -> float* { return lds_x + (((par * 4 + wave) * 2 + dir) * 2 + h) * 16; };
+  const int wr = w * 32 + r;                                                       // row of the workgroup's window
+  const int row = (int)blockIdx.x * VALID - HALO + wr;                           // this lane's pyramid row
   const bool inr = row >= 0 && row < p.rows;
   const int row_c = row < 0 ? 0 : (row < p.rows ? row : p.rows - 1);
   const unsigned fl = inr ? p.nbr[row_c] : 0u;
-  const float sfl = (fl & 1u) ? 1.f : 0.f, lfl = (fl & 2u) ? 1.f : 0.f, rfl = (fl & 4u) ? 1.f : 0.f;
+  // neighbour flags with the accumulator un-scaling folded in.  The left / right neighbour of a row is the previous / next lane,
+  // except for rows 0 / 31 of a wave: theirs sits in the neighbouring WAVE and comes through LDS (exchange below); the window's
+  // first and last row have none (halo rows)
+  const float sfl = (fl & 1u) ? UNSCALE : 0.f;
+  const float lfl_in = ((fl & 2u) && r != 0) ? UNSCALE : 0.f, rfl_in = ((fl & 4u) && r != 31) ? UNSCALE : 0.f;
+  const float lfl_x = ((fl & 2u) && r == 0 && w > 0) ? UNSCALE : 0.f, rfl_x = ((fl & 4u) && r == 31 && w < 3) ? UNSCALE : 0.f;
+  const float lfl1 = (fl & 2u) ? 1.f : 0.f, rfl1 = (fl & 4u) ? 1.f : 0.f, sfl1 = (fl & 1u) ? 1.f : 0.f;   // (output convolution: unscaled partials)
 
   // weight stream: stage g = layer * SPL + 2 ot + hf; wave w requests pieces w, w + 4, ... (the last one twice where PIECES is
   // not a multiple of 4: the same bytes to the same place)
@@ -147,7 +164,7 @@ __global__ __launch_bounds__(256, 1) void k_head_chain(HeadChainArgs p) {
   for (int i = tid; i < C; i += 256) {
     lds_ln[i] = p.ln1_w[i]; lds_ln[C + i] = p.ln1_b[i]; lds_ln[2 * C + i] = p.ln2_w[i]; lds_ln[3 * C + i] = p.ln2_b[i];
   }
-  for (int i = tid; i < NO * 3 * C; i += 256) lds_wo[i] = p.Wout[i];
+  for (int i = tid; i < NO * 3 * C; i += 256) lds_wo[i] = i < p.NO * 3 * C ? p.Wout[i] : 0.f;
 
   // Register budget: X planes 8 KS, Y 16 NT, Z 48, fragments 48.  Y and Z live in accumulation registers (192 of 256 at C = 288);
   // the planes of the first XA K steps join them there (MFMA operands may), which leaves the ordinary registers room for two
@@ -177,6 +194,20 @@ __global__ __launch_bounds__(256, 1) void k_head_chain(HeadChainArgs p) {
   f32x16 Y[NT], Z[3];
   bool bad = false;
 
+  // after the next barrier: rows 0 / 31 of the wave take the neighbouring waves' share of tile OT
+  auto fixup = [&](auto ot_) __attribute__((always_inline)) {
+    constexpr int OT = decltype(ot_)::value;
+    const float* pl_ = xch(OT & 1, w > 0 ? w - 1 : 0, 0);
+    const float* pr_ = xch(OT & 1, w < 3 ? w + 1 : 3, 1);
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(pl_ + 4 * g4), b = *reinterpret_cast<const f32x4*>(pr_ + 4 * g4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Y[OT][4 * g4 + i] = __builtin_fmaf(a[i], lfl_x, __builtin_fmaf(b[i], rfl_x, Y[OT][4 * g4 + i]));
+    }
+    asm volatile("" : "+a"(Y[OT]));
+  };
+
   // one stage: the three taps of output tile OT over K half HF; after the second half the taps are put together into Y[OT]
   auto stage = [&](auto ot_, auto hf_, int layer) __attribute__((always_inline)) {
     constexpr int OT = decltype(ot_)::value, HF = decltype(hf_)::value;
@@ -185,6 +216,7 @@ __global__ __launch_bounds__(256, 1) void k_head_chain(HeadChainArgs p) {
     STAMP(0);
     __syncthreads();                                       // ... everybody's have, and nobody reads the other buffer any more
     STAMP(1);
+    if constexpr (HF == 0 && OT > 0) fixup(std::integral_constant<int, OT - 1>{});
     // SPL is even: stage parity = K half.  The base is made opaque per stage: hoisted out of the layer loop, every fragment
     // address became a register of its own (54 of them, and spills); this way they are immediate offsets of one register
     unsigned ab = lane16 + HF * STAGE;
@@ -242,12 +274,32 @@ __global__ __launch_bounds__(256, 1) void k_head_chain(HeadChainArgs p) {
     }
     if constexpr (HF == 1) {
       STAMP(2);
+      // (all lane shifts of a group first, then the arithmetic: a DPP move right behind the instruction that wrote its source
+      // register waits, and sixteen of them in a dependent row made this step 2 100 cycles per tile)
+      f32x4 bz0[4], bz2[4];                                  // this lane's tap-0 / tap-2 products: what a neighbouring wave may need
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float z0 = Z[0][e] * UNSCALE, z1 = Z[1][e] * UNSCALE, z2 = Z[2][e] * UNSCALE;
-        const float y = __builtin_fmaf(from_prev(z0), lfl, __builtin_fmaf(from_next(z2), rfl, z1 * sfl));
-        bad |= !(__builtin_fabsf(z1) <= 3.4028234664e38f);
-        Y[OT][e] = y;
+      for (int g4 = 0; g4 < 4; ++g4) {
+        float p0[4], n2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { bz0[g4][i] = Z[0][4 * g4 + i]; bz2[g4][i] = Z[2][4 * g4 + i]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { p0[i] = from_prev(bz0[g4][i]); n2[i] = from_next(bz2[g4][i]); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float z1 = Z[1][4 * g4 + i];
+          bad |= !(__builtin_fabsf(z1) <= 3.4028234664e38f);
+          Y[OT][4 * g4 + i] = __builtin_fmaf(p0[i], lfl_in, __builtin_fmaf(n2[i], rfl_in, z1 * sfl));
+        }
+      }
+      if (r == 31) {                                         // the next wave's first row adds these (still scaled by 2^12) ...
+        float* o = xch(OT & 1, w, 0);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) *reinterpret_cast<f32x4*>(o + 4 * g4) = bz0[g4];
+      }
+      if (r == 0) {                                          // ... and the previous wave's last row these
+        float* o = xch(OT & 1, w, 1);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) *reinterpret_cast<f32x4*>(o + 4 * g4) = bz2[g4];
       }
       // park the tile in accumulation registers until the LayerNorm: left to itself the compiler keeps all of Y beside the X planes
       // in the 256 ordinary registers (288 wanted) and spills the shifted taps to scratch, with 64 accumulation registers idle
@@ -255,7 +307,6 @@ __global__ __launch_bounds__(256, 1) void k_head_chain(HeadChainArgs p) {
       STAMP(3);
     }
   };
-
   // LayerNorm over the C channels of the lane's row + ReLU, in place on Y (blocks.py:125-131: mean, then the mean of squared
   // deviations); g / b: the layer's parameters in LDS
   auto ln_relu = [&](const float* g, const float* b) __attribute__((always_inline)) {
@@ -293,6 +344,8 @@ __global__ __launch_bounds__(256, 1) void k_head_chain(HeadChainArgs p) {
     };
     tiles(tiles, std::integral_constant<int, 0>{});
     STAMP(2);
+    __syncthreads();
+    fixup(std::integral_constant<int, NT - 1>{});
     ln_relu(lds_ln + 2 * C * layer, lds_ln + 2 * C * layer + C);
     if (layer == 0) {                                      // the next layer's B operand: Y[ot][8 q .. 8 q + 7] = K step 2 ot + q
 #pragma unroll
@@ -328,13 +381,30 @@ __global__ __launch_bounds__(256, 1) void k_head_chain(HeadChainArgs p) {
           const f32x4 wv = *reinterpret_cast<const f32x4*>(lds_wo + (o * 3 + t) * C + 32 * ot + 8 * g4 + 4 * h);
           pt[t][o] += (Y[ot][4 * g4] * wv.x + Y[ot][4 * g4 + 1] * wv.y) + (Y[ot][4 * g4 + 2] * wv.z + Y[ot][4 * g4 + 3] * wv.w);
         }
+  // (the same exchange for the output convolution's tap partials: 2 NO values per wave)
+  float d0[NO], d1[NO], d2[NO];
+#pragma unroll
+  for (int o = 0; o < NO; ++o) { d0[o] = xor32_sum(pt[0][o]); d1[o] = xor32_sum(pt[1][o]); d2[o] = xor32_sum(pt[2][o]); }
+  __syncthreads();                                         // (everybody is past the last fix-up: the exchange area is free)
+  if (h == 0) {
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      if (r == 31) lds_x[(w * 2 + 0) * 2 + o] = d0[o];
+      if (r == 0) lds_x[(w * 2 + 1) * 2 + o] = d2[o];
+    }
+  }
+  __syncthreads();
   float yo[NO];
 #pragma unroll
   for (int o = 0; o < NO; ++o) {
-    const float d0 = xor32_sum(pt[0][o]), d1 = xor32_sum(pt[1][o]), d2 = xor32_sum(pt[2][o]);
-    yo[o] = __builtin_fmaf(from_prev(d0), lfl, __builtin_fmaf(from_next(d2), rfl, d1 * sfl)) + p.bout[o];
+    const float xl_ = lds_x[((w > 0 ? w - 1 : 0) * 2 + 0) * 2 + o], xr_ = lds_x[((w < 3 ? w + 1 : 3) * 2 + 1) * 2 + o];
+    // (the lane shifts first, with every lane active: a DPP move reads 0 from a lane that a branch has switched off)
+    const float sp = from_prev(d0[o]), sn = from_next(d2[o]);
+    const float pv = r == 0 ? (w > 0 ? xl_ : 0.f) : sp;
+    const float nx = r == 31 ? (w < 3 ? xr_ : 0.f) : sn;
+    yo[o] = __builtin_fmaf(pv, lfl1, __builtin_fmaf(nx, rfl1, d1[o] * sfl1)) + (o < p.NO ? p.bout[o] : 0.f);
   }
-  if (h == 0 && r >= HALO && r < HALO + VALID && inr) {
+  if (h == 0 && wr >= HALO && wr < HALO + VALID && inr) {
     const LevelTable* lt = p.lt;
     const int l = find_level_hc(lt, row);
     int64_t dst = row;
@@ -347,7 +417,7 @@ __global__ __launch_bounds__(256, 1) void k_head_chain(HeadChainArgs p) {
     for (int o = 0; o < NO; ++o) {
       float y = yo[o];
       if (p.mode == 1) y = fmaxf(y * lt->scale[l], 0.f);
-      p.out[dst * NO + o] = y;
+      if (o < p.NO) p.out[dst * p.NO + o] = y;
     }
   }
   if (bad && p.status) atomicOr(p.status, 1u);
@@ -379,28 +449,32 @@ int launch_split_chain3(const float* Wp, unsigned short* img, int C, hipStream_t
   return 0;
 }
 
-template <int C, int NO>
-static int launch_hc(const HeadChainArgs& a, hipStream_t stream) {
-  constexpr int bytes = 2 * Geo<C>::STAGE + (4 * C + NO * 3 * C) * (int)sizeof(float);
+template <int C>
+static int launch_hc(const HeadChainArgs* a, int count, hipStream_t stream) {
+  constexpr int bytes = 2 * Geo<C>::STAGE + (4 * C + 2 * 3 * C + 2 * 4 * 2 * 2 * 16) * (int)sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    DCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head_chain<C, NO>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    DCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head_chain<C>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     attr_set = true;
   }
-  const unsigned grid = (unsigned)((a.rows + 4 * VALID - 1) / (4 * VALID));
-  hipLaunchKernelGGL((k_head_chain<C, NO>), dim3(grid), dim3(256), bytes, stream, a);
+  HeadChainBatch b{};
+  for (int i = 0; i < count; ++i) b.a[i] = a[i];
+  const unsigned grid = (unsigned)((a[0].rows + VALID - 1) / VALID);
+  hipLaunchKernelGGL((k_head_chain<C>), dim3(grid, (unsigned)count), dim3(256), bytes, stream, b);
   DCF_HIP(hipGetLastError());
   return 0;
 }
 
-int launch_head_chain(const HeadChainArgs& a, int C, hipStream_t stream) {
-  DCF_CHECK(head_chain_supports(C, a.NO), "launch_head_chain: C = %d, NO = %d (C 256 / 288, NO 1 / 2)", C, a.NO);
-  DCF_CHECK(a.rows > 0 && a.X && a.nbr && a.W1c && a.W2c && a.ln1_w && a.ln1_b && a.ln2_w && a.ln2_b && a.Wout && a.bout && a.lt && a.out,
-            "launch_head_chain: null argument");
-  DCF_CHECK((reinterpret_cast<uintptr_t>(a.X) & 15) == 0 && a.ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(a.W1c) & 15) == 0 &&
-                (reinterpret_cast<uintptr_t>(a.W2c) & 15) == 0, "launch_head_chain: X / weight images must be 16-byte aligned");
-  if (C == 256) return a.NO == 1 ? launch_hc<256, 1>(a, stream) : launch_hc<256, 2>(a, stream);
-  return a.NO == 1 ? launch_hc<288, 1>(a, stream) : launch_hc<288, 2>(a, stream);
+int launch_head_chain(const HeadChainArgs* a, int count, int C, hipStream_t stream) {
+  DCF_CHECK(count == 1 || count == 2, "launch_head_chain: one or two heads per launch");
+  for (int i = 0; i < count; ++i) {
+    DCF_CHECK(head_chain_supports(C, a[i].NO), "launch_head_chain: C = %d, NO = %d (C 256 / 288, NO 1 / 2)", C, a[i].NO);
+    DCF_CHECK(a[i].rows > 0 && a[i].rows == a[0].rows && a[i].X && a[i].nbr && a[i].W1c && a[i].W2c && a[i].ln1_w && a[i].ln1_b && a[i].ln2_w &&
+                  a[i].ln2_b && a[i].Wout && a[i].bout && a[i].lt && a[i].out, "launch_head_chain: null argument or unequal row counts");
+    DCF_CHECK((reinterpret_cast<uintptr_t>(a[i].X) & 15) == 0 && a[i].ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(a[i].W1c) & 15) == 0 &&
+                  (reinterpret_cast<uintptr_t>(a[i].W2c) & 15) == 0, "launch_head_chain: X / weight images must be 16-byte aligned");
+  }
+  return C == 256 ? launch_hc<256>(a, count, stream) : launch_hc<288>(a, count, stream);
 }
 
 }  // namespace dcf
