@@ -255,20 +255,26 @@ __global__ __launch_bounds__(256, 1) void k_head_chain(HeadChainBatch batch) {
     for (int kq = 0; kq < KH; ++kq) {
       const int set = kq & 1, kk = HF * KH + kq;
       if (kq + 1 < KH) frags(kq + 1, set ^ 1);
-#pragma unroll
-      for (int j = 0; j < PPG; ++j) {
+      // the next stage's pieces: at most one in front of the group's MFMAs and one in the middle (the four waves request at the
+      // same moment and a piece occupies the CU's vector-memory path for ~16 cycles: two in a row per wave queue up behind eight)
+      auto piece = [&](int j) __attribute__((always_inline)) {
         const int i = kq * PPG + j;
-        if (kq + 1 < KH && i < NPW) {
+        if (j < PPG && kq + 1 < KH && i < NPW) {
           if constexpr (LAST) { if (has_next) issue_piece(nimg, nsl, HF ^ 1, i); }
           else issue_piece(nimg, nsl, HF ^ 1, i);
         }
-      }
+      };
+      piece(0);
 #pragma unroll
       for (int tap = 0; tap < 3; ++tap) Z[tap] = mma(fa[set][tap][1], xh[kk], Z[tap]);
-#pragma unroll
-      for (int tap = 0; tap < 3; ++tap) Z[tap] = mma(fa[set][tap][0], xl[kk], Z[tap]);
+      Z[0] = mma(fa[set][0][0], xl[kk], Z[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      piece(1);
+      Z[1] = mma(fa[set][1][0], xl[kk], Z[1]);
+      Z[2] = mma(fa[set][2][0], xl[kk], Z[2]);
 #pragma unroll
       for (int tap = 0; tap < 3; ++tap) Z[tap] = mma(fa[set][tap][0], xh[kk], Z[tap]);
+      static_assert(PPG <= 2, "two request slots per group");
       // nothing moves across a group's end: the compiler's own order read every fragment right before its MFMA (no prefetch)
       __builtin_amdgcn_sched_barrier(0);
     }
