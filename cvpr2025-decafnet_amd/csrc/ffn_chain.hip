@@ -442,11 +442,13 @@ int launch_ffn_chain(const FfnChainArgs& a, hipStream_t stream) {
   DCF_CHECK(al16(a.X) && al16(a.R) && al16(a.C) && al16(a.b1) && al16(a.b2) && al16(a.W1s) && al16(a.W2s) && (!a.ls || al16(a.ls)) &&
                 (!a.ln_s || al16(a.ln_s)) && a.ldx % 4 == 0 && a.ldr % 4 == 0 && a.ldc % 4 == 0,
             "launch_ffn_chain: operands must be 16-byte aligned with row pitches that are multiples of 4");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {};                         // per device: the attribute belongs to the device's copy of the kernel
+  int dev = 0;
+  DCF_HIP(hipGetDevice(&dev));
+  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
     DCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ffn_chain<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     DCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ffn_chain<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    attr_set = true;
+    attr_set[dev] = true;
   }
   const unsigned grid = (unsigned)((a.M + 127) / 128);
   if (a.stats) hipLaunchKernelGGL(k_ffn_chain<true>, dim3(grid), dim3(256), LDS_BYTES, stream, a);

@@ -177,7 +177,12 @@ __global__ __launch_bounds__(256, 1) void k_head_chain(HeadChainBatch batch) {
     const bool use = (fl & 1u) != 0;                       // MaskedConv1D multiplies its input by the mask
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
+#ifndef DCF_HC_NO_X        // (ablation build of tools/hc_stamp.sh: no input rows)
       f32x4 v0 = *reinterpret_cast<const f32x4*>(px + 16 * kk), v1 = *reinterpret_cast<const f32x4*>(px + 16 * kk + 8);
+#else
+      f32x4 v0 = f32x4{0.1f, 0.2f, 0.3f, (float)lane}, v1 = f32x4{0.5f, (float)kk, 0.7f, 0.8f};
+      (void)px;
+#endif
       if (!use) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
       unsigned hi[4], lo[4];
       split2_f16(v0.x, v0.y, SA, hi[0], lo[0]);
@@ -458,10 +463,12 @@ int launch_split_chain3(const float* Wp, unsigned short* img, int C, hipStream_t
 template <int C>
 static int launch_hc(const HeadChainArgs* a, int count, hipStream_t stream) {
   constexpr int bytes = 2 * Geo<C>::STAGE + (4 * C + 2 * 3 * C + 2 * 4 * 2 * 2 * 16) * (int)sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {};                         // per device: the attribute belongs to the device's copy of the kernel
+  int dev = 0;
+  DCF_HIP(hipGetDevice(&dev));
+  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
     DCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head_chain<C>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    attr_set = true;
+    attr_set[dev] = true;
   }
   HeadChainBatch b{};
   for (int i = 0; i < count; ++i) b.a[i] = a[i];
