@@ -25,7 +25,17 @@ struct LocalAttnArgs {
   int B, T, C, heads, window;                        // window odd
 };
 
+// global clip self-attention (vid_net.mha_win_size = 0, blocks.py:339-356, :374-393): every query attends to every valid key of
+// its sequence.  Not on the hot path of the published configurations (window 9 / 19): a plain fp32 online-softmax core.
+struct GlobalAttnArgs {
+  const float* Q; const float* K; const float* V;   // [B*T][C]
+  const uint8_t* mask;                               // [B*T] key validity
+  float* O;                                          // [B*T][C]
+  int B, T, C, heads;
+};
+
 int launch_xattn(const XAttnArgs& a, hipStream_t st);
+int launch_global_attn(const GlobalAttnArgs& a, hipStream_t st);
 int launch_local_attn(const LocalAttnArgs& a, hipStream_t st);
 
 }  // namespace dcf

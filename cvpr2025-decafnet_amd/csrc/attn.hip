@@ -523,6 +523,107 @@ int launch_xattn(const XAttnArgs& a, hipStream_t st) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// Global clip self-attention (window 0): online softmax over key tiles of 64, one workgroup per (64 queries, head, sequence).
+// Thread (qi = tid >> 2, part = tid & 3): the query's D channels in registers (scaled by d^-1/2: the reference scales q and k
+// by d^-1/4 each, blocks.py:376-377), scores of 16 of the tile's 64 keys, a quarter of the D output channels.  K / V tiles and
+// the tile's probabilities go through LDS; max / sum are combined over the four threads of a query by DPP.
+// ------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void k_global_attn(GlobalAttnArgs p) {
+  constexpr int KT = 64, KP = D + 4, DP = D / 4;
+  __shared__ float Ks[KT * KP], Vs[KT * KP], Ps[64 * (KT + 4)];
+  __shared__ float valid[KT];
+  const int tid = threadIdx.x, qi = tid >> 2, part = tid & 3;
+  const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * 64;
+  const int64_t base = (int64_t)b * p.T;
+  const int qrow = q0 + qi < p.T ? q0 + qi : p.T - 1;
+  float q[D];
+  {
+    const float sc = 1.0f / sqrtf((float)D);
+    const float* qp = p.Q + (base + qrow) * p.C + hd * D;
+#pragma unroll
+    for (int d = 0; d < D; d += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(qp + d);
+      q[d] = v.x * sc; q[d + 1] = v.y * sc; q[d + 2] = v.z * sc; q[d + 3] = v.w * sc;
+    }
+  }
+  float m = -INFINITY, l = 0.f, o[DP];
+#pragma unroll
+  for (int d = 0; d < DP; ++d) o[d] = 0.f;
+  for (int k0 = 0; k0 < p.T; k0 += KT) {
+    __syncthreads();                                       // the previous tile is consumed
+    for (int i = tid; i < KT * (D / 4); i += 256) {
+      const int j = i / (D / 4), c4 = (i - j * (D / 4)) * 4;
+      const int kr = k0 + j < p.T ? k0 + j : p.T - 1;
+      *reinterpret_cast<f32x4*>(Ks + j * KP + c4) = *reinterpret_cast<const f32x4*>(p.K + (base + kr) * p.C + hd * D + c4);
+      *reinterpret_cast<f32x4*>(Vs + j * KP + c4) = *reinterpret_cast<const f32x4*>(p.V + (base + kr) * p.C + hd * D + c4);
+    }
+    if (tid < KT) valid[tid] = (k0 + tid < p.T && p.mask[base + k0 + tid]) ? 1.f : 0.f;
+    __syncthreads();
+    float s[16], tmax = -INFINITY;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+      const int j = part * 16 + jj;
+      float a = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; d += 4) {
+        const f32x4 kv = *reinterpret_cast<const f32x4*>(Ks + j * KP + d);
+        a = __builtin_fmaf(q[d], kv.x, a); a = __builtin_fmaf(q[d + 1], kv.y, a);
+        a = __builtin_fmaf(q[d + 2], kv.z, a); a = __builtin_fmaf(q[d + 3], kv.w, a);
+      }
+      s[jj] = valid[j] != 0.f ? a : -INFINITY;
+      tmax = fmaxf(tmax, s[jj]);
+    }
+    tmax = fmaxf(tmax, dpp_self<DPP_XOR1>(tmax));
+    tmax = fmaxf(tmax, dpp_self<DPP_XOR2>(tmax));
+    const float mn = fmaxf(m, tmax);
+    const float corr = mn == -INFINITY ? 1.f : __expf(m - mn);     // (no valid key so far: nothing to rescale)
+    float psum = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+      const float pj = s[jj] == -INFINITY ? 0.f : __expf(s[jj] - mn);
+      Ps[qi * (KT + 4) + part * 16 + jj] = pj;
+      psum += pj;
+    }
+    psum += dpp_zero<DPP_XOR1>(psum);
+    psum += dpp_zero<DPP_XOR2>(psum);
+    l = l * corr + psum;
+    m = mn;
+    __syncthreads();                                       // (the four threads of a query share a wave; the barrier keeps it simple)
+#pragma unroll
+    for (int d = 0; d < DP; ++d) o[d] *= corr;
+    for (int j = 0; j < KT; ++j) {
+      const float pj = Ps[qi * (KT + 4) + j];
+#pragma unroll
+      for (int d = 0; d < DP; d += 4) {
+        const f32x4 vv = *reinterpret_cast<const f32x4*>(Vs + j * KP + part * DP + d);
+        o[d] = __builtin_fmaf(pj, vv.x, o[d]); o[d + 1] = __builtin_fmaf(pj, vv.y, o[d + 1]);
+        o[d + 2] = __builtin_fmaf(pj, vv.z, o[d + 2]); o[d + 3] = __builtin_fmaf(pj, vv.w, o[d + 3]);
+      }
+    }
+  }
+  if (q0 + qi < p.T) {
+    const float inv = l > 0.f ? 1.0f / l : 0.f;            // a sequence without a valid key: zeros
+    float* op = p.O + (base + q0 + qi) * p.C + hd * D + part * DP;
+#pragma unroll
+    for (int d = 0; d < DP; d += 4) *reinterpret_cast<f32x4*>(op + d) = f32x4{o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv};
+  }
+}
+
+int launch_global_attn(const GlobalAttnArgs& a, hipStream_t st) {
+  if ((int64_t)a.B * a.T <= 0) return 0;
+  DCF_CHECK(a.heads > 0 && a.C % a.heads == 0, "global_attn: C = %d, heads = %d", a.C, a.heads);
+  const int D = a.C / a.heads;
+  DCF_CHECK(D == 32 || D == 64, "global_attn: head dimension %d (32 or 64)", D);
+  const dim3 grid((unsigned)((a.T + 63) / 64), (unsigned)a.heads, (unsigned)a.B);
+  ProfScope prof("global_attn", st, 4.0 * a.B * (double)a.T * a.T * a.C, 4.0 * 4.0 * a.B * (double)a.T * a.C);
+  if (D == 64) hipLaunchKernelGGL(k_global_attn<64>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(k_global_attn<32>, grid, dim3(256), 0, st, a);
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_local_attn(const LocalAttnArgs& a, hipStream_t st) {
   int64_t rows = (int64_t)a.B * a.T;
   if (rows <= 0) return 0;

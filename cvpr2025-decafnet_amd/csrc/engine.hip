@@ -826,8 +826,13 @@ static int run_encoder(dcf_model* m, const EncW& w, Buffers& b, const float* Xin
   GemmArgs g3[3] = {gemm(b.R[0], E, w.wq, w.bq, b.R[4], E, rows, E, E), gemm(b.R[1], E, w.wk, w.bk, b.R[5], E, rows, E, E),
                     gemm(b.R[2], E, w.wv, w.bv, b.R[6], E, rows, E, E)};
   TRY(run_gemm(m, g3, 3, A_ROWS, st));
-  LocalAttnArgs la{b.R[4], b.R[5], b.R[6], mask_out, b.R[0], B, To, E, c.vid_heads, c.win};
-  TRY(launch_local_attn(la, st));
+  if (c.win > 0) {
+    LocalAttnArgs la{b.R[4], b.R[5], b.R[6], mask_out, b.R[0], B, To, E, c.vid_heads, c.win};
+    TRY(launch_local_attn(la, st));
+  } else {                                                         // mha_win_size = 0: global self-attention (blocks.py:339-343)
+    GlobalAttnArgs ga{b.R[4], b.R[5], b.R[6], mask_out, b.R[0], B, To, E, c.vid_heads};
+    TRY(launch_global_attn(ga, st));
+  }
   // x' = skip * mask + ls_attn * (proj(ctx) + b)                       (blocks.py:586)
   GemmArgs gp = gemm(b.R[0], E, w.wp, w.bp, b.R[1], E, rows, E, E);
   gp.flags = G_RES | G_RES_MASK; gp.rowmask = mask_out; gp.ls = w.ls_attn;
@@ -1451,7 +1456,7 @@ int dcf_model_create(const dcf_config* cfg, dcf_model** out) {
   DCF_CHECK(cfg->D > 0 && cfg->D % 32 == 0, "D=%d must be a positive multiple of 32", cfg->D);
   DCF_CHECK(cfg->TE > 0 && cfg->TE % 32 == 0, "TE=%d must be a positive multiple of 32", cfg->TE);
   DCF_CHECK(cfg->n_levels >= 1 && cfg->n_levels <= DCF_MAX_LEVELS, "n_levels=%d out of range", cfg->n_levels);
-  DCF_CHECK(cfg->win > 0 && (cfg->win & 1), "mha_win_size=%d must be odd and > 0 (global self-attention over clips is not on the hot path)", cfg->win);
+  DCF_CHECK(cfg->win == 0 || (cfg->win > 0 && (cfg->win & 1)), "mha_win_size=%d must be odd, or 0 for global self-attention over the clips", cfg->win);
   DCF_CHECK(cfg->fusion_layers >= 0 && cfg->head_layers >= 0 && cfg->n_embd_convs >= 0 && cfg->n_stem >= 0, "negative layer count");
   DCF_CHECK(cfg->sn >= 1, "sn must be >= 1");
   DCF_CHECK(cfg->model_kind >= 0 && cfg->model_kind <= 2, "model_kind must be 0 (iterative early fusion), 1 (late fusion) or 2 (early fusion)");
@@ -2096,6 +2101,10 @@ int dcf_op_xattn(const float* Q, const float* K, const float* V, const uint8_t* 
 
 int dcf_op_local_attn(const float* Q, const float* K, const float* V, const uint8_t* mask, float* O, int32_t B, int32_t T,
                       int32_t C, int32_t heads, int32_t window, void* stream) {
+  if (window == 0) {
+    dcf::GlobalAttnArgs g{Q, K, V, mask, O, B, T, C, heads};
+    return dcf::launch_global_attn(g, (hipStream_t)stream);
+  }
   dcf::LocalAttnArgs a{Q, K, V, mask, O, B, T, C, heads, window};
   return dcf::launch_local_attn(a, (hipStream_t)stream);
 }

@@ -295,7 +295,8 @@ int dcf_op_layernorm(const float* X, const float* w, const float* b, float* Y, i
 /* cross-attention core (libs/modeling/blocks.py:374-389): Q (B*T, C), K/V (B*Lk, C), kvmask (B*Lk) -> O (B*T, C) */
 int dcf_op_xattn(const float* Q, const float* K, const float* V, const uint8_t* kvmask, float* O, int32_t B, int32_t T,
                  int32_t Lk, int32_t C, int32_t heads, void* stream);
-/* sliding-window attention core (blocks.py:204-325,357-373): Q/K/V (B*T, C), mask (B*T) -> O */
+/* sliding-window attention core (blocks.py:204-325,357-373): Q/K/V (B*T, C), mask (B*T) -> O; window = 0: global attention over
+ * every valid key of the sequence (blocks.py:339-356, :374-393; head dimension 32 or 64) */
 int dcf_op_local_attn(const float* Q, const float* K, const float* V, const uint8_t* mask, float* O, int32_t B, int32_t T,
                       int32_t C, int32_t heads, int32_t window, void* stream);
 /* sidekick scoring (model.py:500-505): shallow (D, T) channel-major, text_cls (nq, D) -> correl (nq, T) */

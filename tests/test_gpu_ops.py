@@ -385,6 +385,31 @@ def test_local_attn_core(L, B, T, C, heads, w):
     torch.testing.assert_close(O.cpu().view(B, T, C), ref, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize('B,T,C,heads', [(2, 200, 128, 4), (1, 1000, 256, 4), (3, 64, 256, 4), (1, 37, 128, 4)])
+def test_global_attn_core(L, B, T, C, heads):
+    """window 0: every query attends to every valid key of its sequence (blocks.py:339-356, :374-393) -- fp64 softmax"""
+    pkg, lib = L
+    g = torch.Generator().manual_seed(T * 5 + C)
+    q, k, v = (torch.randn(B, T, C, generator=g) for _ in range(3))
+    mask = torch.ones(B, T, dtype=torch.bool)
+    mask[0, int(T * 0.7):] = False
+    if T > 20:
+        mask[0, 5] = False
+    d = C // heads
+
+    def split(z):
+        return z.double().view(B, T, heads, d).permute(0, 2, 1, 3)          # (B, h, T, d)
+
+    att = (split(q) / d ** 0.25) @ (split(k) / d ** 0.25).transpose(2, 3)
+    att = att.masked_fill(~mask[:, None, None, :], float('-inf')).softmax(-1)
+    ref = (att @ split(v)).permute(0, 2, 1, 3).reshape(B, T, C)
+    O = torch.full((B * T + 1, C), float('nan'), device='cuda')
+    pkg._lib.check(lib.dcf_op_local_attn(P(q.cuda()), P(k.cuda()), P(v.cuda()), P(mask.cuda()), P(O), B, T, C, heads, 0, st()))
+    Oc = O.cpu()
+    assert torch.isnan(Oc[B * T]).all()
+    torch.testing.assert_close(Oc[:B * T].view(B, T, C).double(), ref, rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize('D,T,nq,norm', [(256, 256, 3, 1), (1024, 4096, 1, 1), (64, 250, 11, 0), (1024, 16384, 8, 1)])
 def test_sidekick(L, D, T, nq, norm):
     pkg, lib = L
