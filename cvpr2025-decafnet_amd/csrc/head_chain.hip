@@ -296,11 +296,7 @@ __global__ __launch_bounds__(256, 1) void k_head_chain(HeadChainBatch batch) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { p0[i] = from_prev(bz0[g4][i]); n2[i] = from_next(bz2[g4][i]); }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float z1 = Z[1][4 * g4 + i];
-          bad |= !(__builtin_fabsf(z1) <= 3.4028234664e38f);
-          Y[OT][4 * g4 + i] = __builtin_fmaf(p0[i], lfl_in, __builtin_fmaf(n2[i], rfl_in, z1 * sfl));
-        }
+        for (int i = 0; i < 4; ++i) Y[OT][4 * g4 + i] = __builtin_fmaf(p0[i], lfl_in, __builtin_fmaf(n2[i], rfl_in, Z[1][4 * g4 + i] * sfl));
       }
       if (r == 31) {                                         // the next wave's first row adds these (still scaled by 2^12) ...
         float* o = xch(OT & 1, w, 0);
@@ -327,6 +323,8 @@ __global__ __launch_bounds__(256, 1) void k_head_chain(HeadChainBatch batch) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) s += Y[ot][e];
     const float mean = xor32_sum(s) * (1.0f / C);
+    bad |= !(__builtin_fabsf(mean) <= 3.4028234664e38f);   // one test per row and layer: a non-finite accumulator anywhere in the row
+                                                           // (an operand left the fp16 range) makes its sum non-finite
     float q = 0.f;
 #pragma unroll
     for (int ot = 0; ot < NT; ++ot)
