@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, 1) void k_head_chain(HeadChainBatch batch) {
   // Register budget: X planes 8 KS, Y 16 NT, Z 48, fragments 48.  Y and Z live in accumulation registers (192 of 256 at C = 288);
   // the planes of the first XA K steps join them there (MFMA operands may), which leaves the ordinary registers room for two
   // fragment sets beside the rest of the planes
-  constexpr int XA = (256 - 16 * NT - 48) / 8 - 1;
+  constexpr int XA = (256 - 16 * NT - 96) / 8 - 1 > 0 ? (256 - 16 * NT - 96) / 8 - 1 : 0;
   // the window's rows as B operands in chain order: K step kk, lane (r, h): channels 16 kk + 4 h .. + 3 and 16 kk + 8 + 4 h .. + 3
   f16x8 xh[KS], xl[KS];
   {
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256, 1) void k_head_chain(HeadChainBatch batch) {
   }
 
   STAMP(5);
-  f32x16 Y[NT], Z[3];
+  f32x16 Y[NT], Z2[2][3];          // Z2[ot & 1]: the three taps' products of output tile ot (the previous tile's are put together meanwhile)
   bool bad = false;
 
   // after the next barrier: rows 0 / 31 of the wave take the neighbouring waves' share of tile OT
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void k_head_chain(HeadChainBatch batch) {
     STAMP(0);
     __syncthreads();                                       // ... everybody's have, and nobody reads the other buffer any more
     STAMP(1);
-    if constexpr (HF == 0 && OT > 0) fixup(std::integral_constant<int, OT - 1>{});
+    if constexpr (HF == 1 && OT > 0) fixup(std::integral_constant<int, OT - 1>{});    // (tile OT - 1 was put together during stage (OT, 0))
     // SPL is even: stage parity = K half.  The base is made opaque per stage: hoisted out of the layer loop, every fragment
     // address became a register of its own (54 of them, and spills); this way they are immediate offsets of one register
     unsigned ab = lane16 + HF * STAGE;
@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256, 1) void k_head_chain(HeadChainBatch batch) {
     const unsigned short* nimg = LAST ? p.W2c : (layer ? p.W2c : p.W1c);
     const int nsl = LAST ? 0 : 2 * OT + HF + 1;
     const bool has_next = !LAST || layer == 0;             // wave uniform
+    f32x16 (&Z)[3] = Z2[OT & 1];
     if constexpr (HF == 0) {
 #pragma unroll
       for (int t = 0; t < 3; ++t)
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(256, 1) void k_head_chain(HeadChainBatch batch) {
     };
     frags(0, 0);
     constexpr int PPG = (NPW + KH - 2) / (KH - 1);          // pieces of the next stage requested per group (none in the last one)
+    float t0[4], t1[4], t2[4], p0[4], n2[4];
 #pragma unroll
     for (int kq = 0; kq < KH; ++kq) {
       const int set = kq & 1, kk = HF * KH + kq;
@@ -269,6 +271,43 @@ __global__ __launch_bounds__(256, 1) void k_head_chain(HeadChainBatch batch) {
           else issue_piece(nimg, nsl, HF ^ 1, i);
         }
       };
+      if (HF == 0 && OT > 0 && kq < 4) {
+        // the previous tile's taps, a quarter (4 of a lane's 16 values) per group and one micro-step behind every MFMA
+        f32x16 (&Zp)[3] = Z2[(OT + 1) & 1];
+        constexpr int PT = OT > 0 ? OT - 1 : 0;
+        const int g4 = kq;
+        piece(0);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const int tap = k % 3, term = k / 3;
+          if (k == 4) piece(1);
+          Z[tap] = mma(term == 0 ? fa[set][tap][1] : fa[set][tap][0], term == 1 ? xl[kk] : xh[kk], Z[tap]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (k == 0) t0[i] = Zp[0][4 * g4 + i];
+            if (k == 1) t2[i] = Zp[2][4 * g4 + i];
+            if (k == 2) p0[i] = from_prev(t0[i]);
+            if (k == 3) n2[i] = from_next(t2[i]);
+            if (k == 4) t1[i] = Zp[1][4 * g4 + i] * sfl;
+            if (k == 5) t1[i] = __builtin_fmaf(n2[i], rfl_in, t1[i]);
+            if (k == 6) t1[i] = __builtin_fmaf(p0[i], lfl_in, t1[i]);
+            if (k == 7) Y[PT][4 * g4 + i] = t1[i];
+          }
+          if (k == 8) {
+            if (r == 31) *reinterpret_cast<f32x4*>(xch(PT & 1, w, 0) + 4 * g4) = f32x4{t0[0], t0[1], t0[2], t0[3]};
+            if (r == 0) *reinterpret_cast<f32x4*>(xch(PT & 1, w, 1) + 4 * g4) = f32x4{t2[0], t2[1], t2[2], t2[3]};
+          }
+          const int tn = (k + 1) % 3, pn = (k + 1) / 3 == 0 ? 1 : 0;
+#define DCF_HPIN(x) asm volatile("" : "+v"(fa[set][tap][term == 0 ? 1 : 0]), "+v"(fa[set][tn][pn]), "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]))
+          if (k == 0) DCF_HPIN(t0);
+          if (k == 1) DCF_HPIN(t2);
+          if (k == 2) DCF_HPIN(p0);
+          if (k == 3) DCF_HPIN(n2);
+          if (k >= 4 && k <= 6) DCF_HPIN(t1);
+#undef DCF_HPIN
+        }
+        if (kq == 3) asm volatile("" : "+a"(Y[PT]));
+      } else {
       piece(0);
 #pragma unroll
       for (int tap = 0; tap < 3; ++tap) Z[tap] = mma(fa[set][tap][1], xh[kk], Z[tap]);
@@ -280,10 +319,11 @@ __global__ __launch_bounds__(256, 1) void k_head_chain(HeadChainBatch batch) {
 #pragma unroll
       for (int tap = 0; tap < 3; ++tap) Z[tap] = mma(fa[set][tap][0], xh[kk], Z[tap]);
       static_assert(PPG <= 2, "two request slots per group");
+      }
       // nothing moves across a group's end: the compiler's own order read every fragment right before its MFMA (no prefetch)
       __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (HF == 1) {
+    if constexpr (HF == 1 && OT == NT - 1) {
       STAMP(2);
       // (all lane shifts of a group first, then the arithmetic: a DPP move right behind the instruction that wrote its source
       // register waits, and sixteen of them in a dependent row made this step 2 100 cycles per tile)
