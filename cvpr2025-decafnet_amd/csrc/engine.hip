@@ -858,11 +858,11 @@ static int run_encoder(dcf_model* m, const EncW& w, Buffers& b, const float* Xin
   return 0;
 }
 
-// From two videos' pyramids on (60 000 rows), in the f16x3 mode: trunk and output convolution of a head as ONE kernel, the trunk
-// activations in registers (head_chain.hip).  One video (32 640 rows = 268 tiles of 122 rows: one round and a sliver) is 2.6 %
-// slower that way (1.784 against 1.739 ms per forward); two videos per forward are 6 % faster (16.26 against 15.34 M clips/s).
+// From 30 000 pyramid rows on (one video of T = 16 384 has 32 640), in the f16x3 mode: trunk and output convolution of a head as
+// ONE kernel, the trunk activations in registers (head_chain.hip).  One video per forward: 1.69 - 1.72 against 1.73 - 1.76 ms with
+// the GEMM launches (268 tiles of 122 rows: one round of workgroups and a sliver); two videos per forward: +6 %.
 static int head_chain_min_rows() {
-  static const int v = getenv("DCF_HEAD_CHAIN_MIN_ROWS") ? atoi(getenv("DCF_HEAD_CHAIN_MIN_ROWS")) : 60000;     // developer switch
+  static const int v = getenv("DCF_HEAD_CHAIN_MIN_ROWS") ? atoi(getenv("DCF_HEAD_CHAIN_MIN_ROWS")) : 30000;     // developer switch
   return v;
 }
 static bool g_no_head_chain() {
