@@ -55,6 +55,7 @@ SIGNATURES = {
                                      ctypes.POINTER(i32), c_f32p, c_f32p, c_f32p, c_u8p, vp]),
     'dcf_debug_copy': (i32, [vp, i32, c_f32p, i64, vp]),
     'dcf_graph_active': (i32, [vp]),
+    'dcf_debug_set_option': (i32, [ctypes.c_char_p, i32]),
     'dcf_model_set_graph_mode': (i32, [vp, i32]),
     'dcf_profile_enable': (i32, [i32]),
     'dcf_profile_report': (i64, [ctypes.c_char_p, i64]),

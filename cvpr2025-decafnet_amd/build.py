@@ -16,7 +16,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libdecafnet_hip.so')
-SOURCES = ['engine.hip', 'gemm.hip', 'gemm_bf16s.hip', 'ffn_chain.hip', 'head_chain.hip', 'rowops.hip', 'attn.hip', 'score.hip', 'heads.hip', 'postproc.hip', 'loss.hip']
+SOURCES = ['engine.hip', 'gemm.hip', 'gemm_bf16s.hip', 'ffn_chain.hip', 'head_chain.hip', 'dec_chain.hip', 'rowops.hip', 'attn.hip', 'score.hip', 'heads.hip', 'postproc.hip', 'loss.hip']
 ARCH = 'gfx950'
 FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
 
@@ -59,16 +59,23 @@ def _includes(src, seen=None):
     return seen
 
 
-def build(force=False, verbose=False):
-    objdir = os.path.join(HERE, 'build')
+def build(force=False, verbose=False, variant=None, extra=None, drop=None):
+    """variant=None: the product build (cvpr2025-decafnet_amd/libdecafnet_hip.so).  variant='name': a developer build under
+    build/variants/name/ with `extra` = {file: [flags]} added and the flags listed in `drop` = {file: [flags]} removed
+    ('*' = every file) -- loaded through DCF_LIB_PATH for A/B runs inside one GPU call (tools/); never the product path."""
+    objdir = os.path.join(HERE, 'build') if variant is None else os.path.join(HERE, 'build', 'variants', variant)
+    out = OUT if variant is None else os.path.join(objdir, 'libdecafnet_hip.so')
     os.makedirs(objdir, exist_ok=True)
     cc = hipcc()
     jobs = []
+    extra, drop = extra or {}, drop or {}
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace('.hip', '.o'))
         if force or _stale(obj, [src] + sorted(_includes(src))):
-            jobs.append([cc] + FLAGS + EXTRA.get(s, []) + ['-c', src, '-o', obj])
+            gone = set(drop.get(s, [])) | set(drop.get('*', []))
+            flags = [f for f in FLAGS + EXTRA.get(s, []) if f not in gone] + extra.get(s, []) + extra.get('*', [])
+            jobs.append([cc] + flags + ['-c', src, '-o', obj])
 
     def run(cmd):
         if verbose:
@@ -83,9 +90,9 @@ def build(force=False, verbose=False):
             if verbose and err.strip():
                 print(err)
     objs = [os.path.join(objdir, s.replace('.hip', '.o')) for s in SOURCES]
-    if force or jobs or _stale(OUT, objs):
-        run([cc, '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', OUT] + objs)
-    return OUT
+    if force or jobs or _stale(out, objs):
+        run([cc, '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', out] + objs)
+    return out
 
 
 if __name__ == '__main__':

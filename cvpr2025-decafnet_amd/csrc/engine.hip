@@ -24,6 +24,7 @@
 #include "../../include/decafnet_hip.h"
 #include "attn.h"
 #include "common.h"
+#include "dec_chain.h"
 #include "ffn_chain.h"
 #include "gemm.h"
 #include "head_chain.h"
@@ -42,6 +43,18 @@ void set_error(const char* fmt, ...) {
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
   g_err = buf;
+}
+
+// ---- developer / test options (dcf_debug_set_option): named integers that override a built-in threshold, e.g. the row count from
+// which a chain kernel replaces its launches, so that the operator tests can send small fixtures through the large-grid kernels
+static std::unordered_map<std::string, int>& debug_options() {
+  static std::unordered_map<std::string, int> o;
+  return o;
+}
+static int debug_option(const char* name, int dflt) {
+  auto& o = debug_options();
+  auto it = o.find(name);
+  return it == o.end() ? dflt : it->second;
 }
 
 // ---- per-launch profiler (dcf_profile_*) --------------------------------------------------
@@ -161,6 +174,7 @@ struct DecW {   // one TransformerDecoder of the fusion
   const float *wp_il, *bp_il;                // xattn.proj with its output rows in blocks of (32 scale rows, 32 shift rows of the same channels)
   const float *ln_ffn_w, *ln_ffn_b, *fc_w, *fc_b, *pj_w, *pj_b, *ls_ffn;
   const float *fc_wf, *fc_s, *fc_c;          // ffn.fc with ln_ffn folded in
+  const unsigned short *wq_chain, *wp_chain; // chain images of xattn.query / the interleaved xattn.proj (dec_chain.hip) or nullptr
 };
 struct TextEncW {   // one TransformerEncoder of text_net (stride 0: no depthwise convs, global attention)
   const float *ln_attn_w, *ln_attn_b, *wq, *bq, *wk, *bk, *wv, *bv, *wp, *bp, *ls_attn;
@@ -388,6 +402,18 @@ static int resolve_decoder(dcf_model* m, const std::string& p, int E, int TE, hi
     if (pack3(m, w.wp, 2, E / 32, 32 * E, 1, 0, 2, st, &w.wp_il)) return -1;
     if (pack3(m, w.bp, 2, E / 32, 32, 1, 0, 2, st, &w.bp_il)) return -1;
     SPLIT(w.wp_il, 2 * E, E);
+  }
+  // the attention half of the layer as one kernel (dec_chain.hip): chain-order fragment images of the two projections
+  w.wq_chain = w.wp_chain = nullptr;
+  if (m->gemm_terms == GEMM_F16X3 && w.wp_il && dec_chain_supports(E, m->cfg.fusion_heads, 1)) {
+    unsigned short *iq = nullptr, *ip = nullptr;
+    DCF_HIP(hipMalloc(&iq, chain1_image_halfs(E, E) * sizeof(unsigned short)));
+    m->owned.push_back(reinterpret_cast<float*>(iq));
+    DCF_HIP(hipMalloc(&ip, chain1_image_halfs(2 * E, E) * sizeof(unsigned short)));
+    m->owned.push_back(reinterpret_cast<float*>(ip));
+    if (launch_split_chain1(w.wq, iq, E, E, st, nullptr)) return -1;          // (range: the same weights passed split_weight above)
+    if (launch_split_chain1(w.wp_il, ip, 2 * E, E, st, nullptr)) return -1;
+    w.wq_chain = iq; w.wp_chain = ip;
   }
   return 0;
 }
@@ -645,6 +671,8 @@ struct Buffers {
   float *P1, *P2, *tn, *partial, *correl, *gate;
   uint8_t *mask_all, *nbr_all, *kvmask, *maskv;
   float *X, *R[7], *H2, *HID, *F, *HA, *HB, *HC, *HD, *logits1, *tcnA, *tcnB, *kvn, *Kt, *Vt;
+  unsigned short* kvimg;                      // [B] K / V^T fragment images of the projected text (dec_chain.hip)
+  float* kmadd;                               // [B][64] additive key mask
   float* stats;                               // [rows][E / 64] (sum, sum of squares): row statistics carried between GEMMs
   float* hstats[2];                           // the same for the k3 trunks (heads over the whole pyramid, embedding convolutions)
 };
@@ -680,6 +708,8 @@ static void carve(Arena& a, const dcf_config& c, int T0, int B, int nq, int S, i
   b.kvn = a.take<float>((size_t)B * Lk * c.TE);
   b.Kt = a.take<float>((size_t)B * Lk * E);
   b.Vt = a.take<float>((size_t)B * Lk * E);
+  b.kvimg = a.take<unsigned short>((size_t)B * kv_image_halfs(2));
+  b.kmadd = a.take<float>((size_t)B * 64);
 }
 
 static int get_plan(dcf_model* m, int T0, int B, hipStream_t st, Plan** out) {
@@ -743,6 +773,11 @@ constexpr int STATS_W = 64;
 // the GEMM pair on 64-row tiles is faster (16 384 rows = 128 tiles, half the chip: 78 - 86 us against 63 + 40 for the pair;
 // 8 192 rows: the same 80 us against 31 + 29).
 constexpr int FFN_CHAIN_MIN_ROWS = 16384;
+static bool g_no_ffn_chain();
+// (the row / width part of can_chain_ffn: what a producer needs to know to hand over row statistics)
+static bool can_chain_ffn_rows(dcf_model* m, int rows, int E) {
+  return !g_no_ffn_chain() && E == 256 && rows >= FFN_CHAIN_MIN_ROWS && m->gemm_terms == GEMM_F16X3;
+}
 static bool g_no_ffn_chain() {
   static const bool off = getenv("DCF_NO_FFN_CHAIN") != nullptr;     // developer switch: always the GEMM pair
   return off;
@@ -780,10 +815,11 @@ static bool g_no_carry() {
   static const bool off = getenv("DCF_NO_LN_CARRY") != nullptr;      // developer switch: standalone LayerNorm launches instead
   return off;
 }
-static bool can_carry_ln(dcf_model* m, const float* fc_wf, int rows, int n_prod, int k_prod, int E) {
-  if (g_no_carry() || !fc_wf || m->gemm_terms == 0 || !m->wsplit.count(fc_wf)) return false;
-  const int terms = m->wsplit_terms[fc_wf];
-  return gemm_can_carry_stats(rows, n_prod, k_prod, 1, terms) && gemm_can_carry_stats(rows, 4 * E, E, 1, terms);
+// (each GEMM is asked about with the arithmetic of ITS weight image: one of the two may have fallen back to bf16x6)
+static bool can_carry_ln(dcf_model* m, const float* prod_w, const float* fc_wf, int rows, int n_prod, int k_prod, int E) {
+  if (g_no_carry() || !fc_wf || !prod_w || m->gemm_terms == 0 || !m->wsplit.count(fc_wf) || !m->wsplit.count(prod_w)) return false;
+  return gemm_can_carry_stats(rows, n_prod, k_prod, 1, m->wsplit_terms[prod_w]) &&
+         gemm_can_carry_stats(rows, 4 * E, E, 1, m->wsplit_terms[fc_wf]);
 }
 
 // can this GEMM carry its LayerNorm in the epilogue?  (bf16-split path with planes for W, tile spanning the row)
@@ -843,7 +879,7 @@ static int run_encoder(dcf_model* m, const EncW& w, Buffers& b, const float* Xin
   if (can_fuse_ln(m, w.wp, rows, E, E, A_ROWS)) {                 // ln_ffn(x') rides in the epilogue
     gp.ln_w = w.ln_ffn_w; gp.ln_b = w.ln_ffn_b; gp.Y = b.R[2]; gp.ldy = E;
     TRY(run_gemm(m, &gp, 1, A_ROWS, st));
-  } else if (can_carry_ln(m, w.fc_wf, rows, E, E, E)) {
+  } else if (can_carry_ln(m, w.wp, w.fc_wf, rows, E, E, E)) {
     // ... or as row statistics: the projection writes (sum, sum of squares) of every x' row, ffn.fc runs on the raw x' with
     // ln_ffn folded into its weights and applies (mean, rstd) in its epilogue -- ln_ffn(x') is neither written nor read
     gp.stats_out = b.stats; gp.stats_w = STATS_W;
@@ -1012,6 +1048,21 @@ static int run_head_pair(dcf_model* m, const HeadW& h1, const HeadW& h2, Buffers
   return 0;
 }
 
+// From 32 768 level-0 rows on (two videos of T = 16 384 per forward), in the f16x3 mode, E = 256, 4 heads, <= 64 text tokens: the
+// attention half of a fusion layer as ONE kernel (dec_chain.hip).  Below that the 128-row windows leave CUs idle.
+static int dec_chain_min_rows() {
+  const int o = debug_option("dec_chain_min_rows", -1);            // dcf_debug_set_option (tests), then the developer switch
+  if (o >= 0) return o;
+  static const int v = getenv("DCF_DEC_CHAIN_MIN_ROWS") ? atoi(getenv("DCF_DEC_CHAIN_MIN_ROWS")) : 32768;
+  return v;
+}
+static bool can_chain_dec(dcf_model* m, const DecW& w, const LevelTable* lt, int rows, int64_t ldx, int Lk) {
+  static const bool off = getenv("DCF_NO_DEC_CHAIN") != nullptr;    // developer switch: the separate launches
+  const dcf_config& c = m->cfg;
+  return !off && !lt && m->gemm_terms == GEMM_F16X3 && w.wq_chain && w.wp_chain && dec_chain_supports(c.E, c.fusion_heads, Lk) &&
+         c.TE % 32 == 0 && rows >= dec_chain_min_rows() && ldx % 4 == 0;
+}
+
 // XAttNFusion._forward (fusion.py:56-66): n x TransformerDecoder (blocks.py:632-650) + ln_out.
 // X [rows][ldx] is updated in place; the final ln_out goes to out [rows][ld_out].  Either one level of B sequences
 // of T rows (lt == nullptr) or the whole pyramid (lt != nullptr: rows ordered [level][b][t], neighbour flags `nbr`
@@ -1028,16 +1079,39 @@ static int run_fusion(dcf_model* m, Buffers& b, float* X, int64_t ldx, int B, in
   for (size_t li = 0; li < m->dec.size(); ++li) {
     const DecW& w = m->dec[li];
     bool carry = false;
+    const bool chain = can_chain_dec(m, w, lt, rows, ldx, Lk);
+    TextLnArgs tl{*dm, b.kvn, b.kvmask, w.ln_kv_w, w.ln_kv_b, Lk, c.TE};
+    TRY(launch_text_ln(tl, B, st));
+    GemmArgs gkv[2] = {gemm(b.kvn, c.TE, w.wk, w.bk, b.Kt, E, B * Lk, E, c.TE), gemm(b.kvn, c.TE, w.wv, w.bv, b.Vt, E, B * Lk, E, c.TE)};
+    TRY(run_gemm(m, gkv, 2, A_ROWS, st));
+    if (chain) {
+      // q3 = adaln(q) * scale + shift straight from the raw stream: ln_xattn_q, the depthwise convolution, q_norm, the query
+      // projection, the cross attention and the modulating projection in one kernel; ln_ffn(q3) as row statistics where the FFN
+      // can take them, by the LayerNorm kernel otherwise
+      const int lk2 = Lk <= 32 ? 1 : 2;
+      TRY(launch_kv_image(b.Kt, b.Vt, b.kvmask, B, Lk, lk2, b.kvimg, b.kmadd, st));
+      carry = !g_no_carry() && w.fc_wf && m->wsplit.count(w.fc_wf) &&
+              (can_chain_ffn_rows(m, rows, E) || gemm_can_carry_stats(rows, 4 * E, E, 1, m->wsplit_terms[w.fc_wf]));
+      DecChainArgs da{};
+      da.X = X; da.ldx = ldx; da.mask = mask; da.ln_q_w = w.ln_q_w; da.ln_q_b = w.ln_q_b; da.dw = w.dw; da.qn_w = w.qn_w; da.qn_b = w.qn_b;
+      da.Wq = w.wq_chain; da.bq = w.bq; da.KV = b.kvimg; da.kmask = b.kmadd; da.Wp = w.wp_chain; da.bp = w.bp_il;
+      da.Q3 = b.R[2]; da.ldq = E; da.stats_out = carry ? b.stats : nullptr; da.stats_w = STATS_W;
+      da.B = B; da.T = T; da.affine = c.xattn_affine; da.lk2 = lk2; da.status = m->status;
+      {
+        ProfScope prof("gemm_f16x3<dec_chain>", st, 2.0 * rows * E * 3.0 * E + 4.0 * rows * E * Lk, (double)rows * E * 4.0 * 2.0);
+        TRY(launch_dec_chain(da, st));
+      }
+      if (!carry) {
+        LnArgs ln{}; ln.X = b.R[2]; ln.ldx = E; ln.Y = b.R[0]; ln.ldy = E; ln.w = w.ln_ffn_w; ln.b = w.ln_ffn_b; ln.rows = rows; ln.C = E;
+        TRY(launch_ln(ln, st));
+      }
+    } else {
     DecPreArgs dp{X, ldx, mask, w.ln_q_w, w.ln_q_b, w.dw, w.qn_w, w.qn_b, b.R[0], b.R[1], lt ? 1 : B, lt ? rows : T, E};
     dp.nbr = lt ? nbr : nullptr;
     dp.affine = c.xattn_affine;
     TRY(launch_dec_pre(dp, st));
     GemmArgs gq = gemm(b.R[0], E, w.wq, w.bq, b.R[2], E, rows, E, E);
     TRY(run_gemm(m, &gq, 1, A_ROWS, st));
-    TextLnArgs tl{*dm, b.kvn, b.kvmask, w.ln_kv_w, w.ln_kv_b, Lk, c.TE};
-    TRY(launch_text_ln(tl, B, st));
-    GemmArgs gkv[2] = {gemm(b.kvn, c.TE, w.wk, w.bk, b.Kt, E, B * Lk, E, c.TE), gemm(b.kvn, c.TE, w.wv, w.bv, b.Vt, E, B * Lk, E, c.TE)};
-    TRY(run_gemm(m, gkv, 2, A_ROWS, st));
     if (lt) {
       for (int l = 0; l < lt->n_levels; ++l) {
         XAttnArgs xa{b.R[2] + (int64_t)lt->start[l] * E, b.Kt, b.Vt, b.kvmask, b.R[0] + (int64_t)lt->start[l] * E, B, lt->T[l], Lk, E, c.fusion_heads, m->status};
@@ -1052,7 +1126,7 @@ static int run_fusion(dcf_model* m, Buffers& b, float* X, int64_t ldx, int B, in
       // never written; Xn = ln_ffn(q3) by the LayerNorm kernel
       GemmArgs gh = gemm(b.R[0], E, w.wp_il, w.bp_il, b.R[2], E, rows, 2 * E, E);
       gh.flags = G_ADALN; gh.R = b.R[1]; gh.ldr = E;
-      carry = can_carry_ln(m, w.fc_wf, rows, 2 * E, E, E);            // ln_ffn(q3) as row statistics (see run_encoder)
+      carry = can_carry_ln(m, w.wp_il, w.fc_wf, rows, 2 * E, E, E);            // ln_ffn(q3) as row statistics (see run_encoder)
       if (carry) { gh.stats_out = b.stats; gh.stats_w = STATS_W; }
       TRY(run_gemm(m, &gh, 1, A_ROWS, st));
       if (!carry) {
@@ -1064,6 +1138,7 @@ static int run_fusion(dcf_model* m, Buffers& b, float* X, int64_t ldx, int B, in
       TRY(run_gemm(m, &gh, 1, A_ROWS, st));
       TRY(launch_dec_mid(b.R[1], b.H2, w.ln_ffn_w, w.ln_ffn_b, b.R[2], b.R[0], rows, E, st));
     }
+    }   // (!chain)
     GemmArgs go = gemm(b.HID, 4 * E, w.pj_w, w.pj_b, X, ldx, rows, E, 4 * E);
     go.flags = G_RES | G_OUT_MASK; go.rowmask = mask; go.ls = w.ls_ffn; go.R = b.R[2]; go.ldr = E;
     const float* fc_in = carry ? b.R[2] : b.R[0];
@@ -1080,7 +1155,8 @@ static int run_fusion(dcf_model* m, Buffers& b, float* X, int64_t ldx, int B, in
     }
     if (li + 1 == m->dec.size() && carry_out && m->fus_out_w && ldx == E &&
         m->embd_fc_wf && m->wsplit.count(m->embd_fc_wf) && !g_no_carry() &&
-        gemm_can_carry_stats(rows, E, 4 * E, 1, m->wsplit_terms[m->embd_fc_wf]) && gemm_can_carry_stats(rows, E, E, 1, m->wsplit_terms[m->embd_fc_wf])) {
+        m->wsplit.count(w.pj_w) && gemm_can_carry_stats(rows, E, 4 * E, 1, m->wsplit_terms[w.pj_w]) &&
+        gemm_can_carry_stats(rows, E, E, 1, m->wsplit_terms[m->embd_fc_wf])) {
       // last layer: ffn.proj leaves the raw stream in X together with its row statistics, vid_net.embd_fc (ln_out folded into its
       // weights) applies them: ln_out(x) is neither written nor read (fusion.py:64-66 -> video_net.py:131)
       go.stats_out = b.stats; go.stats_w = STATS_W;
@@ -1277,13 +1353,14 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
         const bool with_pe = c.use_abs_pe && i == c.n_embd_convs - 1;
         int sw = 0;
         if (epend >= 0) {
-          // A = the RAW output of the previous convolution (in R[0]); this one writes to R[3], then R[0] <-> R[3] swap roles
+          // A = the RAW output of the previous convolution (in R[0]); this one writes to R[3] (a level-0 sized scratch that no
+          // fusion pass uses) and the LayerNorm reads it from there.  The buffers are NOT swapped: R[0..2] hold rowsF rows (the
+          // whole pyramid with late / second fusion), R[3..6] only the level-0 rows.
           g.A = b.R[0]; g.C = b.R[3];
           norm_a(g, b.hstats[0], E, epend_w, m->embd_ln_w[epend], m->embd_ln_b[epend]);
           epend = -1;
           TRY(run_gemm(m, &g, 1, A_ROWS_TAP3, st));
-          std::swap(b.R[0], b.R[3]);
-          LnArgs ln{}; ln.X = b.R[0]; ln.ldx = E; ln.Y = b.X; ln.ldy = E; ln.w = m->embd_ln_w[i]; ln.b = m->embd_ln_b[i];
+          LnArgs ln{}; ln.X = b.R[3]; ln.ldx = E; ln.Y = b.X; ln.ldy = E; ln.w = m->embd_ln_w[i]; ln.b = m->embd_ln_b[i];
           ln.rows = rows0; ln.C = E; ln.relu = 1;
           if (with_pe) { ln.pe = m->pe; ln.mask = mask0; ln.T = T0; }
           TRY(launch_ln(ln, st));
@@ -1448,7 +1525,7 @@ static int text_encode(dcf_model* m, const float* tokens, const uint8_t* token_m
 extern "C" {
 
 const char* dcf_last_error(void) { return dcf::g_err.c_str(); }
-int dcf_abi_version(void) { return 5; }
+int dcf_abi_version(void) { return 6; }
 
 int dcf_model_create(const dcf_config* cfg, dcf_model** out) {
   DCF_CHECK(cfg && out, "dcf_model_create: null argument");
@@ -1698,6 +1775,17 @@ int dcf_forward_eval_gated(dcf_model* m, const float* vid, const float* shallow_
 }
 
 int dcf_graph_active(const dcf_model* m) { return m ? m->last_launch : 0; }
+
+int dcf_debug_set_option(const char* name, int32_t value) {
+  DCF_CHECK(name && *name, "dcf_debug_set_option: empty name");
+  static const char* known[] = {"dec_chain_min_rows", "enc_chain_min_rows"};
+  bool ok = false;
+  for (const char* k : known) ok = ok || strcmp(k, name) == 0;
+  DCF_CHECK(ok, "dcf_debug_set_option: unknown option '%s'", name);
+  if (value < 0) dcf::debug_options().erase(name);           // back to the built-in value
+  else dcf::debug_options()[name] = value;
+  return 0;
+}
 
 int dcf_model_set_graph_mode(dcf_model* m, int32_t mode) {
   DCF_CHECK(m && mode >= 0 && mode <= 2, "dcf_model_set_graph_mode: mode must be 0 (auto), 1 (always) or 2 (never)");

@@ -207,7 +207,12 @@ __device__ __forceinline__ void gemm_epilogue_wide_body(const GemmArgs& p, f32x1
       const unsigned row = (unsigned)((wm * TM + i) * 32 + rr + 8 * q);
       f32x4 v = *reinterpret_cast<const f32x4*>(tile + (rr + 8 * q) * EPI_PITCH + c4);
       if (fold) {                                                        // LayerNorm of the A row, folded (see GemmArgs)
-        const float mean = wg_in[2 * ((wm * TM + i) * 32 + rr + 8 * q)], rstd = wg_in[2 * ((wm * TM + i) * 32 + rr + 8 * q) + 1];
+        float mean = wg_in[2 * ((wm * TM + i) * 32 + rr + 8 * q)], rstd = wg_in[2 * ((wm * TM + i) * 32 + rr + 8 * q) + 1];
+#if defined(DCF_FOLD_NOP)        // diagnostic builds of tools/micro/pkfma_repro.py (profiles/r04_pkfma_hazard.md): never the product build
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(mean), "+v"(rstd));
+#elif defined(DCF_FOLD_MOV)
+        { float m2, r2; asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(m2), "=&v"(r2) : "v"(mean), "v"(rstd)); mean = m2; rstd = r2; }
+#endif
         // explicit fused multiply-adds: the compiler's own contraction differs between tile instantiations, and a row must
         // get the same bits whatever tile shape its batch size selects
         const f32x4 l = lns[j], bb = bias[j];

@@ -30,6 +30,18 @@ def _reduce(elem, total, count, reduction, shape):
     raise ValueError(f'reduction {reduction!r}')
 
 
+def _selection(select, n, device):
+    """the boolean mask the kernels index with: one byte per element, on the device of the operands (no broadcasting -- the
+    kernel reads select[i] for every i < n)"""
+    if select is None:
+        return None
+    if not select.is_cuda or select.device != device:
+        raise ValueError(f'select must live on {device} (got {select.device})')
+    if select.numel() != n:
+        raise ValueError(f'select has {select.numel()} elements, the loss has {n}')
+    return select.to(torch.bool).contiguous()
+
+
 def sigmoid_focal_loss(inputs, targets, alpha: float = -1, gamma: float = 2.0, smoothing: bool = True, reduction: str = 'none',
                        select=None):
     """loss.py:5-57.  ``select`` (optional bool tensor of the same shape): only these elements count ('sum' / 'mean'); with
@@ -38,7 +50,7 @@ def sigmoid_focal_loss(inputs, targets, alpha: float = -1, gamma: float = 2.0, s
     assert x.shape == t.shape
     n = x.numel()
     lib = _lib.lib()
-    sel = None if select is None else select.to(torch.bool).contiguous()
+    sel = _selection(select, n, x.device)
     elem = torch.empty_like(x) if reduction == 'none' else None
     total = torch.zeros(1, device=x.device) if reduction != 'none' else None
     count = torch.zeros(1, device=x.device, dtype=torch.int32) if reduction == 'mean' else None
@@ -52,7 +64,7 @@ def _ctr_iou(input_offsets, target_offsets, reduction, eps, kind, select):
     assert a.shape == b.shape and a.shape[-1] == 2
     n = a.numel() // 2
     lib = _lib.lib()
-    sel = None if select is None else select.to(torch.bool).contiguous()
+    sel = _selection(select, n, a.device)
     elem = torch.empty(a.shape[:-1], device=a.device) if reduction == 'none' else None
     total = torch.zeros(1, device=a.device) if reduction != 'none' else None
     count = torch.zeros(1, device=a.device, dtype=torch.int32) if reduction == 'mean' else None

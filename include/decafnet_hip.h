@@ -38,7 +38,7 @@ typedef struct dcf_config {
   int32_t n_embd_convs;   /* opt.model.vid_net.arch[0]                                             */
   int32_t n_stem;         /* opt.model.vid_net.arch[1]                                             */
   int32_t n_levels;       /* opt.model.vid_net.arch[2]  (= number of FPN levels = TCN depth)       */
-  int32_t win;            /* opt.model.vid_net.mha_win_size (odd, > 0)                             */
+  int32_t win;            /* opt.model.vid_net.mha_win_size (odd; 0 = global clip attention)      */
   int32_t head_layers;    /* opt.model.cls_head.n_layers (= reg_head.n_layers)                     */
   int32_t sn;             /* opt.model.sn     (clips per scoring block)                            */
   float sratio;           /* opt.model.sratio (fraction of blocks that keep expert features)       */
@@ -189,6 +189,12 @@ int dcf_graph_active(const dcf_model* m);
  * videos; eager launches for the one-video-per-call pattern, which measures 5 % faster that way), 1 = always capture and
  * replay, 2 = never.  The environment variable DCF_NO_GRAPH=1 disables graphs whatever the mode.  ABI version 5. */
 int dcf_model_set_graph_mode(dcf_model* m, int32_t mode);
+/* Test / developer switch (process wide): override a built-in dispatch threshold so that the operator tests can send small
+ * reference fixtures through the kernels the engine only picks for large grids.  Names: "dec_chain_min_rows" (level-0 rows from
+ * which the attention half of a fusion layer runs as one kernel, csrc/dec_chain.hip), "enc_chain_min_rows" (the same for the
+ * encoder layers).  value < 0 restores the built-in value.  Not a reference interface; results do not depend on it beyond
+ * rounding.  ABI version 6. */
+int dcf_debug_set_option(const char* name, int32_t value);
 
 /* --------------------------------------------------------------------------------------------
  * Proposal decoding: replaces Evaluator._collect_segments (libs/worker_v2.py:1131-1187).

@@ -207,6 +207,43 @@ def gen_ops64():
     save('ops64.npz', out)
 
 
+@torch.no_grad()
+def gen_ops256():
+    """The reference's TransformerDecoder and TransformerEncoder (stride 1 / 2, window 9) at the PROBE width E = 256 with four
+    64-channel heads -- the width the one-kernel attention halves (csrc/dec_chain.hip, csrc/enc_chain.hip) are built for, which the
+    32- / 64-channel blocks of ops.npz / ops64.npz cannot reach.  Weights are synth.make_state_dict(shapes, seed): the fixture keeps
+    (shapes, seed) and the reference's outputs, the tests regenerate the tensors."""
+    from libs.modeling import blocks as B
+    g = torch.Generator().manual_seed(13)
+    out = {}
+    E, T, TEk, Lk = 256, 192, 256, 33
+    x = torch.randn(2, E, T, generator=g)
+    mask = torch.ones(2, 1, T, dtype=torch.bool)
+    mask[0, :, 170:] = False
+    mask[1, :, 127:129] = False            # a hole across a 128-row window boundary
+    mask[1, :, 150:] = False
+    kv = torch.randn(2, TEk, Lk, generator=g)
+    kv_mask = torch.ones(2, 1, Lk, dtype=torch.bool)
+    kv_mask[1, :, 20:] = False
+    out['x'], out['mask'], out['kv'], out['kv_mask'] = x, mask, kv, kv_mask
+    meta = {}
+    m = B.TransformerDecoder(E, TEk, n_heads=4).eval()
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict(synth.make_state_dict(shapes, 250))
+    y, _ = m(x, mask, kv, kv_mask)
+    out['dec/y'] = y
+    meta['dec'] = dict(shapes={k: list(v) for k, v in shapes.items()}, seed=250)
+    for s_ in (1, 2):
+        m = B.TransformerEncoder(E, stride=s_, n_heads=4, window_size=9).eval()
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        m.load_state_dict(synth.make_state_dict(shapes, 240 + s_))
+        y, ym = m(x, mask)
+        out[f'enc_s{s_}/y'], out[f'enc_s{s_}/ymask'] = y, ym
+        meta[f'enc_s{s_}'] = dict(shapes={k: list(v) for k, v in shapes.items()}, seed=240 + s_)
+    out['meta'] = meta
+    save('ops256.npz', out)
+
+
 # ------------------------------------------------------------------ G2: gate
 @torch.no_grad()
 def gen_gate():
@@ -750,6 +787,8 @@ if __name__ == '__main__':
         gen_ops()
     if 'ops64' in which or 'ops' in which:
         gen_ops64()
+    if 'ops256' in which:
+        gen_ops256()
     if 'gate' in which:
         gen_gate()
     if 'e2e' in which:

@@ -525,6 +525,81 @@ def test_decoder_block_golden(L, mode, gm):
     lib.dcf_model_destroy(h)
 
 
+def _dec_shapes(E, TE):
+    return {'ln_xattn_q.weight': (E, 1), 'ln_xattn_q.bias': (E, 1), 'ln_xattn_kv.weight': (TE, 1), 'ln_xattn_kv.bias': (TE, 1),
+            'xattn.q_conv.conv.weight': (E, 1, 3), 'xattn.q_norm.weight': (E, 1), 'xattn.q_norm.bias': (E, 1),
+            'xattn.xattn.query.weight': (E, E, 1), 'xattn.xattn.query.bias': (E,), 'xattn.xattn.key.weight': (E, TE, 1),
+            'xattn.xattn.key.bias': (E,), 'xattn.xattn.value.weight': (E, TE, 1), 'xattn.xattn.value.bias': (E,),
+            'xattn.xattn.proj.weight': (2 * E, E, 1), 'xattn.xattn.proj.bias': (2 * E,), 'ln_ffn.weight': (E, 1), 'ln_ffn.bias': (E, 1),
+            'ffn.fc.weight': (4 * E, E, 1), 'ffn.fc.bias': (4 * E,), 'ffn.proj.weight': (E, 4 * E, 1), 'ffn.proj.bias': (E,),
+            'drop_path_ffn.scale': (1, E, 1)}
+
+
+def _run_decoder(pkg, lib, sd, x, mask, kv, kvm, affine, chain_rows):
+    """dcf_op_decoder on a scratch model; chain_rows = the dec_chain_min_rows option (0: the one-kernel attention half)"""
+    bs, E, T = x.shape
+    pkg._lib.check(lib.dcf_debug_set_option(b'dec_chain_min_rows', chain_rows))
+    try:
+        h = scratch_model(pkg, lib, sd, 'd', E=E, TE=kv.size(1), fusion_heads=4, gemm_mode=16, xattn_affine=int(affine))
+        X = tok(x)
+        texts = [kv[b, :, :int(kvm[b, 0].numel())].contiguous().cuda() for b in range(bs)]
+        tmasks = [kvm[b, 0].contiguous().cuda() for b in range(bs)]
+        tp = (ctypes.c_void_p * bs)(*[t.data_ptr() for t in texts])
+        mp = (ctypes.c_void_p * bs)(*[t.data_ptr() for t in tmasks])
+        ln = (ctypes.c_int32 * bs)(*[kv.size(2)] * bs)
+        pkg._lib.check(lib.dcf_op_decoder(h, b'd', P(X), P(mask.reshape(-1).contiguous().cuda()), bs, T, tp, mp, ln, st()), 'dcf_op_decoder')
+        y = untok(X, bs, T)
+        lib.dcf_model_destroy(h)
+        return y
+    finally:
+        pkg._lib.check(lib.dcf_debug_set_option(b'dec_chain_min_rows', -1))
+
+
+# (bs, T, Lk, affine): one and two 32-key tiles, windows with a partial tail (T % 128 != 0), sequences whose tail is padded, a
+# hole inside the valid part, partially masked keys; T = 2560 x 2 is large enough for the row statistics to ride into ffn.fc
+@pytest.mark.parametrize('bs,T,Lk,affine', [(2, 200, 33, 0), (3, 128, 20, 0), (1, 450, 64, 1), (2, 2560, 33, 0)])
+def test_dec_chain_vs_fp64(L, bs, T, Lk, affine):
+    """the attention half of a fusion layer as one kernel (csrc/dec_chain.hip) inside dcf_op_decoder: TransformerDecoder.forward
+    (blocks.py:632-650) at E = 256 against the oracle run in fp64, and against the launches the kernel replaces"""
+    pkg, lib = L
+    E, TE = 256, 256
+    sd = pkg.synth.make_state_dict(_dec_shapes(E, TE), 4000 + T + Lk)
+    g = torch.Generator().manual_seed(bs * 100 + T + Lk)
+    x = torch.randn(bs, E, T, generator=g) * 1.5 + 0.3
+    mask = torch.ones(bs, 1, T, dtype=torch.bool)
+    for b in range(bs):
+        n = int(torch.randint(T // 2, T + 1, (1,), generator=g)) if b else T
+        mask[b, :, n:] = False
+        if T > 140:
+            mask[b, :, 127:129] = False                           # a hole across a window boundary
+    kv = torch.randn(bs, TE, Lk, generator=g)
+    kvm = torch.ones(bs, 1, Lk, dtype=torch.bool)
+    if bs > 1:
+        kvm[1, :, Lk * 2 // 3:] = False
+    sdd = {'d.' + k: v.double() for k, v in sd.items()}
+    want, _ = R.transformer_decoder(sdd, 'd', x.double(), mask, kv.double(), kvm, 4, adaln=not affine)
+    got = _run_decoder(pkg, lib, sd, x, mask, kv, kvm, affine, 0)
+    old = _run_decoder(pkg, lib, sd, x, mask, kv, kvm, affine, 1 << 30)
+    torch.testing.assert_close(old.double(), want, rtol=2e-5, atol=2e-5)      # (padded rows included: they carry the shift)
+    torch.testing.assert_close(got.double(), want, rtol=2e-5, atol=2e-5)
+
+
+def _ops256_weights(pkg, o, block):
+    meta = o.js('meta')[block]
+    return pkg.synth.make_state_dict({k: tuple(v) for k, v in meta['shapes'].items()}, meta['seed'])
+
+
+@pytest.mark.parametrize('chain_rows', [0, 1 << 30])
+def test_decoder_block_golden_probe_width(L, chain_rows):
+    """TransformerDecoder.forward (blocks.py:632-650) at E = 256, four heads, 33 keys: reference fixture ops256.npz through
+    dcf_op_decoder, with the attention half as one kernel (dec_chain.hip) and as the separate launches"""
+    pkg, lib = L
+    o = Golden('ops256.npz')
+    sd = _ops256_weights(pkg, o, 'dec')
+    got = _run_decoder(pkg, lib, sd, o.t('x'), o.t('mask'), o.t('kv'), o.t('kv_mask'), 0, chain_rows)
+    torch.testing.assert_close(got, o.t('dec/y'), rtol=2e-5, atol=2e-5)
+
+
 def test_tcn_golden(L):
     """TCN.forward (tcn.py:66-84), 4 dilated residual layers: reference fixture tcn/y"""
     pkg, lib = L

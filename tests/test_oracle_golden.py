@@ -93,6 +93,26 @@ def test_ops64_wide_text_stream():
     close(y, o.t('dec/y'))
 
 
+def _ops256_weights(pkg, o, block):
+    meta = o.js('meta')[block]
+    return pkg.synth.make_state_dict({k: tuple(v) for k, v in meta['shapes'].items()}, meta['seed'])
+
+
+def test_ops256_probe_width_blocks(pkg):
+    """TransformerDecoder and TransformerEncoder (stride 1 / 2, window 9) at the probe width E = 256, four 64-channel heads:
+    ops256.npz (the reference's outputs; weights regenerated from the recorded shapes and seed)"""
+    o = Golden('ops256.npz')
+    x, mask = o.t('x'), o.t('mask')
+    sd = {'d.' + k: v for k, v in _ops256_weights(pkg, o, 'dec').items()}
+    y, _ = R.transformer_decoder(sd, 'd', x, mask, o.t('kv'), o.t('kv_mask'), 4)
+    close(y, o.t('dec/y'), rtol=2e-5, atol=2e-5)
+    for s in (1, 2):
+        sd = {'e.' + k: v for k, v in _ops256_weights(pkg, o, f'enc_s{s}').items()}
+        y, m = R.transformer_encoder(sd, 'e', x, mask, s, 4, 9)
+        close(y, o.t(f'enc_s{s}/y'), rtol=2e-5, atol=2e-5)
+        assert torch.equal(m, o.t(f'enc_s{s}/ymask'))
+
+
 def test_tcn(ops):
     sd = {'r.' + k: v for k, v in ops.sub('tcn/w/').items()}
     y = R.tcn_refine(sd, 'r', ops.t('tcn/x'), ops.t('mask'), 4)
