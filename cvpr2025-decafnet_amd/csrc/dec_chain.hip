@@ -67,6 +67,21 @@ __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigne
 
 __device__ __forceinline__ f32x16 mma(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
+#ifdef DCF_DC_STAMP
+// diagnostic build only (tools/dc_stamp.sh): cycles wave 0 of workgroup 1 spends in the segments of the kernel
+__device__ unsigned long long dcf_dc_stamps[16];
+__device__ __forceinline__ unsigned long long dc_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define STAMP(i) do { const unsigned long long t_ = dc_stamp(); acc_[i] += t_ - last_; last_ = t_; } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 // lane i <- lane i - 1 / lane i + 1 of the wave; the lane without a source (0 / 63) takes `edge`
 __device__ __forceinline__ float shr1(float v, float edge) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x138, 0xf, 0xf, false));
@@ -172,18 +187,9 @@ __global__ __launch_bounds__(256, 1) void k_dec_chain(DecChainArgs p) {
     const unsigned short* src = s >= 8 ? p.Wp + (size_t)(s - 8) * 64 * 512 : (kv ? kv_b + (size_t)(s >> 1) * KVP * 512 : p.Wq + (size_t)(s >> 1) * 64 * 512);
     glds16(src + (size_t)pc * 512, lane16, (unsigned)(s & 1) * STAGE + (unsigned)pc * 1024u);
   };
-#pragma unroll
-  for (int i = 0; i < 16; ++i) issue_piece(0, i);
-
-  // ---- per-channel parameters -> LDS
-  {
-    ldf[P_LNW + tid] = p.ln_q_w[tid]; ldf[P_LNB + tid] = p.ln_q_b[tid];
-    ldf[P_QNW + tid] = p.qn_w[tid]; ldf[P_QNB + tid] = p.qn_b[tid];
-    ldf[P_DW + tid] = p.dw[tid]; ldf[P_DW + 256 + tid] = p.dw[256 + tid]; ldf[P_DW + 512 + tid] = p.dw[512 + tid];
-    ldf[P_BQ + tid] = p.bq[tid];
-    ldf[P_BP + tid] = p.bp[tid]; ldf[P_BP + 256 + tid] = p.bp[256 + tid];
-    if (tid < 64) ldf[P_MS + tid] = p.kmask[(size_t)b * 64 + tid];
-  }
+#ifdef DCF_DC_STAMP
+  unsigned long long acc_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = dc_stamp();
+#endif
 
   // ---- the lane's row: 128 channels in D layout, xv[4 ot + g] = channels 32 ot + 8 g + 4 h .. + 3
   const float* px = p.X + row * p.ldx + 4 * h;
@@ -197,6 +203,20 @@ __global__ __launch_bounds__(256, 1) void k_dec_chain(DecChainArgs p) {
   const bool evalid = edge_wave && te >= 0 && te < p.T && p.mask[(int64_t)b * p.T + (te >= 0 && te < p.T ? te : 0)] != 0;
   f32x4 ev = f32x4{0.f, 0.f, 0.f, 0.f};
   if (evalid) ev = *reinterpret_cast<const f32x4*>(p.X + ((int64_t)b * p.T + te) * p.ldx + 4 * lane);
+  // (the rows first: their latency is the kernel's start-up; the first stage of the weight stream has the whole front end to land)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) issue_piece(0, i);
+
+  // ---- per-channel parameters -> LDS
+  {
+    ldf[P_LNW + tid] = p.ln_q_w[tid]; ldf[P_LNB + tid] = p.ln_q_b[tid];
+    ldf[P_QNW + tid] = p.qn_w[tid]; ldf[P_QNB + tid] = p.qn_b[tid];
+    ldf[P_DW + tid] = p.dw[tid]; ldf[P_DW + 256 + tid] = p.dw[256 + tid]; ldf[P_DW + 512 + tid] = p.dw[512 + tid];
+    ldf[P_BQ + tid] = p.bq[tid];
+    ldf[P_BP + tid] = p.bp[tid]; ldf[P_BP + 256 + tid] = p.bp[256 + tid];
+    if (tid < 64) ldf[P_MS + tid] = p.kmask[(size_t)b * 64 + tid];
+  }
+
 
   if (!valid) {
 #pragma unroll
@@ -204,6 +224,7 @@ __global__ __launch_bounds__(256, 1) void k_dec_chain(DecChainArgs p) {
   }
   float mean1, rstd1;
   row_stats(xv, mean1, rstd1);
+  STAMP(0);
   __syncthreads();                                               // parameters are in LDS
   // xq = ln_xattn_q(q) * mask, in place
 #pragma unroll
@@ -233,7 +254,9 @@ __global__ __launch_bounds__(256, 1) void k_dec_chain(DecChainArgs p) {
     if (evalid) y = d * rs * *reinterpret_cast<const f32x4*>(ldf + P_LNW + 4 * lane) + *reinterpret_cast<const f32x4*>(ldf + P_LNB + 4 * lane);
     *reinterpret_cast<f32x4*>(ldf + (w == 0 ? X_LAST : X_FIRST + 4 * 256) + 4 * lane) = y;
   }
+  STAMP(1);
   __syncthreads();
+  STAMP(2);
   // depthwise k3 convolution along the rows (MaskedConv1D: the inputs are already masked), in place
   {
     const bool is32 = lane == 32, is31 = lane == 31;
@@ -273,16 +296,68 @@ __global__ __launch_bounds__(256, 1) void k_dec_chain(DecChainArgs p) {
     }
   }
 
+  STAMP(3);
   // ---- heads: Q_h, softmax(K_h Q_h^T), V_h^T P^T -> ctx planes
   f16x8 cth[16], ctl[16];
   const float qscale = 1.0f / sqrtf(sqrtf((float)DHD));         // d^-1/4 on q (and on k, in the image): blocks.py:179, :379
   auto stage_begin = [&](int s) __attribute__((always_inline)) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's pieces of stage s have landed ...
+    STAMP(4);
     __syncthreads();                                             // ... everybody's have, and nobody reads the other buffer any more
+    STAMP(5);
+  };
+  // Two 32-row output tiles over 16 K steps: acc[t2] += A(t2, kk) B[kk], three products per step (lo x hi, hi x lo, hi x hi), the
+  // two tiles alternating.  The fragments of step kk + 1 are read while step kk computes; `dma(kk)` requests pieces of the next
+  // stage at the start of the step; `side(kk, slot)` is vector work of ANOTHER part of the chain (the previous head's context
+  // split, the previous block's epilogue) placed between the MFMAs: a wave issues in order, so vector work hides behind MFMAs only
+  // where it sits between them in program order (the compiler left to itself puts it behind the last one: ffn_chain.hip).
+  auto gemm2 = [&](const unsigned char* buf, const f16x8 (&bh)[16], const f16x8 (&bl)[16], f32x16 (&acc)[2], auto&& dma, auto&& side)
+                   __attribute__((always_inline)) {
+    f16x8 fr[2][4];
+    auto frags = [&](int kk, int set) __attribute__((always_inline)) {
+      fr[set][0] = *reinterpret_cast<const f16x8*>(buf + ((0 * 16 + kk) * 2) * 1024);
+      fr[set][1] = *reinterpret_cast<const f16x8*>(buf + ((0 * 16 + kk) * 2 + 1) * 1024);
+      fr[set][2] = *reinterpret_cast<const f16x8*>(buf + ((1 * 16 + kk) * 2) * 1024);
+      fr[set][3] = *reinterpret_cast<const f16x8*>(buf + ((1 * 16 + kk) * 2 + 1) * 1024);
+    };
+    frags(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const int set = kk & 1;
+      if (kk + 1 < 16) frags(kk + 1, set ^ 1);
+      acc[0] = mma(fr[set][1], bh[kk], acc[0]);
+      acc[1] = mma(fr[set][3], bh[kk], acc[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      side(kk, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0] = mma(fr[set][0], bl[kk], acc[0]);
+      acc[1] = mma(fr[set][2], bl[kk], acc[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      side(kk, 1);
+      dma(kk);                                                   // (behind the step's fragment reads; 258 against 264 us in front of them)
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0] = mma(fr[set][0], bh[kk], acc[0]);
+      acc[1] = mma(fr[set][2], bh[kk], acc[1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // the context of a head (O, two 32-channel tiles in D layout) -> planes of K steps 2 (2 hd + ct) + q of the projection, one pair
+  // of values per call: piece u = 0 .. 15 <-> (ct, q, i) = (u >> 3, (u >> 2) & 1, u & 3)
+  f32x16 O[2];
+  u32x4 cx_h, cx_l;
+  auto ctx_piece = [&](int hd, int u) __attribute__((always_inline)) {
+    const int ct = u >> 3, q = (u >> 2) & 1, i = u & 3;
+    unsigned hi, lo;
+    split2_f16(O[ct][8 * q + 2 * i], O[ct][8 * q + 2 * i + 1], SA, hi, lo);
+    cx_h[i] = hi; cx_l[i] = lo;
+    if (i == 3) {
+      cth[2 * (2 * hd + ct) + q] = __builtin_bit_cast(f16x8, cx_h);
+      ctl[2 * (2 * hd + ct) + q] = __builtin_bit_cast(f16x8, cx_l);
+    }
   };
 #pragma unroll
   for (int hd = 0; hd < DHEADS; ++hd) {
-    // -- stage 2 hd: Q_h^T = Wq_h qc^T
+    // -- stage 2 hd: Q_h^T = Wq_h qc^T; beside its MFMAs the context split of the previous head
     f32x16 QA[2];
     {
       stage_begin(2 * hd);
@@ -291,19 +366,13 @@ __global__ __launch_bounds__(256, 1) void k_dec_chain(DecChainArgs p) {
       for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
         for (int e = 0; e < 16; ++e) QA[t2][e] = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        if (kk < KVP / 4) issue_piece(2 * hd + 1, kk);            // the next stage (K_h | V_h): KVP / 4 pieces per wave
-        const f16x8 a0h = *reinterpret_cast<const f16x8*>(buf + ((0 * 16 + kk) * 2) * 1024), a0l = *reinterpret_cast<const f16x8*>(buf + ((0 * 16 + kk) * 2 + 1) * 1024);
-        const f16x8 a1h = *reinterpret_cast<const f16x8*>(buf + ((1 * 16 + kk) * 2) * 1024), a1l = *reinterpret_cast<const f16x8*>(buf + ((1 * 16 + kk) * 2 + 1) * 1024);
-        QA[0] = mma(a0l, qh[kk], QA[0]);
-        QA[1] = mma(a1l, qh[kk], QA[1]);
-        QA[0] = mma(a0h, ql[kk], QA[0]);
-        QA[1] = mma(a1h, ql[kk], QA[1]);
-        QA[0] = mma(a0h, qh[kk], QA[0]);
-        QA[1] = mma(a1h, qh[kk], QA[1]);
-      }
+      gemm2(buf, qh, ql, QA,
+            [&](int kk) __attribute__((always_inline)) {                                  // the next stage (K_h | V_h)
+              if (kk < KVP / 4) issue_piece(2 * hd + 1, kk);
+            },
+            [&](int kk, int slot) __attribute__((always_inline)) { if (hd > 0 && slot == 0) ctx_piece(hd - 1, kk); });
     }
+    STAMP(6);
     // q_h * d^-1/4 as unscaled fp16 planes (attn.hip): K step ks = 2 t2 + q <- QA[t2][8 q .. 8 q + 7]
     f16x8 sh_[4], sl_[4];
 #pragma unroll
@@ -320,6 +389,7 @@ __global__ __launch_bounds__(256, 1) void k_dec_chain(DecChainArgs p) {
         }
         split8(v8, 1.f, sh_[2 * t2 + q], sl_[2 * t2 + q]);
       }
+    STAMP(7);
     // -- stage 2 hd + 1: S^T = K_h Q_h^T, softmax over the keys, O_h^T = V_h^T P^T
     {
       stage_begin(2 * hd + 1);
@@ -329,24 +399,43 @@ __global__ __launch_bounds__(256, 1) void k_dec_chain(DecChainArgs p) {
       for (int kt = 0; kt < LK2; ++kt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) S[kt][e] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        // the next stage (Wq of the next head, or the first projection block): 16 pieces per wave, four per K step
-#pragma unroll
-        for (int i = 0; i < 4; ++i) issue_piece(2 * hd + 2, 4 * ks + i);
-        f16x8 kh[LK2], kl[LK2];
+      f16x8 kf[2][LK2][2];
+      auto kfrags = [&](int ks, int set) __attribute__((always_inline)) {
 #pragma unroll
         for (int kt = 0; kt < LK2; ++kt) {
-          kh[kt] = *reinterpret_cast<const f16x8*>(buf + ((kt * 4 + ks) * 2) * 1024);
-          kl[kt] = *reinterpret_cast<const f16x8*>(buf + ((kt * 4 + ks) * 2 + 1) * 1024);
+          kf[set][kt][0] = *reinterpret_cast<const f16x8*>(buf + ((kt * 4 + ks) * 2) * 1024);
+          kf[set][kt][1] = *reinterpret_cast<const f16x8*>(buf + ((kt * 4 + ks) * 2 + 1) * 1024);
         }
+      };
+      kfrags(0, 0);
 #pragma unroll
-        for (int kt = 0; kt < LK2; ++kt) S[kt] = mma(kh[kt], sl_[ks], S[kt]);
+      for (int ks = 0; ks < 4; ++ks) {
+        const int set = ks & 1;
+        if (ks + 1 < 4) kfrags(ks + 1, set ^ 1);
+        // the next stage (Wq of the next head, or the first projection block): 16 pieces per wave, two per K step here, the rest
+        // beside the second product
+        issue_piece(2 * hd + 2, 2 * ks);
+        issue_piece(2 * hd + 2, 2 * ks + 1);
 #pragma unroll
-        for (int kt = 0; kt < LK2; ++kt) S[kt] = mma(kl[kt], sh_[ks], S[kt]);
+        for (int kt = 0; kt < LK2; ++kt) S[kt] = mma(kf[set][kt][0], sl_[ks], S[kt]);
 #pragma unroll
-        for (int kt = 0; kt < LK2; ++kt) S[kt] = mma(kh[kt], sh_[ks], S[kt]);
+        for (int kt = 0; kt < LK2; ++kt) S[kt] = mma(kf[set][kt][1], sh_[ks], S[kt]);
+#pragma unroll
+        for (int kt = 0; kt < LK2; ++kt) S[kt] = mma(kf[set][kt][0], sh_[ks], S[kt]);
+        __builtin_amdgcn_sched_barrier(0);
       }
+      STAMP(8);
+      // the first fragments of the second product are on their way while the softmax runs
+      f16x8 vf[2][2][2];
+      auto vfrags = [&](int st_, int set) __attribute__((always_inline)) {          // st_ = kt * 2 + q
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const int pc = 8 * LK2 + ((ct * LK2 + (st_ >> 1)) * 2 + (st_ & 1)) * 2;
+          vf[set][ct][0] = *reinterpret_cast<const f16x8*>(buf + pc * 1024);
+          vf[set][ct][1] = *reinterpret_cast<const f16x8*>(buf + (pc + 1) * 1024);
+        }
+      };
+      vfrags(0, 0);
       // softmax over the keys of the row: slot e of lane half h = key 32 kt + (e & 3) + 8 (e >> 2) + 4 h
       float mx = -INFINITY;
 #pragma unroll
@@ -374,87 +463,92 @@ __global__ __launch_bounds__(256, 1) void k_dec_chain(DecChainArgs p) {
           for (int e = 0; e < 8; ++e) v8[e] = S[kt][8 * q + e] * inv;
           split8(v8, 1.f, ph[kt][q], pl[kt][q]);
         }
-      f32x16 O[2];
+      STAMP(9);
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int e = 0; e < 16; ++e) O[ct][e] = 0.f;
 #pragma unroll
-      for (int kt = 0; kt < LK2; ++kt)
+      for (int st_ = 0; st_ < 2 * LK2; ++st_) {
+        const int set = st_ & 1, kt = st_ >> 1, q = st_ & 1;
+        if (st_ + 1 < 2 * LK2) vfrags(st_ + 1, set ^ 1);
+        // (the rest of the next stage's pieces)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          f16x8 vh[2], vl[2];
+        for (int i = 0; i < 8 / (2 * LK2); ++i) issue_piece(2 * hd + 2, 8 + st_ * (8 / (2 * LK2)) + i);
 #pragma unroll
-          for (int ct = 0; ct < 2; ++ct) {
-            const int pc = 8 * LK2 + ((ct * LK2 + kt) * 2 + q) * 2;
-            vh[ct] = *reinterpret_cast<const f16x8*>(buf + pc * 1024);
-            vl[ct] = *reinterpret_cast<const f16x8*>(buf + (pc + 1) * 1024);
-          }
+        for (int ct = 0; ct < 2; ++ct) O[ct] = mma(vf[set][ct][0], pl[kt][q], O[ct]);
 #pragma unroll
-          for (int ct = 0; ct < 2; ++ct) O[ct] = mma(vh[ct], pl[kt][q], O[ct]);
+        for (int ct = 0; ct < 2; ++ct) O[ct] = mma(vf[set][ct][1], ph[kt][q], O[ct]);
 #pragma unroll
-          for (int ct = 0; ct < 2; ++ct) O[ct] = mma(vl[ct], ph[kt][q], O[ct]);
-#pragma unroll
-          for (int ct = 0; ct < 2; ++ct) O[ct] = mma(vh[ct], ph[kt][q], O[ct]);
-        }
-      // ctx of this head -> planes of K steps 2 (2 hd + ct) + q of the projection (f16x3 scaling)
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          float v8[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v8[e] = O[ct][8 * q + e];
-          split8(v8, SA, cth[2 * (2 * hd + ct) + q], ctl[2 * (2 * hd + ct) + q]);
-        }
+        for (int ct = 0; ct < 2; ++ct) O[ct] = mma(vf[set][ct][0], ph[kt][q], O[ct]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      STAMP(10);
     }
   }
 
-  // ---- projection blocks: (scale_j, shift_j) = Wp_j ctx, q3 = Xa * scale + shift
+  // ---- projection blocks: (scale_j, shift_j) = Wp_j ctx, q3 = Xa * scale + shift.  The context split of the last head rides in
+  // the first eight K steps of block 0 (its planes are K steps 12 .. 15); the epilogue of block j - 1 beside the MFMAs of block j.
   float ps = 0.f, pss = 0.f;
   float* qout = p.Q3 + row * p.ldq + 4 * h;
+  f32x16 A2[2][2];                                               // [block parity][scale, shift]
+  f32x4 xr[2][4];                                                // the rows' own channels of a block again (L2): Xa is not kept in registers
+  auto load_xr = [&](int j) __attribute__((always_inline)) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    stage_begin(8 + j);
-    const unsigned char* buf = lds + (j & 1) * STAGE + lane16;
-    // the rows' own channels of this block again (L2): Xa is not kept in registers across the chain
-    f32x4 xr[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) xr[g] = *reinterpret_cast<const f32x4*>(px + 32 * j + 8 * g);
-    f32x16 A2[2];
-#pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) A2[t2][e] = 0.f;
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      if (j + 1 < 8) issue_piece(8 + j + 1, kk);
-      const f16x8 a0h = *reinterpret_cast<const f16x8*>(buf + ((0 * 16 + kk) * 2) * 1024), a0l = *reinterpret_cast<const f16x8*>(buf + ((0 * 16 + kk) * 2 + 1) * 1024);
-      const f16x8 a1h = *reinterpret_cast<const f16x8*>(buf + ((1 * 16 + kk) * 2) * 1024), a1l = *reinterpret_cast<const f16x8*>(buf + ((1 * 16 + kk) * 2 + 1) * 1024);
-      A2[0] = mma(a0l, cth[kk], A2[0]);
-      A2[1] = mma(a1l, cth[kk], A2[1]);
-      A2[0] = mma(a0h, ctl[kk], A2[0]);
-      A2[1] = mma(a1h, ctl[kk], A2[1]);
-      A2[0] = mma(a0h, cth[kk], A2[0]);
-      A2[1] = mma(a1h, cth[kk], A2[1]);
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < 4; ++g) xr[j & 1][g] = *reinterpret_cast<const f32x4*>(px + 32 * j + 8 * g);
+  };
+  f32x4 ep_sc, ep_sf;                                            // (scale, shift) of the group whose first half has run
+  auto epilogue = [&](int j, int g, int half) __attribute__((always_inline)) {   // half 0: scale / shift; half 1: modulate, store, statistics
+    if (half == 0) {
       const f32x4 bs = *reinterpret_cast<const f32x4*>(ldf + P_BP + 64 * j + 8 * g + 4 * h);
       const f32x4 bh = *reinterpret_cast<const f32x4*>(ldf + P_BP + 64 * j + 32 + 8 * g + 4 * h);
-      f32x4 xa = valid ? xr[g] : f32x4{0.f, 0.f, 0.f, 0.f};
-      if (!p.affine) xa = (xa - mean1) * rstd1;                  // adaln: LayerNorm without affine (blocks.py:620-621)
-      f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float sc = __builtin_fmaf(A2[0][4 * g + e], UNSCALE, bs[e]), sf = __builtin_fmaf(A2[1][4 * g + e], UNSCALE, bh[e]);
-        o[e] = xa[e] * sc + sf;
+        ep_sc[e] = __builtin_fmaf(A2[j & 1][0][4 * g + e], UNSCALE, bs[e]);
+        ep_sf[e] = __builtin_fmaf(A2[j & 1][1][4 * g + e], UNSCALE, bh[e]);
       }
+    } else {
+      f32x4 xa = valid ? xr[j & 1][g] : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (!p.affine) xa = (xa - mean1) * rstd1;                  // adaln: LayerNorm without affine (blocks.py:620-621)
+      const f32x4 o = xa * ep_sc + ep_sf;
       if (inseq) *reinterpret_cast<f32x4*>(qout + 32 * j + 8 * g) = o;
       ps += (o.x + o.y) + (o.z + o.w);
       pss += __builtin_fmaf(o.x, o.x, o.y * o.y) + __builtin_fmaf(o.z, o.z, o.w * o.w);
     }
+  };
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    stage_begin(8 + j);
+    const unsigned char* buf = lds + (j & 1) * STAGE + lane16;
+    // xr of block j - 1 (requested a stage ago) has landed with the vmcnt(0) of stage_begin: tell the compiler, or its own wait at
+    // the first use would also wait for the LDS-DMA pieces requested since (it does not count them, the hardware does, in order)
+    if (j > 0) asm volatile("" : "+v"(xr[(j - 1) & 1][0]), "+v"(xr[(j - 1) & 1][1]), "+v"(xr[(j - 1) & 1][2]), "+v"(xr[(j - 1) & 1][3]));
+    load_xr(j);                                                  // consumed by epilogue(j), beside the MFMAs of block j + 1
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) A2[j & 1][t2][e] = 0.f;
+    if (j == 0) {
+      // K steps 0 .. 11 first is the natural order: the planes of K steps 12 .. 15 are complete after the first eight steps
+      gemm2(buf, cth, ctl, A2[0],
+            [&](int kk) __attribute__((always_inline)) {
+              issue_piece(9, kk);
+            },
+            [&](int kk, int slot) __attribute__((always_inline)) { if (kk < 8) ctx_piece(DHEADS - 1, 2 * kk + slot); });
+    } else {
+      gemm2(buf, cth, ctl, A2[j & 1],
+            [&](int kk) __attribute__((always_inline)) {
+              if (j + 1 < 8) issue_piece(8 + j + 1, kk);
+            },
+            [&](int kk, int slot) __attribute__((always_inline)) { if ((kk & 3) == 0) epilogue(j - 1, kk >> 2, slot); });
+    }
+    STAMP(11);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("" : "+v"(xr[1][0]), "+v"(xr[1][1]), "+v"(xr[1][2]), "+v"(xr[1][3]));
+#pragma unroll
+  for (int g = 0; g < 4; ++g) { epilogue(7, g, 0); epilogue(7, g, 1); }
+  STAMP(12);
   const float s1 = xor32_sum(ps), s2 = xor32_sum(pss);
   if (p.stats_out && inseq && h == 0) {
     const int slots = DE / p.stats_w;
@@ -471,7 +565,20 @@ __global__ __launch_bounds__(256, 1) void k_dec_chain(DecChainArgs p) {
     for (int k = 0; k < 64; ++k) anykey = anykey || ldf[P_MS + k] == 0.f;
     if (anykey) atomicOr(p.status, 1u);
   }
+#ifdef DCF_DC_STAMP
+  STAMP(13);
+  if (blockIdx.x == 1 && tid == 0)
+    for (int i = 0; i < 16; ++i) dcf_dc_stamps[i] = acc_[i];
+#endif
 }
+
+#ifdef DCF_DC_STAMP
+}  // namespace dcf
+extern "C" int dcf_debug_dc_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(dcf::dcf_dc_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+namespace dcf {
+#endif
 
 bool dec_chain_supports(int E, int heads, int Lk) { return E == DE && heads == DHEADS && Lk >= 1 && Lk <= 64; }
 

@@ -210,6 +210,12 @@ __device__ __forceinline__ void gemm_epilogue_wide_body(const GemmArgs& p, f32x1
         float mean = wg_in[2 * ((wm * TM + i) * 32 + rr + 8 * q)], rstd = wg_in[2 * ((wm * TM + i) * 32 + rr + 8 * q) + 1];
 #if defined(DCF_FOLD_NOP)        // diagnostic builds of tools/micro/pkfma_repro.py (profiles/r04_pkfma_hazard.md): never the product build
         asm volatile("s_nop 7\n\ts_nop 7" : "+v"(mean), "+v"(rstd));
+#elif defined(DCF_FOLD_NOP0)
+        asm volatile("s_nop 0" : "+v"(mean), "+v"(rstd));
+#elif defined(DCF_FOLD_NOP3)
+        asm volatile("s_nop 3" : "+v"(mean), "+v"(rstd));
+#elif defined(DCF_FOLD_EMPTY)
+        asm volatile("" : "+v"(mean), "+v"(rstd));
 #elif defined(DCF_FOLD_MOV)
         { float m2, r2; asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(m2), "=&v"(r2) : "v"(mean), "v"(rstd)); mean = m2; rstd = r2; }
 #endif

@@ -158,6 +158,33 @@ def test_linear_layernorm_carried_as_row_statistics(L, M, N1, K1, N2, res, gelu,
                                                   P(d['W2']), P(d['b2']), P(X), P(Y), 1024, N1, K1, N2, gelu, nterms, st()))
 
 
+@pytest.mark.parametrize('M,N1,K1,N2,res,gelu', [(65600, 256, 256, 1024, 1, 1), (14400, 256, 256, 1024, 0, 1)])
+def test_layernorm_carry_bit_identical_across_repeats(L, M, N1, K1, N2, res, gelu):
+    """Determinism gate of the row-statistics path (dcf_op_linear_ln_carry): 30 repeats on the same inputs, X and Y bit for bit
+    equal to the first run.  With the SLP-vectorised fold (v_pk_fma_f32 ... op_sel:[0,1,0]) every repeat differed in a few
+    thousand elements (tools/micro/pkfma_repro.py, profiles/r04_pkfma_hazard.md)."""
+    pkg, lib = L
+    g = torch.Generator().manual_seed(M + N1 + N2)
+    d = {k: v.cuda() for k, v in dict(A=torch.randn(M, K1, generator=g), W1=torch.randn(N1, K1, generator=g) / math.sqrt(K1),
+                                      b1=torch.randn(N1, generator=g) * 0.3, R=torch.randn(M, N1, generator=g),
+                                      lw=torch.rand(N1, generator=g) + 0.5, lb=torch.randn(N1, generator=g) * 0.5,
+                                      W2=torch.randn(N2, N1, generator=g) / math.sqrt(N1), b2=torch.randn(N2, generator=g) * 0.3).items()}
+    X = torch.empty(M, N1, device='cuda')
+    Y = torch.empty(M, N2, device='cuda')
+    first = None
+    for rep in range(31):
+        X.fill_(float('nan'))
+        Y.fill_(float('nan'))
+        pkg._lib.check(lib.dcf_op_linear_ln_carry(P(d['A']), P(d['W1']), P(d['b1']), P(d['R']) if res else None, P(d['lw']), P(d['lb']),
+                                                  P(d['W2']), P(d['b2']), P(X), P(Y), M, N1, K1, N2, gelu, 16, st()))
+        torch.cuda.synchronize()
+        if first is None:
+            first = (X.clone(), Y.clone())
+            continue
+        assert torch.equal(X.view(torch.int32), first[0].view(torch.int32)), f'repeat {rep}: X differs from the first run'
+        assert torch.equal(Y.view(torch.int32), first[1].view(torch.int32)), f'repeat {rep}: Y differs from the first run'
+
+
 # (B, T, C, NO, scale): both widths, both output counts, sequences shorter and longer than a 104-row tile, ragged masks with
 # holes, several sequences back to back (their ends must not see each other)
 @pytest.mark.parametrize('B,T,C,NO,scale', [(3, 100, 256, 1, 0.0), (2, 333, 288, 2, 1.7), (5, 64, 288, 1, 0.0), (1, 4000, 256, 2, 0.6)])

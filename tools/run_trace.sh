@@ -4,5 +4,5 @@
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/trace_$tag -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-post "$@" > /dev/null 2>&1
-cd $GRAFT_REPO_ROOT && python3 tools/trace_step.py $(ls gpurun_out/trace_$tag/*/*_kernel_trace.csv | head -1) > gpurun_out/step_$tag.txt
+cd $GRAFT_REPO_ROOT && python3 tools/trace_step.py $(ls gpurun_out/trace_$tag/*/*_kernel_trace.csv | head -1) gpurun_out/${tag}_dispatches.json > gpurun_out/step_$tag.txt
 rm -rf gpurun_out/trace_$tag

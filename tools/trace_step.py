@@ -1,5 +1,5 @@
 """Summarise one steady-state forward from a rocprofv3 --kernel-trace CSV: per-dispatch kernel, grid, duration and the
-gap to the previous kernel.  usage: python tools/trace_step.py <kernel_trace.csv> [kernels_per_step]"""
+gap to the previous kernel.  usage: python tools/trace_step.py <kernel_trace.csv> [dispatches.json]"""
 import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
@@ -31,3 +31,10 @@ for r in step:
     prev_end = e
     tot += e - s
 print(f'sum of kernel durations {tot / 1e3:.1f} us')
+if len(sys.argv) > 2:      # <out.json>: the dispatch count keyed on the kernel sources (bench.py reports it as dispatches_per_forward)
+    import json, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    json.dump({'one_video_dispatches': len(step), 'wall_us': (int(step[-1]['End_Timestamp']) - t0) / 1e3, 'csrc_sha16': bench.csrc_hash(),
+               'note': 'kernel dispatches of one steady-state one-video forward (rocprofv3 --kernel-trace of bench.py --videos 1 --batch 1, tools/run_trace.sh)'},
+              open(sys.argv[2], 'w'), indent=1)
