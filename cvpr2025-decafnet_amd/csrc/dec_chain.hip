@@ -19,19 +19,16 @@
 
 #include <type_traits>
 
+#include "chain_common.h"
 #include "common.h"
 
 namespace dcf {
 
 namespace {
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+using namespace chain;
 
 constexpr int DE = 256, DHEADS = 4, DHD = 64;
-constexpr float SA = 16.f, SW = 256.f, UNSCALE = 1.f / 4096.f;     // the f16x3 scaling of gemm_bf16s.hip
 constexpr int STAGE = 65536;                   // bytes per ring buffer (64 pieces of 1 KiB)
 constexpr int WGROWS = 128;
 // LDS behind the ring (floats)
@@ -40,32 +37,6 @@ constexpr int X_LAST = P_END;                  // [5][256]: last[0] = the row be
 constexpr int X_FIRST = X_LAST + 5 * 256;      // [5][256]: first[w] = row 0 of wave w, first[4] = the row behind the window
 constexpr int LDS_FLOATS = X_FIRST + 5 * 256;
 constexpr int LDS_BYTES = 2 * STAGE + LDS_FLOATS * (int)sizeof(float);
-
-__device__ __forceinline__ void split2_f16(float x0, float x1, float s, unsigned& hi, unsigned& lo) {
-  const f16x2 h = __builtin_convertvector(f32x2{x0 * s, x1 * s}, f16x2);
-  hi = __builtin_bit_cast(unsigned, h);
-  const float r0 = __builtin_fmaf(x0, s, -(float)h[0]), r1 = __builtin_fmaf(x1, s, -(float)h[1]);
-  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, f16x2));
-}
-// eight consecutive accumulator slots -> the B operand (hi, lo planes) of one K step
-__device__ __forceinline__ void split8(const float (&v)[8], float s, f16x8& hi, f16x8& lo) {
-  unsigned h4[4], l4[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) split2_f16(v[2 * i], v[2 * i + 1], s, h4[i], l4[i]);
-  hi = __builtin_bit_cast(f16x8, u32x4{h4[0], h4[1], h4[2], h4[3]});
-  lo = __builtin_bit_cast(f16x8, u32x4{l4[0], l4[1], l4[2], l4[3]});
-}
-
-// one 1 KiB LDS-DMA piece (ffn_chain.hip): lane l copies the 16 bytes at sbase + voff to LDS byte lds_dst + 16 l
-__device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(voff), "s"(sbase), "s"(lds_dst)
-               : "memory");
-}
-
-__device__ __forceinline__ f32x16 mma(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 #ifdef DCF_DC_STAMP
 // diagnostic build only (tools/dc_stamp.sh): cycles wave 0 of workgroup 1 spends in the segments of the kernel
@@ -81,31 +52,6 @@ __device__ __forceinline__ unsigned long long dc_stamp() {
 #else
 #define STAMP(i) do { } while (0)
 #endif
-
-// lane i <- lane i - 1 / lane i + 1 of the wave; the lane without a source (0 / 63) takes `edge`
-__device__ __forceinline__ float shr1(float v, float edge) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x138, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float shl1(float v, float edge) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x130, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
-
-// LayerNorm statistics of the lane's row: the lane holds 128 of its 256 channels, the other lane half the rest (blocks.py:125-131:
-// mean, then the mean of squared deviations)
-__device__ __forceinline__ void row_stats(const f32x4 (&v)[32], float& mean, float& rstd) {
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < 32; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-  mean = xor32_sum(s) * (1.0f / DE);
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    const f32x4 d = v[i] - mean;
-    q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
-  }
-  rstd = 1.0f / sqrtf(xor32_sum(q) * (1.0f / DE) + 1e-5f);
-}
 
 }  // namespace
 
@@ -223,7 +169,7 @@ __global__ __launch_bounds__(256, 1) void k_dec_chain(DecChainArgs p) {
     for (int i = 0; i < 32; ++i) xv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   float mean1, rstd1;
-  row_stats(xv, mean1, rstd1);
+  row_stats<DE>(xv, mean1, rstd1);
   STAMP(0);
   __syncthreads();                                               // parameters are in LDS
   // xq = ln_xattn_q(q) * mask, in place
@@ -281,7 +227,7 @@ __global__ __launch_bounds__(256, 1) void k_dec_chain(DecChainArgs p) {
   f16x8 qh[16], ql[16];
   {
     float mean2, rstd2;
-    row_stats(xv, mean2, rstd2);
+    row_stats<DE>(xv, mean2, rstd2);
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
       float v8[8];

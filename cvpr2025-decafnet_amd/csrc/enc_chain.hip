@@ -1,0 +1,341 @@
+// The attention half of an encoder layer on chip, part 1 (enc_chain.h): ln_attn, the three depthwise k3 convolutions, q / k / v_norm
+// and the query / key / value projections of blocks.py:462-470, :348-350 in ONE kernel (k_enc_qkv).
+//
+// The formulation of dec_chain.hip: a lane owns a row -- lane (r = lane & 31, h = lane >> 5) of wave w holds OUTPUT row 32 w + r of
+// the workgroup's 128-row window, 128 of its 256 channels in the MFMA D layout (tile ot, slot e: channel 32 ot + (e & 3) + 8 (e >> 2)
+// + 4 h); LayerNorm is a per-lane sum + one exchange between the lane halves; the depthwise convolution's neighbour rows are the
+// neighbouring lanes (wave_shr:1 / wave_shl:1, the rows at the wave boundaries through LDS, the rows next to the window loaded by
+// waves 0 / 3); the normalised convolution output, split into fp16 planes, IS the B operand of the transposed projection
+// Y^T = W qc^T, whose A fragments stream through a two-buffer LDS ring (chain images, launch_split_chain1).  ln_attn(x) stays in
+// registers for the three branches; per branch: convolution -> LayerNorm -> planes (128 registers) -> four stages of two 32-channel
+// output tiles, the finished tiles stored beside the MFMAs of the next stage.
+// Stride 2 (levels >= 1): output row i reads input rows 2 i - 1, 2 i, 2 i + 1: the lane holds the even row 2 i and the odd row
+// 2 i + 1, the third tap is the previous lane's odd row; the masked max-pool of the same three rows (the layer's skip path,
+// blocks.py:31-47, :583) leaves in the same pass.
+#include "enc_chain.h"
+
+#include <type_traits>
+
+#include "chain_common.h"
+#include "common.h"
+
+namespace dcf {
+
+namespace {
+
+using namespace chain;
+
+constexpr int EE = 256;
+constexpr int STAGE = 65536;                   // bytes per ring buffer (64 pieces of 1 KiB)
+constexpr int WGROWS = 128;
+// LDS behind the ring (floats)
+constexpr int P_LNW = 0, P_LNB = 256, P_DW = 512, P_FS = 2816, P_FC = 3584, P_END = 4352;      // (P_FS / P_FC: the folded LayerNorm's s[n], c[n] of q, k, v)
+constexpr int X_LAST = P_END;                  // [5][256] normalised rows: [0] the row before the window, [w + 1] the last (odd) row of wave w
+constexpr int X_OTHER = X_LAST + 5 * 256;      // [5][256] stride 1: [w] row 0 of wave w, [4] the row behind the window; stride 2: RAW odd rows as X_LAST
+constexpr int X_FLAG = X_OTHER + 5 * 256;      // [8] stride 2: validity of the raw rows of X_OTHER
+constexpr int LDS_FLOATS = X_FLAG + 8;
+constexpr int LDS_BYTES = 2 * STAGE + LDS_FLOATS * (int)sizeof(float);
+
+}  // namespace
+
+template <int S>
+__global__ __launch_bounds__(256, 1) void k_enc_qkv(EncQkvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  float* ldf = reinterpret_cast<float*>(lds + 2 * STAGE);
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  // Every per-lane LDS access below is base + 16 h + CONSTANT: the bases are made opaque so that the constants become the
+  // instructions' immediate offsets (left to itself the compiler keeps one address register per constant alive across the three
+  // branches -- 100+ registers and 1 KB of scratch per lane)
+  // (the OFFSETS are opaque, not the pointers: a laundered pointer loses its LDS address space and every access becomes a flat one)
+  unsigned o_lh = 4u * (unsigned)h, o_last = (unsigned)(X_LAST + w * 256 + 4 * h), o_oth = (unsigned)(X_OTHER + w * 256 + 4 * h);
+  asm volatile("" : "+v"(o_lh), "+v"(o_last), "+v"(o_oth));
+  float* lh = ldf + o_lh;                                        // parameters
+  float* lh_last = ldf + o_last;                                 // [0] the row before this wave's first (normalised), [256] this wave's last
+  float* lh_oth = ldf + o_oth;                                   // stride 2: the same, raw; stride 1: [0] this wave's first row, [256] the row behind its last
+  const int To = p.T_in / S;
+  const int wins = (To + WGROWS - 1) / WGROWS;                  // windows per sequence
+  const int b = (int)blockIdx.x / wins, t0 = ((int)blockIdx.x - b * wins) * WGROWS;
+  const int t = t0 + w * 32 + r;                                 // this lane's OUTPUT position in sequence b
+  const bool inseq = t < To;
+  const int tc = inseq ? t : To - 1;
+  const int64_t ibase = (int64_t)b * p.T_in, orow = (int64_t)b * To + tc;
+
+  // ---- the weight stream: per branch four stages (output tiles 2 pair, 2 pair + 1), buffer = pair & 1
+  auto issue_piece = [&](const unsigned short* Wimg, int pair, int i) __attribute__((always_inline)) {     // piece w + 4 i of a stage
+    const int pc = w + 4 * i;
+    glds16(Wimg + (size_t)pair * 64 * 512 + (size_t)pc * 512, lane16, (unsigned)(pair & 1) * STAGE + (unsigned)pc * 1024u);
+  };
+
+  // ---- the lane's input row(s): 128 channels in D layout, v[4 ot + g] = channels 32 ot + 8 g + 4 h .. + 3
+  const int te = S * tc;                                          // even / only input row
+  const bool valid_e = inseq && p.mask_in[ibase + te] != 0;
+  const bool valid_o = S == 2 && inseq && p.mask_in[ibase + te + (S == 2 ? 1 : 0)] != 0;
+  f32x4 xe[32], xo[S == 2 ? 32 : 1];
+  {
+    const float* px = p.X + (ibase + te) * p.ldx + 4 * h;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) xe[i] = *reinterpret_cast<const f32x4*>(px + 32 * (i >> 2) + 8 * (i & 3));
+    if constexpr (S == 2) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) xo[i] = *reinterpret_cast<const f32x4*>(px + p.ldx + 32 * (i >> 2) + 8 * (i & 3));
+    }
+  }
+  // the rows next to the window: input row S t0 - 1 (wave 0) and, stride 1, row t0 + 128 (wave 3); lane l takes channels 4 l .. 4 l + 3
+  const bool edge_wave = w == 0 || (S == 1 && w == 3);
+  const int tedge = w == 0 ? S * t0 - 1 : t0 + WGROWS;
+  const bool evalid = edge_wave && tedge >= 0 && tedge < p.T_in && p.mask_in[ibase + (tedge >= 0 && tedge < p.T_in ? tedge : 0)] != 0;
+  f32x4 ev = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (evalid) ev = *reinterpret_cast<const f32x4*>(p.X + (ibase + tedge) * p.ldx + 4 * lane);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) issue_piece(p.W[0], 0, i);
+
+  // ---- per-channel parameters -> LDS
+  {
+    ldf[P_LNW + tid] = p.ln_w[tid]; ldf[P_LNB + tid] = p.ln_b[tid];
+#pragma unroll
+    for (int op = 0; op < 3; ++op) {
+      ldf[P_DW + op * 768 + tid] = p.dw[op][tid]; ldf[P_DW + op * 768 + 256 + tid] = p.dw[op][256 + tid]; ldf[P_DW + op * 768 + 512 + tid] = p.dw[op][512 + tid];
+      ldf[P_FS + op * 256 + tid] = p.fs[op][tid]; ldf[P_FC + op * 256 + tid] = p.fc[op][tid];
+    }
+  }
+  if (!valid_e) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) xe[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if constexpr (S == 2) {
+    if (!valid_o) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) xo[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // the masked max-pool needs the RAW odd row of the previous output position: wave boundaries and the window's left edge via LDS
+    if (r == 31) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) *reinterpret_cast<f32x4*>(lh_oth + 256 + 32 * (i >> 2) + 8 * (i & 3)) = xo[i];
+      if (h == 0) ldf[X_FLAG + w + 1] = valid_o ? 1.f : 0.f;
+    }
+    if (w == 0) {
+      *reinterpret_cast<f32x4*>(ldf + X_OTHER + 4 * lane) = ev;
+      if (lane == 0) ldf[X_FLAG] = evalid ? 1.f : 0.f;
+    }
+  }
+  const bool is32 = lane == 32, is31 = lane == 31;
+  __syncthreads();                                               // parameters (and the raw boundary rows) are in LDS
+  if constexpr (S == 2) {
+    // skip = max over the valid rows of {2 i - 1, 2 i, 2 i + 1}, 0 where row 2 i itself is padded (blocks.py:31-47 as the layer uses
+    // it: the global-minimum filler never wins a window that holds a valid element, rowops.hip k_enc_pre)
+    const float pflag = ldf[X_FLAG + w];
+    float vprev = shr1(valid_o ? 1.f : 0.f, pflag);
+    vprev = is32 ? pflag : vprev;                                // (r = 0 of the upper lane half: the previous wave's row as well)
+    const bool vp = vprev != 0.f;
+    float* ps = p.Skip + orow * EE + 4 * h;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int c = 32 * (i >> 2) + 8 * (i & 3);
+      const f32x4 lastv = *reinterpret_cast<const f32x4*>(lh_oth + c);
+      f32x4 m = xe[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float sp = shr1(xo[i][e], lastv[e]);
+        const float pv = is32 ? lastv[e] : sp;
+        if (vp) m[e] = fmaxf(m[e], pv);
+        if (valid_o) m[e] = fmaxf(m[e], xo[i][e]);
+      }
+      if (!valid_e) m = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (inseq) *reinterpret_cast<f32x4*>(ps + 32 * (i >> 2) + 8 * (i & 3)) = m;
+    }
+  }
+  // ---- xn = ln_attn(x) * mask, in place
+  auto ln_inplace = [&](f32x4 (&v)[32], bool valid) __attribute__((always_inline)) {
+    float mean, rstd;
+    row_stats<EE>(v, mean, rstd);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int c = 32 * (i >> 2) + 8 * (i & 3);
+      const f32x4 g = *reinterpret_cast<const f32x4*>(lh + P_LNW + c), bb = *reinterpret_cast<const f32x4*>(lh + P_LNB + c);
+      f32x4 y = (v[i] - mean) * rstd * g + bb;
+      if (!valid) y = f32x4{0.f, 0.f, 0.f, 0.f};
+      v[i] = y;
+    }
+  };
+  ln_inplace(xe, valid_e);
+  if constexpr (S == 2) ln_inplace(xo, valid_o);
+  // boundary rows of the wave -> LDS; the window's outer neighbours from waves 0 / 3
+  {
+    if (r == 31) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        f32x4 v;
+        if constexpr (S == 2) v = xo[i]; else v = xe[i];
+        *reinterpret_cast<f32x4*>(lh_last + 256 + 32 * (i >> 2) + 8 * (i & 3)) = v;
+      }
+    }
+    if constexpr (S == 1) {
+      if (r == 0) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) *reinterpret_cast<f32x4*>(lh_oth + 32 * (i >> 2) + 8 * (i & 3)) = xe[i];
+      }
+    }
+    if (edge_wave) {
+      f32x4 y = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float s = wave_sum((ev.x + ev.y) + (ev.z + ev.w));
+      const float mean = s * (1.0f / EE);
+      const f32x4 d = ev - mean;
+      const float var = wave_sum((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * (1.0f / EE);
+      const float rs = 1.0f / sqrtf(var + 1e-5f);
+      if (evalid) y = d * rs * *reinterpret_cast<const f32x4*>(ldf + P_LNW + 4 * lane) + *reinterpret_cast<const f32x4*>(ldf + P_LNB + 4 * lane);
+      *reinterpret_cast<f32x4*>(ldf + (w == 0 ? X_LAST : X_OTHER + 4 * 256) + 4 * lane) = y;
+    }
+  }
+  __syncthreads();
+  // ---- the three branches
+  auto stage_begin = [&](int s) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's pieces of stage s have landed ...
+    __syncthreads();                                             // ... everybody's have, and nobody reads the other buffer any more
+  };
+  // (dec_chain.hip: two 32-row output tiles over 16 K steps, fragments one step ahead, vector work between the MFMAs)
+  auto gemm2 = [&](const unsigned char* buf, const f16x8 (&bh)[16], const f16x8 (&bl)[16], f32x16 (&acc)[2], auto&& dma, auto&& side)
+                   __attribute__((always_inline)) {
+    f16x8 fr[2][4];
+    auto frags = [&](int kk, int set) __attribute__((always_inline)) {
+      fr[set][0] = *reinterpret_cast<const f16x8*>(buf + ((0 * 16 + kk) * 2) * 1024);
+      fr[set][1] = *reinterpret_cast<const f16x8*>(buf + ((0 * 16 + kk) * 2 + 1) * 1024);
+      fr[set][2] = *reinterpret_cast<const f16x8*>(buf + ((1 * 16 + kk) * 2) * 1024);
+      fr[set][3] = *reinterpret_cast<const f16x8*>(buf + ((1 * 16 + kk) * 2 + 1) * 1024);
+    };
+    frags(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const int set = kk & 1;
+      if (kk + 1 < 16) frags(kk + 1, set ^ 1);
+      acc[0] = mma(fr[set][1], bh[kk], acc[0]);
+      acc[1] = mma(fr[set][3], bh[kk], acc[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      side(kk, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0] = mma(fr[set][0], bl[kk], acc[0]);
+      acc[1] = mma(fr[set][2], bl[kk], acc[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      side(kk, 1);
+      dma(kk);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0] = mma(fr[set][0], bh[kk], acc[0]);
+      acc[1] = mma(fr[set][2], bh[kk], acc[1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  f32x16 A2[2][2];                                               // [stage parity][tile of the pair]
+  float chk = 0.f;
+  // (a rolled loop over the branches: unrolled, the three copies of everything below cost registers and spilled)
+#pragma unroll 1
+  for (int op = 0; op < 3; ++op) {
+    const unsigned short* Wimg = op == 0 ? p.W[0] : (op == 1 ? p.W[1] : p.W[2]);
+    const unsigned short* Wnext = op == 0 ? p.W[1] : p.W[2];
+    float* outp = (op == 0 ? p.out[0] : (op == 1 ? p.out[1] : p.out[2])) + orow * EE + 4 * h;
+    const int pdw = P_DW + op * 768, pfs = P_FS + op * 256, pfc = P_FC + op * 256;
+    // depthwise k3 convolution along the rows (MaskedConv1D: the inputs are masked already), split into the B operand's planes as
+    // it is produced; the branch's LayerNorm (q / k / v_norm) is folded into the projection -- W' = W diag(g) in the weight image,
+    // (mean, rstd) of the raw convolution output applied in the epilogue -- so the normalised rows never exist and the convolution
+    // output needs no registers of its own (one-pass variance, as the row statistics the GEMMs carry: gemm_common.h stats_load)
+    f16x8 ph[16], pl[16];
+    float fmean, frstd;
+    {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        float v8[8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int i = 2 * kk + u, c = 32 * (i >> 2) + 8 * (i & 3);
+          const f32x4 lastv = *reinterpret_cast<const f32x4*>(lh_last + c);
+          const f32x4 w0 = *reinterpret_cast<const f32x4*>(lh + pdw + c), w1 = *reinterpret_cast<const f32x4*>(lh + pdw + 256 + c),
+                      w2 = *reinterpret_cast<const f32x4*>(lh + pdw + 512 + c);
+          f32x4 pv, nv, y;
+          if constexpr (S == 1) {
+            const f32x4 firstv = *reinterpret_cast<const f32x4*>(lh_oth + 256 + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {                          // (the lane shifts with every lane active)
+              const float sp = shr1(xe[i][e], lastv[e]), sn = shl1(xe[i][e], firstv[e]);
+              pv[e] = is32 ? lastv[e] : sp;
+              nv[e] = is31 ? firstv[e] : sn;
+            }
+            y = w0 * pv + w1 * xe[i] + w2 * nv;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float sp = shr1(xo[i][e], lastv[e]);
+              pv[e] = is32 ? lastv[e] : sp;
+            }
+            y = w0 * pv + w1 * xe[i] + w2 * xo[i];
+          }
+          s1 += (y.x + y.y) + (y.z + y.w);
+          s2 += __builtin_fmaf(y.x, y.x, y.y * y.y) + __builtin_fmaf(y.z, y.z, y.w * y.w);
+          v8[4 * u] = y.x; v8[4 * u + 1] = y.y; v8[4 * u + 2] = y.z; v8[4 * u + 3] = y.w;
+        }
+        split8(v8, SA, ph[kk], pl[kk]);
+      }
+      const float mean = xor32_sum(s1) * (1.0f / EE);
+      const float var = fmaxf(__builtin_fmaf(-mean, mean, xor32_sum(s2) * (1.0f / EE)), 0.f);
+      fmean = mean;
+      frstd = 1.0f / sqrtf(var + 1e-5f);
+    }
+    // output tile t2 of pair `pr`, group g: the folded LayerNorm rstd (acc - mean s[n]) + c[n] (GemmArgs::stats_in), store
+    auto epilogue = [&](int pr, int t2, int g) __attribute__((always_inline)) {
+      const int tile = 2 * pr + t2;
+      const f32x4 fs = *reinterpret_cast<const f32x4*>(lh + pfs + 32 * tile + 8 * g);
+      const f32x4 fc = *reinterpret_cast<const f32x4*>(lh + pfc + 32 * tile + 8 * g);
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(__builtin_fmaf(-fmean, fs[e], A2[pr & 1][t2][4 * g + e] * UNSCALE), frstd, fc[e]);
+      if (inseq) *reinterpret_cast<f32x4*>(outp + 32 * tile + 8 * g) = v;
+      chk += (v.x + v.y) + (v.z + v.w);
+    };
+#pragma unroll
+    for (int pair = 0; pair < 4; ++pair) {
+      stage_begin(0);
+      const unsigned char* buf = lds + (pair & 1) * STAGE + lane16;
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) A2[pair & 1][t2][e] = 0.f;
+      gemm2(buf, ph, pl, A2[pair & 1],
+            [&](int kk) __attribute__((always_inline)) {           // the next stage: this branch's next pair, or the next branch's first
+              if (pair < 3) issue_piece(Wimg, pair + 1, kk);
+              else if (op < 2) issue_piece(Wnext, 0, kk);
+            },
+            [&](int kk, int slot) __attribute__((always_inline)) { if (pair > 0 && slot == 0 && (kk & 1) == 0) epilogue(pair - 1, kk >> 3, (kk >> 1) & 3); });
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) epilogue(3, u >> 2, u & 3);
+  }
+  // a non-finite accumulator anywhere (an operand left the fp16 range) makes the row's checksum non-finite
+  if (inseq && !(__builtin_fabsf(chk) <= 3.4028234664e38f) && p.status) atomicOr(p.status, 1u);
+}
+
+bool enc_chain_supports(int E, int heads, int win, int stride) { return E == EE && heads == 4 && win >= 1 && win <= 9 && (stride == 1 || stride == 2); }
+
+int launch_enc_qkv(const EncQkvArgs& a, hipStream_t stream) {
+  DCF_CHECK(a.B > 0 && a.T_in > 0 && (a.stride == 1 || a.stride == 2) && a.T_in % a.stride == 0 && a.X && a.mask_in && a.ln_w && a.ln_b,
+            "launch_enc_qkv: bad arguments");
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  for (int op = 0; op < 3; ++op)
+    DCF_CHECK(a.dw[op] && a.fs[op] && a.fc[op] && a.W[op] && a.out[op] && al16(a.W[op]) && al16(a.out[op]), "launch_enc_qkv: null or misaligned argument");
+  DCF_CHECK(al16(a.X) && a.ldx % 4 == 0 && (a.stride == 1 || (a.Skip && al16(a.Skip))), "launch_enc_qkv: X / Skip must be 16-byte aligned (stride 2 needs Skip)");
+  static bool attr_set[64] = {};                         // per device: the attribute belongs to the device's copy of the kernel
+  int dev = 0;
+  DCF_HIP(hipGetDevice(&dev));
+  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+    DCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_enc_qkv<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    DCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_enc_qkv<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    attr_set[dev] = true;
+  }
+  const int To = a.T_in / a.stride;
+  const unsigned grid = (unsigned)(a.B * ((To + WGROWS - 1) / WGROWS));
+  if (a.stride == 1) hipLaunchKernelGGL(k_enc_qkv<1>, dim3(grid), dim3(256), LDS_BYTES, stream, a);
+  else hipLaunchKernelGGL(k_enc_qkv<2>, dim3(grid), dim3(256), LDS_BYTES, stream, a);
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace dcf

@@ -25,6 +25,7 @@
 #include "attn.h"
 #include "common.h"
 #include "dec_chain.h"
+#include "enc_chain.h"
 #include "ffn_chain.h"
 #include "gemm.h"
 #include "head_chain.h"
@@ -167,6 +168,9 @@ struct EncW {   // one TransformerEncoder of vid_net
   const float *wq, *bq, *wk, *bk, *wv, *bv, *wp, *bp, *ls_attn;
   const float *ln_ffn_w, *ln_ffn_b, *fc_w, *fc_b, *pj_w, *pj_b, *ls_ffn;
   const float *fc_wf, *fc_s, *fc_c;          // ffn.fc with ln_ffn folded in (k_fold_ln); nullptr where not built
+  // enc_chain.hip: query / key / value with q / k / v_norm folded in, as chain images + the fold's s[n], c[n]; nullptr where not built
+  const unsigned short* qkv_chain[3];
+  const float *qkv_s[3], *qkv_c[3];
 };
 struct DecW {   // one TransformerDecoder of the fusion
   const float *ln_q_w, *ln_q_b, *ln_kv_w, *ln_kv_b, *dw, *qn_w, *qn_b;
@@ -374,6 +378,22 @@ static int resolve_encoder(dcf_model* m, const std::string& p, int E, hipStream_
   SPLIT(w.fc_w, 4 * E, E); SPLIT(w.pj_w, E, 4 * E);
   w.fc_wf = w.fc_s = w.fc_c = nullptr;
   if (m->gemm_terms != 0 && E % 64 == 0 && fold_ln(m, w.fc_w, w.fc_b, w.ln_ffn_w, w.ln_ffn_b, 4 * E, E, st, &w.fc_wf, &w.fc_s, &w.fc_c)) return -1;
+  for (int i = 0; i < 3; ++i) { w.qkv_chain[i] = nullptr; w.qkv_s[i] = w.qkv_c[i] = nullptr; }
+  if (m->gemm_terms == GEMM_F16X3 && enc_chain_supports(E, m->cfg.vid_heads, m->cfg.win > 0 ? m->cfg.win : 99, 1)) {
+    const float* W3[3] = {w.wq, w.wk, w.wv};
+    const float* B3[3] = {w.bq, w.bk, w.bv};
+    const float* G3[3] = {w.qn_w, w.kn_w, w.vn_w};
+    const float* H3[3] = {w.qn_b, w.kn_b, w.vn_b};
+    for (int i = 0; i < 3; ++i) {
+      const float* wf;
+      if (fold_ln(m, W3[i], B3[i], G3[i], H3[i], E, E, st, &wf, &w.qkv_s[i], &w.qkv_c[i])) return -1;
+      unsigned short* img = nullptr;
+      DCF_HIP(hipMalloc(&img, chain1_image_halfs(E, E) * sizeof(unsigned short)));
+      m->owned.push_back(reinterpret_cast<float*>(img));
+      if (launch_split_chain1(wf, img, E, E, st, m->status ? m->status + 1 : nullptr)) return -1;     // (the gain widens the weight's range)
+      w.qkv_chain[i] = img;
+    }
+  }
   return 0;
 }
 
@@ -847,11 +867,35 @@ static void norm_a(GemmArgs& g, const float* stats, int C, int stats_w, const fl
   g.a_stats = stats; g.a_stats_slots = C / stats_w; g.a_ln_g = ln_g; g.a_ln_b = ln_b;
 }
 
+// From 32 768 rows on, f16x3, E = 256, 4 heads, window <= 9, stride 1: ln_attn, the depthwise convolutions, q / k / v_norm and the three
+// projections of an encoder layer as ONE kernel (enc_chain.hip k_enc_qkv) instead of k_enc_pre + the grouped GEMM.
+static int enc_chain_min_rows() {
+  const int o = debug_option("enc_chain_min_rows", -1);            // dcf_debug_set_option (tests), then the developer switch
+  if (o >= 0) return o;
+  static const int v = getenv("DCF_ENC_CHAIN_MIN_ROWS") ? atoi(getenv("DCF_ENC_CHAIN_MIN_ROWS")) : 32768;
+  return v;
+}
+static bool can_chain_enc(dcf_model* m, const EncW& w, int rows, int stride, int64_t ldx) {
+  static const bool off = getenv("DCF_NO_ENC_CHAIN") != nullptr;    // developer switch: the separate launches
+  const dcf_config& c = m->cfg;
+  return !off && m->gemm_terms == GEMM_F16X3 && w.qkv_chain[0] && w.qkv_chain[1] && w.qkv_chain[2] && stride == 1 &&
+         enc_chain_supports(c.E, c.vid_heads, c.win > 0 ? c.win : 99, stride) && rows >= enc_chain_min_rows() && ldx % 4 == 0;
+}
+
 // TransformerEncoder (vid_net) at one level.  Xin: [B*T_in][ldx]; output rows [B*T_out] at Xout (ld ldo).
 static int run_encoder(dcf_model* m, const EncW& w, Buffers& b, const float* Xin, int64_t ldx, const uint8_t* mask_in,
                        const uint8_t* mask_out, int B, int T_in, int stride, float* Xout, int64_t ldo, hipStream_t st) {
   const dcf_config& c = m->cfg;
   const int E = c.E, To = T_in / stride, rows = B * To;
+  if (can_chain_enc(m, w, rows, stride, ldx)) {
+    EncQkvArgs ea{};
+    ea.X = Xin; ea.ldx = ldx; ea.mask_in = mask_in; ea.ln_w = w.ln_attn_w; ea.ln_b = w.ln_attn_b;
+    ea.dw[0] = w.dw_q; ea.dw[1] = w.dw_k; ea.dw[2] = w.dw_v;
+    for (int i = 0; i < 3; ++i) { ea.W[i] = w.qkv_chain[i]; ea.fs[i] = w.qkv_s[i]; ea.fc[i] = w.qkv_c[i]; ea.out[i] = b.R[4 + i]; }
+    ea.Skip = stride == 2 ? b.R[3] : nullptr; ea.B = B; ea.T_in = T_in; ea.stride = stride; ea.status = m->status;
+    ProfScope prof("gemm_f16x3<enc_qkv>", st, 2.0 * rows * E * 3.0 * E, (double)rows * E * 4.0 * 4.0);
+    TRY(launch_enc_qkv(ea, st));
+  } else {
   EncPreArgs ep{};
   ep.X = Xin; ep.ldx = ldx; ep.mask_in = mask_in; ep.ln_w = w.ln_attn_w; ep.ln_b = w.ln_attn_b;
   ep.dw_q = w.dw_q; ep.dw_k = w.dw_k; ep.dw_v = w.dw_v;
@@ -862,6 +906,7 @@ static int run_encoder(dcf_model* m, const EncW& w, Buffers& b, const float* Xin
   GemmArgs g3[3] = {gemm(b.R[0], E, w.wq, w.bq, b.R[4], E, rows, E, E), gemm(b.R[1], E, w.wk, w.bk, b.R[5], E, rows, E, E),
                     gemm(b.R[2], E, w.wv, w.bv, b.R[6], E, rows, E, E)};
   TRY(run_gemm(m, g3, 3, A_ROWS, st));
+  }
   if (c.win > 0) {
     LocalAttnArgs la{b.R[4], b.R[5], b.R[6], mask_out, b.R[0], B, To, E, c.vid_heads, c.win};
     TRY(launch_local_attn(la, st));

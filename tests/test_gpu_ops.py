@@ -627,6 +627,76 @@ def test_decoder_block_golden_probe_width(L, chain_rows):
     torch.testing.assert_close(got, o.t('dec/y'), rtol=2e-5, atol=2e-5)
 
 
+def _run_encoder(pkg, lib, sd, x, mask, stride, chain_rows, win=9):
+    """dcf_op_encoder on a scratch model; chain_rows = the enc_chain_min_rows option (0: the one-kernel q / k / v front half)"""
+    bs, E, T = x.shape
+    pkg._lib.check(lib.dcf_debug_set_option(b'enc_chain_min_rows', chain_rows))
+    try:
+        h = scratch_model(pkg, lib, sd, 'e', E=E, win=win, vid_heads=4, gemm_mode=16)
+        To = T // stride
+        Y = torch.empty(bs * To, E, device='cuda')
+        mo = torch.empty(bs * To, dtype=torch.bool, device='cuda')
+        pkg._lib.check(lib.dcf_op_encoder(h, b'e', P(tok(x)), P(mask.reshape(-1).contiguous().cuda()), bs, T, stride, P(Y), P(mo), st()),
+                       'dcf_op_encoder')
+        y = untok(Y, bs, To)
+        lib.dcf_model_destroy(h)
+        return y, mo.cpu().view(bs, 1, To)
+    finally:
+        pkg._lib.check(lib.dcf_debug_set_option(b'enc_chain_min_rows', -1))
+
+
+@pytest.mark.parametrize('chain_rows', [0, 1 << 30])
+@pytest.mark.parametrize('stride', [1, 2])
+def test_encoder_block_golden_probe_width(L, stride, chain_rows):
+    """TransformerEncoder.forward (blocks.py:578-591) at E = 256, four heads, window 9, stride 1 / 2: reference fixture ops256.npz
+    through dcf_op_encoder, with the q / k / v front half as one kernel (enc_chain.hip) and as the separate launches"""
+    pkg, lib = L
+    o = Golden('ops256.npz')
+    sd = _ops256_weights(pkg, o, f'enc_s{stride}')
+    got, gm = _run_encoder(pkg, lib, sd, o.t('x'), o.t('mask'), stride, chain_rows)
+    assert torch.equal(gm, o.t(f'enc_s{stride}/ymask'))
+    torch.testing.assert_close(got, o.t(f'enc_s{stride}/y'), rtol=2e-5, atol=2e-5)
+
+
+def _enc_shapes(E):
+    sh = {'ln_attn.weight': (E, 1), 'ln_attn.bias': (E, 1), 'ln_ffn.weight': (E, 1), 'ln_ffn.bias': (E, 1),
+          'drop_path_attn.scale': (1, E, 1), 'drop_path_ffn.scale': (1, E, 1),
+          'ffn.fc.weight': (4 * E, E, 1), 'ffn.fc.bias': (4 * E,), 'ffn.proj.weight': (E, 4 * E, 1), 'ffn.proj.bias': (E,)}
+    for n in 'qkv':
+        sh[f'attn.{n}_conv.conv.weight'] = (E, 1, 3)
+        sh[f'attn.{n}_norm.weight'] = (E, 1)
+        sh[f'attn.{n}_norm.bias'] = (E, 1)
+    for n in ('query', 'key', 'value', 'proj'):
+        sh[f'attn.attn.{n}.weight'] = (E, E, 1)
+        sh[f'attn.attn.{n}.bias'] = (E,)
+    return sh
+
+
+# (bs, T, stride): windows with a partial tail, sequences with a padded tail, a hole across a 128-row window boundary
+@pytest.mark.parametrize('bs,T,stride', [(2, 200, 1), (3, 128, 1), (1, 452, 1), (2, 2560, 1)])
+def test_enc_chain_vs_fp64(L, bs, T, stride):
+    """the q / k / v front half of an encoder layer as one kernel (csrc/enc_chain.hip) inside dcf_op_encoder: TransformerEncoder.forward
+    (blocks.py:578-591) at E = 256 against the oracle run in fp64, and against the launches the kernel replaces"""
+    pkg, lib = L
+    E = 256
+    sd = pkg.synth.make_state_dict(_enc_shapes(E), 5000 + T)
+    g = torch.Generator().manual_seed(bs * 77 + T)
+    x = torch.randn(bs, E, T, generator=g) * 1.5 + 0.3
+    mask = torch.ones(bs, 1, T, dtype=torch.bool)
+    for b in range(bs):
+        n = int(torch.randint(T // 2, T + 1, (1,), generator=g)) if b else T
+        mask[b, :, n:] = False
+        if T > 140:
+            mask[b, :, 127:129] = False
+    sdd = {'e.' + k: v.double() for k, v in sd.items()}
+    want, wm = R.transformer_encoder(sdd, 'e', x.double(), mask, stride, 4, 9)
+    got, gm = _run_encoder(pkg, lib, sd, x, mask, stride, 0)
+    old, om = _run_encoder(pkg, lib, sd, x, mask, stride, 1 << 30)
+    assert torch.equal(gm, wm) and torch.equal(om, wm)
+    torch.testing.assert_close(old.double(), want, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(got.double(), want, rtol=2e-5, atol=2e-5)
+
+
 def test_tcn_golden(L):
     """TCN.forward (tcn.py:66-84), 4 dilated residual layers: reference fixture tcn/y"""
     pkg, lib = L
