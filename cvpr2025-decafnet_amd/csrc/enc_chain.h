@@ -32,4 +32,21 @@ struct EncQkvArgs {
 bool enc_chain_supports(int E, int heads, int win, int stride);
 int launch_enc_qkv(const EncQkvArgs& a, hipStream_t stream);
 
+struct EncAttnArgs {
+  const float* Q; const float* K; const float* V;    // [B*T][256] projected rows
+  const uint8_t* mask;          // [B*T] row validity at this level
+  const unsigned short* Wp;     // chain image of attn.attn.proj.weight (256 x 256), launch_split_chain1
+  const float* bp;              // [256]
+  const float* ls;              // [256] drop_path_attn.scale (LayerScale)
+  const float* R;               // [B*T][ldr] skip rows: the layer's input (stride 1) or its masked max-pool (stride 2)
+  int64_t ldr;
+  float* Y;                     // [B*T][ldy] out: x' = R * mask + ls * (proj(ctx) + bp)       (blocks.py:586)
+  int64_t ldy;
+  float* stats_out;             // optional [B*T][256 / stats_w] float2 (sum, sum of squares) of the Y rows (slot 0 carries the row)
+  int stats_w;
+  int B, T, win;                // window size (odd, <= 9)
+  unsigned* status;
+};
+int launch_enc_attn(const EncAttnArgs& a, hipStream_t stream);
+
 }  // namespace dcf

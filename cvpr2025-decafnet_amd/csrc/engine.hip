@@ -171,6 +171,7 @@ struct EncW {   // one TransformerEncoder of vid_net
   // enc_chain.hip: query / key / value with q / k / v_norm folded in, as chain images + the fold's s[n], c[n]; nullptr where not built
   const unsigned short* qkv_chain[3];
   const float *qkv_s[3], *qkv_c[3];
+  const unsigned short* wp_chain;            // chain image of attn.proj (enc_chain.hip k_enc_attn) or nullptr
 };
 struct DecW {   // one TransformerDecoder of the fusion
   const float *ln_q_w, *ln_q_b, *ln_kv_w, *ln_kv_b, *dw, *qn_w, *qn_b;
@@ -379,7 +380,15 @@ static int resolve_encoder(dcf_model* m, const std::string& p, int E, hipStream_
   w.fc_wf = w.fc_s = w.fc_c = nullptr;
   if (m->gemm_terms != 0 && E % 64 == 0 && fold_ln(m, w.fc_w, w.fc_b, w.ln_ffn_w, w.ln_ffn_b, 4 * E, E, st, &w.fc_wf, &w.fc_s, &w.fc_c)) return -1;
   for (int i = 0; i < 3; ++i) { w.qkv_chain[i] = nullptr; w.qkv_s[i] = w.qkv_c[i] = nullptr; }
+  w.wp_chain = nullptr;
   if (m->gemm_terms == GEMM_F16X3 && enc_chain_supports(E, m->cfg.vid_heads, m->cfg.win > 0 ? m->cfg.win : 99, 1)) {
+    {
+      unsigned short* img = nullptr;
+      DCF_HIP(hipMalloc(&img, chain1_image_halfs(E, E) * sizeof(unsigned short)));
+      m->owned.push_back(reinterpret_cast<float*>(img));
+      if (launch_split_chain1(w.wp, img, E, E, st, nullptr)) return -1;          // (range: the same weights passed split_weight above)
+      w.wp_chain = img;
+    }
     const float* W3[3] = {w.wq, w.wk, w.wv};
     const float* B3[3] = {w.bq, w.bk, w.bv};
     const float* G3[3] = {w.qn_w, w.kn_w, w.vn_w};
@@ -882,6 +891,19 @@ static bool can_chain_enc(dcf_model* m, const EncW& w, int rows, int stride, int
          enc_chain_supports(c.E, c.vid_heads, c.win > 0 ? c.win : 99, stride) && rows >= enc_chain_min_rows() && ldx % 4 == 0;
 }
 
+static int enc_attn_min_rows() {
+  const int o = debug_option("enc_attn_min_rows", -1);
+  if (o >= 0) return o;
+  static const int v = getenv("DCF_ENC_ATTN_MIN_ROWS") ? atoi(getenv("DCF_ENC_ATTN_MIN_ROWS")) : 32768;
+  return v;
+}
+static bool can_chain_enc_attn(dcf_model* m, const EncW& w, int rows, int64_t ldr) {
+  static const bool off = getenv("DCF_NO_ENC_ATTN") != nullptr;     // developer switch: k_local_attn + the projection GEMM
+  const dcf_config& c = m->cfg;
+  return !off && m->gemm_terms == GEMM_F16X3 && w.wp_chain && c.win > 0 && (c.win & 1) && enc_chain_supports(c.E, c.vid_heads, c.win, 1) &&
+         rows >= enc_attn_min_rows() && ldr % 4 == 0;
+}
+
 // TransformerEncoder (vid_net) at one level.  Xin: [B*T_in][ldx]; output rows [B*T_out] at Xout (ld ldo).
 static int run_encoder(dcf_model* m, const EncW& w, Buffers& b, const float* Xin, int64_t ldx, const uint8_t* mask_in,
                        const uint8_t* mask_out, int B, int T_in, int stride, float* Xout, int64_t ldo, hipStream_t st) {
@@ -906,6 +928,25 @@ static int run_encoder(dcf_model* m, const EncW& w, Buffers& b, const float* Xin
   GemmArgs g3[3] = {gemm(b.R[0], E, w.wq, w.bq, b.R[4], E, rows, E, E), gemm(b.R[1], E, w.wk, w.bk, b.R[5], E, rows, E, E),
                     gemm(b.R[2], E, w.wv, w.bv, b.R[6], E, rows, E, E)};
   TRY(run_gemm(m, g3, 3, A_ROWS, st));
+  }
+  // the window attention, attn.proj and the residual as one kernel (enc_chain.hip k_enc_attn) where the FFN takes x' with row statistics
+  if (can_chain_enc_attn(m, w, rows, stride == 2 ? (int64_t)E : ldx)) {
+    const bool carry = w.fc_wf && m->wsplit.count(w.fc_wf) && !g_no_carry() &&
+                       (can_chain_ffn_rows(m, rows, E) || gemm_can_carry_stats(rows, 4 * E, E, 1, m->wsplit_terms[w.fc_wf]));
+    EncAttnArgs aa{};
+    aa.Q = b.R[4]; aa.K = b.R[5]; aa.V = b.R[6]; aa.mask = mask_out; aa.Wp = w.wp_chain; aa.bp = w.bp; aa.ls = w.ls_attn;
+    if (stride == 2) { aa.R = b.R[3]; aa.ldr = E; } else { aa.R = Xin; aa.ldr = ldx; }
+    aa.Y = b.R[1]; aa.ldy = E; aa.stats_out = carry ? b.stats : nullptr; aa.stats_w = STATS_W; aa.B = B; aa.T = To; aa.win = c.win; aa.status = m->status;
+    {
+      ProfScope prof("gemm_f16x3<enc_attn>", st, 2.0 * rows * E * E + 4.0 * rows * E * c.win, (double)rows * E * 4.0 * 5.0);
+      TRY(launch_enc_attn(aa, st));
+    }
+    GemmArgs go = gemm(b.HID, 4 * E, w.pj_w, w.pj_b, Xout, ldo, rows, E, 4 * E);
+    go.flags = G_RES | G_OUT_MASK; go.rowmask = mask_out; go.ls = w.ls_ffn; go.R = b.R[1]; go.ldr = E;
+    if (carry) return run_ffn(m, b.R[1], w.fc_wf, w.fc_c, go, b.HID, rows, E, st, b.stats, w.fc_s);
+    LnArgs ln{}; ln.X = b.R[1]; ln.ldx = E; ln.Y = b.R[2]; ln.ldy = E; ln.w = w.ln_ffn_w; ln.b = w.ln_ffn_b; ln.rows = rows; ln.C = E;
+    TRY(launch_ln(ln, st));
+    return run_ffn(m, b.R[2], w.fc_w, w.fc_b, go, b.HID, rows, E, st);
   }
   if (c.win > 0) {
     LocalAttnArgs la{b.R[4], b.R[5], b.R[6], mask_out, b.R[0], B, To, E, c.vid_heads, c.win};
@@ -1093,12 +1134,12 @@ static int run_head_pair(dcf_model* m, const HeadW& h1, const HeadW& h2, Buffers
   return 0;
 }
 
-// From 32 768 level-0 rows on (two videos of T = 16 384 per forward), in the f16x3 mode, E = 256, 4 heads, <= 64 text tokens: the
-// attention half of a fusion layer as ONE kernel (dec_chain.hip).  Below that the 128-row windows leave CUs idle.
+// From 16 384 level-0 rows on (one video of T = 16 384), in the f16x3 mode, E = 256, 4 heads, <= 64 text tokens: the attention half
+// of a fusion layer as ONE kernel (dec_chain.hip).
 static int dec_chain_min_rows() {
   const int o = debug_option("dec_chain_min_rows", -1);            // dcf_debug_set_option (tests), then the developer switch
   if (o >= 0) return o;
-  static const int v = getenv("DCF_DEC_CHAIN_MIN_ROWS") ? atoi(getenv("DCF_DEC_CHAIN_MIN_ROWS")) : 32768;
+  static const int v = getenv("DCF_DEC_CHAIN_MIN_ROWS") ? atoi(getenv("DCF_DEC_CHAIN_MIN_ROWS")) : 16384;   // (one video per call: 1.70 against 1.74 ms)
   return v;
 }
 static bool can_chain_dec(dcf_model* m, const DecW& w, const LevelTable* lt, int rows, int64_t ldx, int Lk) {
@@ -1823,7 +1864,7 @@ int dcf_graph_active(const dcf_model* m) { return m ? m->last_launch : 0; }
 
 int dcf_debug_set_option(const char* name, int32_t value) {
   DCF_CHECK(name && *name, "dcf_debug_set_option: empty name");
-  static const char* known[] = {"dec_chain_min_rows", "enc_chain_min_rows"};
+  static const char* known[] = {"dec_chain_min_rows", "enc_chain_min_rows", "enc_attn_min_rows"};
   bool ok = false;
   for (const char* k : known) ok = ok || strcmp(k, name) == 0;
   DCF_CHECK(ok, "dcf_debug_set_option: unknown option '%s'", name);

@@ -191,8 +191,8 @@ int dcf_graph_active(const dcf_model* m);
 int dcf_model_set_graph_mode(dcf_model* m, int32_t mode);
 /* Test / developer switch (process wide): override a built-in dispatch threshold so that the operator tests can send small
  * reference fixtures through the kernels the engine only picks for large grids.  Names: "dec_chain_min_rows" (level-0 rows from
- * which the attention half of a fusion layer runs as one kernel, csrc/dec_chain.hip), "enc_chain_min_rows" (the same for the
- * encoder layers).  value < 0 restores the built-in value.  Not a reference interface; results do not depend on it beyond
+ * which the attention half of a fusion layer runs as one kernel, csrc/dec_chain.hip), "enc_chain_min_rows" / "enc_attn_min_rows" (the same for
+ * the two halves of the encoder layers' attention, csrc/enc_chain.hip).  value < 0 restores the built-in value.  Not a reference interface; results do not depend on it beyond
  * rounding.  ABI version 6. */
 int dcf_debug_set_option(const char* name, int32_t value);
 

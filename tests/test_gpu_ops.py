@@ -631,6 +631,7 @@ def _run_encoder(pkg, lib, sd, x, mask, stride, chain_rows, win=9):
     """dcf_op_encoder on a scratch model; chain_rows = the enc_chain_min_rows option (0: the one-kernel q / k / v front half)"""
     bs, E, T = x.shape
     pkg._lib.check(lib.dcf_debug_set_option(b'enc_chain_min_rows', chain_rows))
+    pkg._lib.check(lib.dcf_debug_set_option(b'enc_attn_min_rows', chain_rows))
     try:
         h = scratch_model(pkg, lib, sd, 'e', E=E, win=win, vid_heads=4, gemm_mode=16)
         To = T // stride
@@ -643,6 +644,7 @@ def _run_encoder(pkg, lib, sd, x, mask, stride, chain_rows, win=9):
         return y, mo.cpu().view(bs, 1, To)
     finally:
         pkg._lib.check(lib.dcf_debug_set_option(b'enc_chain_min_rows', -1))
+        pkg._lib.check(lib.dcf_debug_set_option(b'enc_attn_min_rows', -1))
 
 
 @pytest.mark.parametrize('chain_rows', [0, 1 << 30])
@@ -673,7 +675,7 @@ def _enc_shapes(E):
 
 
 # (bs, T, stride): windows with a partial tail, sequences with a padded tail, a hole across a 128-row window boundary
-@pytest.mark.parametrize('bs,T,stride', [(2, 200, 1), (3, 128, 1), (1, 452, 1), (2, 2560, 1)])
+@pytest.mark.parametrize('bs,T,stride', [(2, 200, 1), (3, 128, 1), (1, 452, 1), (2, 2560, 1), (2, 400, 2), (2, 5120, 2)])
 def test_enc_chain_vs_fp64(L, bs, T, stride):
     """the q / k / v front half of an encoder layer as one kernel (csrc/enc_chain.hip) inside dcf_op_encoder: TransformerEncoder.forward
     (blocks.py:578-591) at E = 256 against the oracle run in fp64, and against the launches the kernel replaces"""
