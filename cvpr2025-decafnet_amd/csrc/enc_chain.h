@@ -1,9 +1,9 @@
 // The attention half of a TransformerEncoder (vid_net layer, libs/modeling/blocks.py:578-586 with ConvAttNLayer :462-473 and the
 // local branch of MaskedMHA :357-373) as two kernels, E = 256, 4 heads of 64 channels, window <= 9, f16x3 operand split:
 //
-//   k_enc_qkv   x -> ln_attn -> three depthwise k3 convolutions (lane shifts) -> q / k / v_norm -> query / key / value projections,
-//               chained on chip (enc_chain.hip); writes Q, K, V (and, with stride 2, the max-pooled skip rows).  Replaces k_enc_pre +
-//               the grouped q / k / v GEMM: the three normalised conv outputs (3 rows written, 3 read back) never reach memory.
+//   k_enc_qkv   (stride 1) x -> ln_attn -> three depthwise k3 convolutions (lane shifts) -> q / k / v_norm -> query / key / value
+//               projections, chained on chip (enc_chain.hip); writes Q, K, V.  Replaces k_enc_pre + the grouped q / k / v GEMM: the
+//               three normalised conv outputs (3 rows written, 3 read back) never reach memory.
 //   k_enc_attn  Q, K, V -> sliding-window attention on the matrix cores (S^T = K Q^T over the wave's own 32 keys + an 8-key halo
 //               tile, band mask + softmax in registers, O^T = V^T P^T) -> attn.proj -> x' = skip * mask + ls_attn * (.) and the row
 //               statistics of x' for the folded ln_ffn.  Replaces k_local_attn + the projection GEMM.
@@ -23,13 +23,12 @@ struct EncQkvArgs {
   const unsigned short* W[3];   // chain images of the folded attn.attn.query / key / value.weight (256 x 256), launch_split_chain1
   const float* fs[3];           // [256] s
   const float* fc[3];           // [256] c
-  float* out[3];                // Q, K, V [B*T_out][256]
-  float* Skip;                  // [B*T_out][256] masked max-pool of the input (stride 2 only)
-  int B, T_in, stride;          // T_out = T_in / stride
+  float* out[3];                // Q, K, V [B*T_in][256]
+  int B, T_in;
   unsigned* status;             // sticky numerics word (GemmArgs::status)
 };
 
-bool enc_chain_supports(int E, int heads, int win, int stride);
+bool enc_chain_supports(int E, int heads, int win);
 int launch_enc_qkv(const EncQkvArgs& a, hipStream_t stream);
 
 struct EncAttnArgs {

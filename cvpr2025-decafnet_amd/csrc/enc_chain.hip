@@ -9,9 +9,9 @@
 // Y^T = W qc^T, whose A fragments stream through a two-buffer LDS ring (chain images, launch_split_chain1).  ln_attn(x) stays in
 // registers for the three branches; per branch: convolution -> LayerNorm -> planes (128 registers) -> four stages of two 32-channel
 // output tiles, the finished tiles stored beside the MFMAs of the next stage.
-// Stride 2 (levels >= 1): output row i reads input rows 2 i - 1, 2 i, 2 i + 1: the lane holds the even row 2 i and the odd row
-// 2 i + 1, the third tap is the previous lane's odd row; the masked max-pool of the same three rows (the layer's skip path,
-// blocks.py:31-47, :583) leaves in the same pass.
+// Stride 1 only (level 0 and the stem layers): at stride 2 a lane would hold the even AND the odd input row of its output row (256
+// registers) beside the planes, which does not fit one wave's 512 registers (628 bytes of scratch per lane in the build that tried):
+// levels >= 1 keep k_enc_pre + the grouped GEMM for this half and use k_enc_attn for the other.
 #include "enc_chain.h"
 
 #include <type_traits>
@@ -30,15 +30,13 @@ constexpr int STAGE = 65536;                   // bytes per ring buffer (64 piec
 constexpr int WGROWS = 128;
 // LDS behind the ring (floats)
 constexpr int P_LNW = 0, P_LNB = 256, P_DW = 512, P_FS = 2816, P_FC = 3584, P_END = 4352;      // (P_FS / P_FC: the folded LayerNorm's s[n], c[n] of q, k, v)
-constexpr int X_LAST = P_END;                  // [5][256] normalised rows: [0] the row before the window, [w + 1] the last (odd) row of wave w
-constexpr int X_OTHER = X_LAST + 5 * 256;      // [5][256] stride 1: [w] row 0 of wave w, [4] the row behind the window; stride 2: RAW odd rows as X_LAST
-constexpr int X_FLAG = X_OTHER + 5 * 256;      // [8] stride 2: validity of the raw rows of X_OTHER
-constexpr int LDS_FLOATS = X_FLAG + 8;
+constexpr int X_LAST = P_END;                  // [5][256] normalised rows: [0] the row before the window, [w + 1] the last row of wave w
+constexpr int X_OTHER = X_LAST + 5 * 256;      // [5][256] [w] row 0 of wave w, [4] the row behind the window
+constexpr int LDS_FLOATS = X_OTHER + 5 * 256;
 constexpr int LDS_BYTES = 2 * STAGE + LDS_FLOATS * (int)sizeof(float);
 
 }  // namespace
 
-template <int S>
 __global__ __launch_bounds__(256, 1) void k_enc_qkv(EncQkvArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   float* ldf = reinterpret_cast<float*>(lds + 2 * STAGE);
@@ -53,8 +51,8 @@ __global__ __launch_bounds__(256, 1) void k_enc_qkv(EncQkvArgs p) {
   asm volatile("" : "+v"(o_lh), "+v"(o_last), "+v"(o_oth));
   float* lh = ldf + o_lh;                                        // parameters
   float* lh_last = ldf + o_last;                                 // [0] the row before this wave's first (normalised), [256] this wave's last
-  float* lh_oth = ldf + o_oth;                                   // stride 2: the same, raw; stride 1: [0] this wave's first row, [256] the row behind its last
-  const int To = p.T_in / S;
+  float* lh_oth = ldf + o_oth;                                   // [0] this wave's first row, [256] the row behind its last
+  const int To = p.T_in;
   const int wins = (To + WGROWS - 1) / WGROWS;                  // windows per sequence
   const int b = (int)blockIdx.x / wins, t0 = ((int)blockIdx.x - b * wins) * WGROWS;
   const int t = t0 + w * 32 + r;                                 // this lane's OUTPUT position in sequence b
@@ -69,22 +67,18 @@ __global__ __launch_bounds__(256, 1) void k_enc_qkv(EncQkvArgs p) {
   };
 
   // ---- the lane's input row(s): 128 channels in D layout, v[4 ot + g] = channels 32 ot + 8 g + 4 h .. + 3
-  const int te = S * tc;                                          // even / only input row
+  const int te = tc;
   const bool valid_e = inseq && p.mask_in[ibase + te] != 0;
-  const bool valid_o = S == 2 && inseq && p.mask_in[ibase + te + (S == 2 ? 1 : 0)] != 0;
-  f32x4 xe[32], xo[S == 2 ? 32 : 1];
+  f32x4 xe[32];
   {
     const float* px = p.X + (ibase + te) * p.ldx + 4 * h;
 #pragma unroll
     for (int i = 0; i < 32; ++i) xe[i] = *reinterpret_cast<const f32x4*>(px + 32 * (i >> 2) + 8 * (i & 3));
-    if constexpr (S == 2) {
-#pragma unroll
-      for (int i = 0; i < 32; ++i) xo[i] = *reinterpret_cast<const f32x4*>(px + p.ldx + 32 * (i >> 2) + 8 * (i & 3));
-    }
+    
   }
-  // the rows next to the window: input row S t0 - 1 (wave 0) and, stride 1, row t0 + 128 (wave 3); lane l takes channels 4 l .. 4 l + 3
-  const bool edge_wave = w == 0 || (S == 1 && w == 3);
-  const int tedge = w == 0 ? S * t0 - 1 : t0 + WGROWS;
+  // the rows next to the window: row t0 - 1 (wave 0) and row t0 + 128 (wave 3); lane l takes channels 4 l .. 4 l + 3
+  const bool edge_wave = w == 0 || w == 3;
+  const int tedge = w == 0 ? t0 - 1 : t0 + WGROWS;
   const bool evalid = edge_wave && tedge >= 0 && tedge < p.T_in && p.mask_in[ibase + (tedge >= 0 && tedge < p.T_in ? tedge : 0)] != 0;
   f32x4 ev = f32x4{0.f, 0.f, 0.f, 0.f};
   if (evalid) ev = *reinterpret_cast<const f32x4*>(p.X + (ibase + tedge) * p.ldx + 4 * lane);
@@ -104,48 +98,10 @@ __global__ __launch_bounds__(256, 1) void k_enc_qkv(EncQkvArgs p) {
 #pragma unroll
     for (int i = 0; i < 32; ++i) xe[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  if constexpr (S == 2) {
-    if (!valid_o) {
-#pragma unroll
-      for (int i = 0; i < 32; ++i) xo[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    // the masked max-pool needs the RAW odd row of the previous output position: wave boundaries and the window's left edge via LDS
-    if (r == 31) {
-#pragma unroll
-      for (int i = 0; i < 32; ++i) *reinterpret_cast<f32x4*>(lh_oth + 256 + 32 * (i >> 2) + 8 * (i & 3)) = xo[i];
-      if (h == 0) ldf[X_FLAG + w + 1] = valid_o ? 1.f : 0.f;
-    }
-    if (w == 0) {
-      *reinterpret_cast<f32x4*>(ldf + X_OTHER + 4 * lane) = ev;
-      if (lane == 0) ldf[X_FLAG] = evalid ? 1.f : 0.f;
-    }
-  }
+  
   const bool is32 = lane == 32, is31 = lane == 31;
   __syncthreads();                                               // parameters (and the raw boundary rows) are in LDS
-  if constexpr (S == 2) {
-    // skip = max over the valid rows of {2 i - 1, 2 i, 2 i + 1}, 0 where row 2 i itself is padded (blocks.py:31-47 as the layer uses
-    // it: the global-minimum filler never wins a window that holds a valid element, rowops.hip k_enc_pre)
-    const float pflag = ldf[X_FLAG + w];
-    float vprev = shr1(valid_o ? 1.f : 0.f, pflag);
-    vprev = is32 ? pflag : vprev;                                // (r = 0 of the upper lane half: the previous wave's row as well)
-    const bool vp = vprev != 0.f;
-    float* ps = p.Skip + orow * EE + 4 * h;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const int c = 32 * (i >> 2) + 8 * (i & 3);
-      const f32x4 lastv = *reinterpret_cast<const f32x4*>(lh_oth + c);
-      f32x4 m = xe[i];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float sp = shr1(xo[i][e], lastv[e]);
-        const float pv = is32 ? lastv[e] : sp;
-        if (vp) m[e] = fmaxf(m[e], pv);
-        if (valid_o) m[e] = fmaxf(m[e], xo[i][e]);
-      }
-      if (!valid_e) m = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (inseq) *reinterpret_cast<f32x4*>(ps + 32 * (i >> 2) + 8 * (i & 3)) = m;
-    }
-  }
+  
   // ---- xn = ln_attn(x) * mask, in place
   auto ln_inplace = [&](f32x4 (&v)[32], bool valid) __attribute__((always_inline)) {
     float mean, rstd;
@@ -160,23 +116,22 @@ __global__ __launch_bounds__(256, 1) void k_enc_qkv(EncQkvArgs p) {
     }
   };
   ln_inplace(xe, valid_e);
-  if constexpr (S == 2) ln_inplace(xo, valid_o);
+  
   // boundary rows of the wave -> LDS; the window's outer neighbours from waves 0 / 3
   {
     if (r == 31) {
 #pragma unroll
       for (int i = 0; i < 32; ++i) {
         f32x4 v;
-        if constexpr (S == 2) v = xo[i]; else v = xe[i];
+        v = xe[i];
         *reinterpret_cast<f32x4*>(lh_last + 256 + 32 * (i >> 2) + 8 * (i & 3)) = v;
       }
     }
-    if constexpr (S == 1) {
-      if (r == 0) {
+          if (r == 0) {
 #pragma unroll
         for (int i = 0; i < 32; ++i) *reinterpret_cast<f32x4*>(lh_oth + 32 * (i >> 2) + 8 * (i & 3)) = xe[i];
       }
-    }
+    
     if (edge_wave) {
       f32x4 y = f32x4{0.f, 0.f, 0.f, 0.f};
       const float s = wave_sum((ev.x + ev.y) + (ev.z + ev.w));
@@ -252,8 +207,7 @@ __global__ __launch_bounds__(256, 1) void k_enc_qkv(EncQkvArgs p) {
           const f32x4 w0 = *reinterpret_cast<const f32x4*>(lh + pdw + c), w1 = *reinterpret_cast<const f32x4*>(lh + pdw + 256 + c),
                       w2 = *reinterpret_cast<const f32x4*>(lh + pdw + 512 + c);
           f32x4 pv, nv, y;
-          if constexpr (S == 1) {
-            const f32x4 firstv = *reinterpret_cast<const f32x4*>(lh_oth + 256 + c);
+                      const f32x4 firstv = *reinterpret_cast<const f32x4*>(lh_oth + 256 + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {                          // (the lane shifts with every lane active)
               const float sp = shr1(xe[i][e], lastv[e]), sn = shl1(xe[i][e], firstv[e]);
@@ -261,14 +215,7 @@ __global__ __launch_bounds__(256, 1) void k_enc_qkv(EncQkvArgs p) {
               nv[e] = is31 ? firstv[e] : sn;
             }
             y = w0 * pv + w1 * xe[i] + w2 * nv;
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float sp = shr1(xo[i][e], lastv[e]);
-              pv[e] = is32 ? lastv[e] : sp;
-            }
-            y = w0 * pv + w1 * xe[i] + w2 * xo[i];
-          }
+          
           s1 += (y.x + y.y) + (y.z + y.w);
           s2 += __builtin_fmaf(y.x, y.x, y.y * y.y) + __builtin_fmaf(y.z, y.z, y.w * y.w);
           v8[4 * u] = y.x; v8[4 * u + 1] = y.y; v8[4 * u + 2] = y.z; v8[4 * u + 3] = y.w;
@@ -582,27 +529,24 @@ int launch_enc_attn(const EncAttnArgs& a, hipStream_t stream) {
   return 0;
 }
 
-bool enc_chain_supports(int E, int heads, int win, int stride) { return E == EE && heads == 4 && win >= 1 && win <= 9 && (stride == 1 || stride == 2); }
+bool enc_chain_supports(int E, int heads, int win) { return E == EE && heads == 4 && win >= 1 && win <= 9 && (win & 1); }
 
 int launch_enc_qkv(const EncQkvArgs& a, hipStream_t stream) {
-  DCF_CHECK(a.B > 0 && a.T_in > 0 && (a.stride == 1 || a.stride == 2) && a.T_in % a.stride == 0 && a.X && a.mask_in && a.ln_w && a.ln_b,
+  DCF_CHECK(a.B > 0 && a.T_in > 0 && a.X && a.mask_in && a.ln_w && a.ln_b,
             "launch_enc_qkv: bad arguments");
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   for (int op = 0; op < 3; ++op)
     DCF_CHECK(a.dw[op] && a.fs[op] && a.fc[op] && a.W[op] && a.out[op] && al16(a.W[op]) && al16(a.out[op]), "launch_enc_qkv: null or misaligned argument");
-  DCF_CHECK(al16(a.X) && a.ldx % 4 == 0 && (a.stride == 1 || (a.Skip && al16(a.Skip))), "launch_enc_qkv: X / Skip must be 16-byte aligned (stride 2 needs Skip)");
+  DCF_CHECK(al16(a.X) && a.ldx % 4 == 0, "launch_enc_qkv: X must be 16-byte aligned, its row pitch a multiple of 4");
   static bool attr_set[64] = {};                         // per device: the attribute belongs to the device's copy of the kernel
   int dev = 0;
   DCF_HIP(hipGetDevice(&dev));
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    DCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_enc_qkv<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    DCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_enc_qkv<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    DCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_enc_qkv), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set[dev] = true;
   }
-  const int To = a.T_in / a.stride;
-  const unsigned grid = (unsigned)(a.B * ((To + WGROWS - 1) / WGROWS));
-  if (a.stride == 1) hipLaunchKernelGGL(k_enc_qkv<1>, dim3(grid), dim3(256), LDS_BYTES, stream, a);
-  else hipLaunchKernelGGL(k_enc_qkv<2>, dim3(grid), dim3(256), LDS_BYTES, stream, a);
+  const unsigned grid = (unsigned)(a.B * ((a.T_in + WGROWS - 1) / WGROWS));
+  hipLaunchKernelGGL(k_enc_qkv, dim3(grid), dim3(256), LDS_BYTES, stream, a);
   DCF_HIP(hipGetLastError());
   return 0;
 }

@@ -381,7 +381,7 @@ static int resolve_encoder(dcf_model* m, const std::string& p, int E, hipStream_
   if (m->gemm_terms != 0 && E % 64 == 0 && fold_ln(m, w.fc_w, w.fc_b, w.ln_ffn_w, w.ln_ffn_b, 4 * E, E, st, &w.fc_wf, &w.fc_s, &w.fc_c)) return -1;
   for (int i = 0; i < 3; ++i) { w.qkv_chain[i] = nullptr; w.qkv_s[i] = w.qkv_c[i] = nullptr; }
   w.wp_chain = nullptr;
-  if (m->gemm_terms == GEMM_F16X3 && enc_chain_supports(E, m->cfg.vid_heads, m->cfg.win > 0 ? m->cfg.win : 99, 1)) {
+  if (m->gemm_terms == GEMM_F16X3 && enc_chain_supports(E, m->cfg.vid_heads, m->cfg.win > 0 ? m->cfg.win : 99)) {
     {
       unsigned short* img = nullptr;
       DCF_HIP(hipMalloc(&img, chain1_image_halfs(E, E) * sizeof(unsigned short)));
@@ -888,7 +888,7 @@ static bool can_chain_enc(dcf_model* m, const EncW& w, int rows, int stride, int
   static const bool off = getenv("DCF_NO_ENC_CHAIN") != nullptr;    // developer switch: the separate launches
   const dcf_config& c = m->cfg;
   return !off && m->gemm_terms == GEMM_F16X3 && w.qkv_chain[0] && w.qkv_chain[1] && w.qkv_chain[2] && stride == 1 &&
-         enc_chain_supports(c.E, c.vid_heads, c.win > 0 ? c.win : 99, stride) && rows >= enc_chain_min_rows() && ldx % 4 == 0;
+         enc_chain_supports(c.E, c.vid_heads, c.win > 0 ? c.win : 99) && rows >= enc_chain_min_rows() && ldx % 4 == 0;
 }
 
 static int enc_attn_min_rows() {
@@ -900,7 +900,7 @@ static int enc_attn_min_rows() {
 static bool can_chain_enc_attn(dcf_model* m, const EncW& w, int rows, int64_t ldr) {
   static const bool off = getenv("DCF_NO_ENC_ATTN") != nullptr;     // developer switch: k_local_attn + the projection GEMM
   const dcf_config& c = m->cfg;
-  return !off && m->gemm_terms == GEMM_F16X3 && w.wp_chain && c.win > 0 && (c.win & 1) && enc_chain_supports(c.E, c.vid_heads, c.win, 1) &&
+  return !off && m->gemm_terms == GEMM_F16X3 && w.wp_chain && c.win > 0 && (c.win & 1) && enc_chain_supports(c.E, c.vid_heads, c.win) &&
          rows >= enc_attn_min_rows() && ldr % 4 == 0;
 }
 
@@ -914,7 +914,7 @@ static int run_encoder(dcf_model* m, const EncW& w, Buffers& b, const float* Xin
     ea.X = Xin; ea.ldx = ldx; ea.mask_in = mask_in; ea.ln_w = w.ln_attn_w; ea.ln_b = w.ln_attn_b;
     ea.dw[0] = w.dw_q; ea.dw[1] = w.dw_k; ea.dw[2] = w.dw_v;
     for (int i = 0; i < 3; ++i) { ea.W[i] = w.qkv_chain[i]; ea.fs[i] = w.qkv_s[i]; ea.fc[i] = w.qkv_c[i]; ea.out[i] = b.R[4 + i]; }
-    ea.Skip = stride == 2 ? b.R[3] : nullptr; ea.B = B; ea.T_in = T_in; ea.stride = stride; ea.status = m->status;
+    ea.B = B; ea.T_in = T_in; ea.status = m->status;
     ProfScope prof("gemm_f16x3<enc_qkv>", st, 2.0 * rows * E * 3.0 * E, (double)rows * E * 4.0 * 4.0);
     TRY(launch_enc_qkv(ea, st));
   } else {
