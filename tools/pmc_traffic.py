@@ -12,7 +12,7 @@ def family(name):
     m = re.search(r'gemm_bf16s_kernel<\s*\d+,\s*\d+,\s*\d+,\s*\d+,\s*\d+,\s*(\d+)', name) or re.search(r'gemm_bf16s_kslice_kernel<\s*(\d+)', name)
     if m:
         return 'gemm_f16x3' if m.group(1) == '16' else 'gemm_bf16s'
-    if 'k_ffn_chain<' in name or 'k_head_chain<' in name or 'k_dec_chain<' in name or 'k_enc_chain<' in name:      # fc + proj (a head's trunk) as one f16x3 kernel: same family as in bench.py
+    if 'k_ffn_chain<' in name or 'k_head_chain<' in name or 'k_dec_chain<' in name or 'k_enc_qkv' in name or 'k_enc_attn' in name:      # fc + proj (a head's trunk) as one f16x3 kernel: same family as in bench.py
         return 'gemm_f16x3'
     return 'gemm_f32' if 'gemm_f32' in name else None
 
