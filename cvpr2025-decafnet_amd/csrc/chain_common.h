@@ -68,4 +68,18 @@ __device__ __forceinline__ void row_stats(const f32x4 (&v)[32], float& mean, flo
 
 
 }  // namespace chain
+// in-kernel stamps of the diagnostic builds (tools/dc_stamp.sh, tools/ea_stamp.sh): cycles one wave spends in the segments of a kernel
+#if defined(DCF_DC_STAMP) || defined(DCF_EA_STAMP)
+__device__ __forceinline__ unsigned long long dc_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define STAMP(i) do { const unsigned long long t_ = dcf::dc_stamp(); acc_[i] += t_ - last_; last_ = t_; } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 }  // namespace dcf

@@ -37,22 +37,9 @@ constexpr int X_LAST = P_END;                  // [5][256]: last[0] = the row be
 constexpr int X_FIRST = X_LAST + 5 * 256;      // [5][256]: first[w] = row 0 of wave w, first[4] = the row behind the window
 constexpr int LDS_FLOATS = X_FIRST + 5 * 256;
 constexpr int LDS_BYTES = 2 * STAGE + LDS_FLOATS * (int)sizeof(float);
-
 #ifdef DCF_DC_STAMP
-// diagnostic build only (tools/dc_stamp.sh): cycles wave 0 of workgroup 1 spends in the segments of the kernel
-__device__ unsigned long long dcf_dc_stamps[16];
-__device__ __forceinline__ unsigned long long dc_stamp() {
-  unsigned long long t;
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  return t;
-}
-#define STAMP(i) do { const unsigned long long t_ = dc_stamp(); acc_[i] += t_ - last_; last_ = t_; } while (0)
-#else
-#define STAMP(i) do { } while (0)
+__device__ unsigned long long dcf_dc_stamps[16];   // diagnostic build only (tools/dc_stamp.sh): wave 0 of workgroup 1
 #endif
-
 }  // namespace
 
 // ---- images ---------------------------------------------------------------------------------------------------------------------

@@ -261,17 +261,22 @@ __global__ __launch_bounds__(256, 1) void k_enc_qkv(EncQkvArgs p) {
 }
 
 // ---- part 2: sliding-window attention + attn.proj + the residual --------------------------------------------------------------
-// A wave owns 32 consecutive rows of which the inner 24 come out (rows 4 .. 27; the windows of consecutive waves overlap by 8 rows), so
-// every key a query may attend to (|i - j| <= 4) is one of the wave's own 32 rows: S^T = K_h Q_h^T is ONE 32 x 32 tile per head whose A
-// operand is the wave's K rows exactly as they are loaded (lane = key row), the band |key - query| <= win / 2 is a per-slot predicate of
-// the D layout (slot e of lane half h is key (e & 3) + 8 (e >> 2) + 4 h), the softmax a reduction over the lane's 16 slots and the
-// other lane half, and P (D layout: lane = query row, slots = keys) the B operand of O_h^T = V_h^T P^T.  V^T wants lane = channel:
-// it is read from the ordinary (row, channel) rows with one dword per key (a half wave reads 32 consecutive channels of one row).
-// O^T has lane = row again: ctx, split into planes, feeds attn.proj as in dec_chain.hip (chain image through the LDS ring).
+// A wave owns 32 consecutive rows.  The keys of its queries (|i - j| <= 4) are its own 32 rows plus the 4 rows before and the 4 behind:
+// S^T = K_h Q_h^T is a 32 x 32 tile over the wave's own keys, whose A operand is the wave's K rows exactly as they are loaded
+// (lane = key row), plus a HALO tile whose A rows 0 .. 3 / 4 .. 7 are the neighbouring rows (loaded by lanes 0 .. 7).  The band
+// |key - query| <= win / 2 is a per-slot predicate of the D layout (slot e of lane half h is key (e & 3) + 8 (e >> 2) + 4 h; of the
+// halo tile only slots 0 .. 3 exist), the softmax a reduction over the lane's 16 + 4 slots and the other lane half, and P (D layout:
+// lane = query row, slots = keys) the B operand of O_h^T = V_h^T P^T.  V^T wants lane = channel: it is read from the ordinary
+// (row, channel) rows with one dword per key (a half wave reads 32 consecutive channels of one row).  O^T has lane = row again:
+// ctx, split into planes, feeds attn.proj as in dec_chain.hip (chain image through the LDS ring).  q and k carry d^-1/4 each in the
+// reference; here the product is scaled by d^-1/2 afterwards (16 + 4 multiplications instead of 128 per head).
 namespace {
-constexpr int AW_VALID = 24, AW_HALO = 4, AWG_ROWS = 4 * AW_VALID;     // rows a wave / a workgroup produces
+constexpr int AWG_ROWS = 128;
 constexpr int A_BP = 0, A_LS = 256, A_END = 512;
 constexpr int A_LDS_BYTES = 2 * STAGE + A_END * (int)sizeof(float);
+#ifdef DCF_EA_STAMP
+__device__ unsigned long long dcf_ea_stamps[16];   // diagnostic build only (tools/ea_stamp.sh): wave 0 of workgroup 1
+#endif
 }  // namespace
 
 __global__ __launch_bounds__(256, 1) void k_enc_attn(EncAttnArgs p) {
@@ -282,16 +287,23 @@ __global__ __launch_bounds__(256, 1) void k_enc_attn(EncAttnArgs p) {
   const unsigned lane16 = (unsigned)lane * 16u;
   const int wins = (p.T + AWG_ROWS - 1) / AWG_ROWS;
   const int b = (int)blockIdx.x / wins, t0 = ((int)blockIdx.x - b * wins) * AWG_ROWS;
-  const int base = t0 + AW_VALID * w - AW_HALO;                  // sequence position of the wave's row 0
+  const int base = t0 + 32 * w;                                  // sequence position of the wave's row 0
   const int t = base + r;
-  const bool inseq = t >= 0 && t < p.T;
-  const int tc = t < 0 ? 0 : (t < p.T ? t : p.T - 1);
-  const int64_t row = (int64_t)b * p.T + tc;
+  const bool inseq = t < p.T;
+  const int tc = inseq ? t : p.T - 1;
+  const int64_t seq = (int64_t)b * p.T, row = seq + tc;
   const bool live = inseq && p.mask[row] != 0;                   // padded query rows are forced to 0 (blocks.py:293)
-  const bool owns = inseq && r >= AW_HALO && r < AW_HALO + AW_VALID && t < t0 + AWG_ROWS;   // this lane's row leaves the kernel here
   const int half = p.win / 2;
   // validity of the wave's 32 rows as keys: bit i of km = row i is a valid key, bit i of ki = it exists at all
   const unsigned km = (unsigned)__ballot(h == 0 && live), ki = (unsigned)__ballot(h == 0 && inseq);
+  // the halo tile: slot i < 4 = row base - 4 + i, slot 4 <= i < 8 = row base + 28 + i (lanes 0 .. 7 of the lower half look them up)
+  const int th = r < 4 ? base - 4 + r : base + 28 + r;
+  const bool hex = r < 8 && th >= 0 && th < p.T;
+  const int thc = th < 0 ? 0 : (th < p.T ? th : p.T - 1);
+  const unsigned kih = (unsigned)__ballot(h == 0 && hex), kmh = (unsigned)__ballot(h == 0 && hex && p.mask[seq + thc] != 0);
+#ifdef DCF_EA_STAMP
+  unsigned long long acc_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = dc_stamp();
+#endif
 
   auto issue_piece = [&](int pair, int i) __attribute__((always_inline)) {
     const int pc = w + 4 * i;
@@ -302,21 +314,28 @@ __global__ __launch_bounds__(256, 1) void k_enc_attn(EncAttnArgs p) {
   ldf[A_BP + tid] = p.bp[tid];
   ldf[A_LS + tid] = p.ls ? p.ls[tid] : 1.f;
 
-  const float qscale = 1.0f / sqrtf(sqrtf(64.f));               // d^-1/4 on q AND k (blocks.py:179, :359)
+  const float sscale = 1.0f / sqrtf(64.f);                       // d^-1/4 on q AND k (blocks.py:179, :359) = d^-1/2 on the product
   const float* pq = p.Q + row * EE + 4 * h;
   const float* pk = p.K + row * EE + 4 * h;
+  const float* pkh = p.K + (seq + thc) * EE + 4 * h;             // the lane's halo row (lanes 0 .. 7)
   // V^T operand: lane (c = r, h) reads channel 64 hd + 32 ct + c of the wave's rows; the row of key slot i, clamped into the sequence
   // (a key outside it has probability exactly 0, its value only has to be finite)
-  const float* pv = p.V + (int64_t)b * p.T * EE + r;
+  const float* pv = p.V + seq * EE + r;
   f16x8 cth[16], ctl[16];
   // raw operands of a head, requested one head ahead (two register sets): Q_h, K_h of the lane's row (8 + 8 pieces of 16 bytes) and
-  // the 32 values of V_h^T (2 channel tiles x 16 keys of the lane's lane half)
-  int voff[16];                                                  // row offsets of the lane's 16 key slots (2 q x 8 j), clamped into the sequence
+  // the 32 + 8 values of V_h^T (2 channel tiles x (16 own + 4 halo) keys of the lane's lane half)
+  int voff[16], voffh[4];
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     int tk = base + 16 * (k >> 3) + 8 * ((k & 7) >> 2) + 4 * h + (k & 3);
-    tk = tk < 0 ? 0 : (tk < p.T ? tk : p.T - 1);
+    tk = tk < p.T ? tk : p.T - 1;
     voff[k] = tk * EE;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {                                  // halo K step: half j of lane half h = halo slot 4 h + j
+    int tk = h == 0 ? base - 4 + j : base + 32 + j;
+    tk = tk < 0 ? 0 : (tk < p.T ? tk : p.T - 1);
+    voffh[j] = tk * EE;
   }
   f32x4 rq[2][8], rk[2][8];
   float rv[2][32];
@@ -338,25 +357,38 @@ __global__ __launch_bounds__(256, 1) void k_enc_attn(EncAttnArgs p) {
       }
   };
   load_head(0);
+  STAMP(0);
 #pragma unroll
   for (int hd = 0; hd < 4; ++hd) {
+    // the halo rows of this head (the neighbouring waves / workgroups load the same rows: L2 hits), then the next head's own rows
+    f32x4 rkh[8];
+    float rvh[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) rkh[u] = r < 8 ? *reinterpret_cast<const f32x4*>(pkh + 64 * hd + 8 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rvh[4 * ct + j] = pv[voffh[j] + 64 * hd + 32 * ct];
     if (hd + 1 < 4) load_head(hd + 1);
-    // Q_h, K_h as planes: K step ks = 2 t2 + q <- channels 64 hd + 32 t2 + 16 q + (chain order) = pieces 4 t2 + 2 q, + 1
-    f16x8 qh[4], ql[4], kh[4], kl[4];
+    STAMP(1);
+    // Q_h, K_h as planes: K step ks = 2 t2 + q <- channels 64 hd + 32 t2 + 16 q + (chain order) = pieces 2 ks, 2 ks + 1
+    f16x8 qh[4], ql[4], kh[4], kl[4], hh[4], hl[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      float a8[8], b8[8];
+      float a8[8], b8[8], c8[8];
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { a8[4 * u + e] = rq[hd & 1][2 * ks + u][e] * qscale; b8[4 * u + e] = rk[hd & 1][2 * ks + u][e] * qscale; }
+        for (int e = 0; e < 4; ++e) { a8[4 * u + e] = rq[hd & 1][2 * ks + u][e]; b8[4 * u + e] = rk[hd & 1][2 * ks + u][e]; c8[4 * u + e] = rkh[2 * ks + u][e]; }
       split8(a8, 1.f, qh[ks], ql[ks]);
       split8(b8, 1.f, kh[ks], kl[ks]);
+      split8(c8, 1.f, hh[ks], hl[ks]);
     }
-    // V_h^T fragments: (ct, q): half j of lane half h = key 16 q + 8 (j >> 2) + 4 h + (j & 3)
-    f16x8 vh[2][2], vl[2][2];
+    STAMP(2);
+    // V_h^T fragments: (ct, q): half j of lane half h = key 16 q + 8 (j >> 2) + 4 h + (j & 3); the halo K step: halves 0 .. 3 = slot 4 h + j
+    f16x8 vh[2][3], vl[2][3];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < 2; ++ct) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         float v8[8];
@@ -364,16 +396,26 @@ __global__ __launch_bounds__(256, 1) void k_enc_attn(EncAttnArgs p) {
         for (int j = 0; j < 8; ++j) v8[j] = rv[hd & 1][16 * ct + 8 * q + j];
         split8(v8, 1.f, vh[ct][q], vl[ct][q]);
       }
-    // S^T = K_h Q_h^T: slot e of lane (r, h) = key (e & 3) + 8 (e >> 2) + 4 h against query row r
-    f32x16 S;
+      float v8[8];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) S[e] = 0.f;
+      for (int j = 0; j < 8; ++j) v8[j] = j < 4 ? rvh[4 * ct + j] : 0.f;
+      split8(v8, 1.f, vh[ct][2], vl[ct][2]);
+    }
+    STAMP(3);
+    // S^T = K_h Q_h^T: slot e of lane (r, h) = key (e & 3) + 8 (e >> 2) + 4 h against query row r; SH: the halo tile
+    f32x16 S, SH;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { S[e] = 0.f; SH[e] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       S = mma(kl[ks], qh[ks], S);
+      SH = mma(hl[ks], qh[ks], SH);
       S = mma(kh[ks], ql[ks], S);
+      SH = mma(hh[ks], ql[ks], SH);
       S = mma(kh[ks], qh[ks], S);
+      SH = mma(hh[ks], qh[ks], SH);
     }
+    STAMP(4);
     // band + key mask + softmax (blocks.py:252-262, :279-294): keys outside the window or the sequence are -inf, padded keys inside
     // it get -1e4, padded queries come out 0
     float mx = -INFINITY;
@@ -383,15 +425,28 @@ __global__ __launch_bounds__(256, 1) void k_enc_attn(EncAttnArgs p) {
       const int d = i - r;
       const bool in = d >= -half && d <= half && ((ki >> i) & 1u);
       const float pen = ((km >> i) & 1u) ? 0.f : -1e4f;
-      S[e] = in ? S[e] + pen : -INFINITY;
+      S[e] = in ? __builtin_fmaf(S[e], sscale, pen) : -INFINITY;
       mx = fmaxf(mx, S[e]);
+    }
+    float sh4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = e + 4 * h;                                   // halo slot: row base - 4 + i (i < 4) or base + 28 + i
+      const int d = (i < 4 ? i - 4 : 28 + i) - r;
+      const bool in = d >= -half && d <= half && ((kih >> i) & 1u);
+      const float pen = ((kmh >> i) & 1u) ? 0.f : -1e4f;
+      sh4[e] = in ? __builtin_fmaf(SH[e], sscale, pen) : -INFINITY;
+      mx = fmaxf(mx, sh4[e]);
     }
     mx = xor32_max(mx);
     float sum = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { S[e] = fast_exp(S[e] - mx); sum += S[e]; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sh4[e] = fast_exp(sh4[e] - mx); sum += sh4[e]; }
     const float inv = live ? 1.0f / xor32_sum(sum) : 0.f;
-    f16x8 ph[2], pl[2];
+    STAMP(5);
+    f16x8 ph[3], pl[3];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       float v8[8];
@@ -399,27 +454,40 @@ __global__ __launch_bounds__(256, 1) void k_enc_attn(EncAttnArgs p) {
       for (int e = 0; e < 8; ++e) v8[e] = live ? S[8 * q + e] * inv : 0.f;
       split8(v8, 1.f, ph[q], pl[q]);
     }
+    {
+      float v8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v8[e] = (e < 4 && live) ? sh4[e & 3] * inv : 0.f;
+      split8(v8, 1.f, ph[2], pl[2]);
+    }
+    STAMP(6);
     // O_h^T = V_h^T P^T -> ctx planes of K steps 2 (2 hd + ct) + q of the projection
+    f32x16 O[2];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      f32x16 O;
+    for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) O[e] = 0.f;
+      for (int e = 0; e < 16; ++e) O[ct][e] = 0.f;
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        O = mma(vl[ct][q], ph[q], O);
-        O = mma(vh[ct][q], pl[q], O);
-        O = mma(vh[ct][q], ph[q], O);
-      }
+    for (int q = 0; q < 3; ++q) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) O[ct] = mma(vl[ct][q], ph[q], O[ct]);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) O[ct] = mma(vh[ct][q], pl[q], O[ct]);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) O[ct] = mma(vh[ct][q], ph[q], O[ct]);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         float v8[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v8[e] = O[8 * q + e];
+        for (int e = 0; e < 8; ++e) v8[e] = O[ct][8 * q + e];
         split8(v8, SA, cth[2 * (2 * hd + ct) + q], ctl[2 * (2 * hd + ct) + q]);
       }
-    }
+    STAMP(7);
   }
+  const bool owns = inseq;                                       // every row of the window leaves the kernel here
 
   // ---- attn.proj + the residual: x' = skip * mask + ls * (proj(ctx) + b), row statistics for the folded ln_ffn
   auto stage_begin = [&]() __attribute__((always_inline)) {
@@ -482,7 +550,9 @@ __global__ __launch_bounds__(256, 1) void k_enc_attn(EncAttnArgs p) {
   };
 #pragma unroll
   for (int pair = 0; pair < 4; ++pair) {
+    STAMP(8);
     stage_begin();
+    STAMP(9);
     if (pair > 0) asm volatile("" : "+v"(rr[(pair - 1) & 1][0]), "+v"(rr[(pair - 1) & 1][1]), "+v"(rr[(pair - 1) & 1][2]), "+v"(rr[(pair - 1) & 1][3]),
                                "+v"(rr[(pair - 1) & 1][4]), "+v"(rr[(pair - 1) & 1][5]), "+v"(rr[(pair - 1) & 1][6]), "+v"(rr[(pair - 1) & 1][7]));
     load_r(pair);
@@ -495,7 +565,9 @@ __global__ __launch_bounds__(256, 1) void k_enc_attn(EncAttnArgs p) {
           [&](int kk) __attribute__((always_inline)) { if (pair < 3) issue_piece(pair + 1, kk); },
           [&](int kk, int slot) __attribute__((always_inline)) { if (pair > 0 && slot == 0 && (kk & 1) == 0) epilogue(pair - 1, kk >> 3, (kk >> 1) & 3); });
   }
+  STAMP(8);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(10);
   asm volatile("" : "+v"(rr[1][0]), "+v"(rr[1][1]), "+v"(rr[1][2]), "+v"(rr[1][3]), "+v"(rr[1][4]), "+v"(rr[1][5]), "+v"(rr[1][6]), "+v"(rr[1][7]));
 #pragma unroll
   for (int u = 0; u < 8; ++u) epilogue(3, u >> 2, u & 3);
@@ -507,7 +579,20 @@ __global__ __launch_bounds__(256, 1) void k_enc_attn(EncAttnArgs p) {
     for (int k = 1; k < slots; ++k) { o[2 * k] = 0.f; o[2 * k + 1] = 0.f; }
   }
   if (owns && !(__builtin_fabsf(s1) <= 3.4028234664e38f) && p.status) atomicOr(p.status, 1u);
+#ifdef DCF_EA_STAMP
+  STAMP(11);
+  if (blockIdx.x == 1 && tid == 0)
+    for (int i = 0; i < 16; ++i) dcf_ea_stamps[i] = acc_[i];
+#endif
 }
+
+#ifdef DCF_EA_STAMP
+}  // namespace dcf
+extern "C" int dcf_debug_ea_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(dcf::dcf_ea_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+namespace dcf {
+#endif
 
 int launch_enc_attn(const EncAttnArgs& a, hipStream_t stream) {
   DCF_CHECK(a.B > 0 && a.T > 0 && a.Q && a.K && a.V && a.mask && a.Wp && a.bp && a.R && a.Y && a.win >= 1 && a.win <= 9 && (a.win & 1),

@@ -17,6 +17,10 @@ lib = pkg._lib.lib()
 P = pkg._lib.ptr
 
 
+EA_SEG = ['setup + head 0 requests', 'halo + next head requests', 'Q / K / halo split', 'V split', 'S MFMAs', 'band + softmax', 'P split',
+          'O MFMAs + ctx split', 'projection MFMAs + epilogue', 'stage wait + barrier', 'last wait', 'last epilogue + stats']
+
+
 def shapes(E):
     sh = {'ln_attn.weight': (E, 1), 'ln_attn.bias': (E, 1), 'ln_ffn.weight': (E, 1), 'ln_ffn.bias': (E, 1),
           'drop_path_attn.scale': (1, E, 1), 'drop_path_ffn.scale': (1, E, 1),
@@ -72,6 +76,15 @@ def main():
         print(f'== B={B} T={T} stride={stride} chain={"on" if chain_rows == 0 else "off"}: {sum(v["ms"] for v in prof.values()) * 1e3:.1f} us in all')
         for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms']):
             print(f'   {k:40s} {v["ms"] * 1e3:9.1f} us  n={v["count"]}')
+        if chain_rows == 0 and hasattr(lib, 'dcf_debug_ea_stamps'):      # diagnostic build of tools/ea_stamp.sh
+            out = (ctypes.c_ulonglong * 16)()
+            lib.dcf_debug_ea_stamps.restype = ctypes.c_int
+            if lib.dcf_debug_ea_stamps(out) == 0:
+                tot = sum(out)
+                print(f'   k_enc_attn in-kernel stamps (wave 0 of workgroup 1): {tot} cycles')
+                for n, v in zip(EA_SEG, out):
+                    if v:
+                        print(f'      {n:28s} {v:9d}  {100.0 * v / tot:5.1f} %')
     for o in (b'enc_chain_min_rows', b'enc_attn_min_rows'):
         pkg._lib.check(lib.dcf_debug_set_option(o, -1))
 
