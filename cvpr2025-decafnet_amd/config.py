@@ -40,14 +40,15 @@ def to_attr(d):
 def make_opt(D=1024, E=256, TE=256, text_in=300, n_levels=8, win=9, n_heads=4, sn=60, sratio=0.3,
              msf=True, scat=False, norm=True, max_seq_len=2304, text_layers=5, fusion_layers=2,
              text_max_len=48, n_embd_convs=2, n_stem=0, head_layers=2, use_abs_pe=True,
-             text_use_abs_pe=False, max_vid_len=None, sfonly=False, text_name='transformer', text_bkgd=True, xattn_mode='adaln'):
+             text_use_abs_pe=False, max_vid_len=None, sfonly=False, text_name='transformer', text_bkgd=True, xattn_mode='adaln',
+             vid_stride=1, pool_only=False):
     """Build an ``opt`` tree with the keys the hot path reads.  Defaults are
     the survey's probe configuration: D=1024, E=TE=256, L=8, w=9,
     4 heads, 2 fusion layers, sn=60, sratio=0.3, msf, norm."""
     opt = dict(
         model=dict(
             name='iter', sn=sn, sratio=sratio, msf=msf, scat=scat, sfonly=sfonly, norm=norm,
-            max_vid_len=max_vid_len or max_seq_len, vid_stride=1,
+            max_vid_len=max_vid_len or max_seq_len, vid_stride=vid_stride,
             num_fpn_levels=n_levels, mha_win_size=win,
             text_net=(dict(name='transformer', in_dim=text_in, embd_dim=TE, max_seq_len=text_max_len,
                            n_heads=n_heads, n_layers=text_layers, attn_pdrop=0.0, proj_pdrop=0.0,
@@ -55,9 +56,9 @@ def make_opt(D=1024, E=256, TE=256, text_in=300, n_levels=8, win=9, n_heads=4, s
                       dict(name='identity', in_dim=text_in, embd_dim=TE, max_seq_len=text_max_len, n_heads=n_heads,
                            use_abs_pe=text_use_abs_pe, use_bkgd_token=text_bkgd)),
             vid_net=dict(name='transformer', in_dim=D, embd_dim=E, n_heads=n_heads,
-                         max_seq_len=max_seq_len, stride=1, arch=(n_embd_convs, n_stem, n_levels),
+                         max_seq_len=max_seq_len, stride=vid_stride, arch=(n_embd_convs, n_stem, n_levels),
                          mha_win_size=win, attn_pdrop=0.0, proj_pdrop=0.0, path_pdrop=0.0,
-                         use_abs_pe=use_abs_pe, fuse='cat', pool_only=False, cdrop=0.0),
+                         use_abs_pe=use_abs_pe, fuse='cat', pool_only=pool_only, cdrop=0.0),
             fusion=dict(name='xattn', vid_dim=E, text_dim=TE, n_layers=fusion_layers, n_heads=n_heads,
                         attn_pdrop=0.0, proj_pdrop=0.0, path_pdrop=0.0, xattn_mode=xattn_mode),
             cls_head=dict(name='cls', embd_dim=E, n_layers=head_layers, prior_prob=0.0),

@@ -193,6 +193,9 @@ struct HeadW {
   const unsigned short* chain[2] = {nullptr, nullptr};   // chain images of the two trunk convolutions (head_chain.hip) or nullptr
 };
 
+// opt.model.vid_net.stride (video_net.py:39): the embedding convolutions divide the sequence by it; 0 (older callers) reads as 1
+static inline int vid_stride_of(const dcf_config& c) { return c.vid_stride > 1 ? c.vid_stride : 1; }
+
 struct Plan {    // geometry for one (T0, B)
   int T0 = 0, B = 0;
   LevelTable lt{};
@@ -228,6 +231,7 @@ struct dcf_model {
   const float *embd_fc_wf = nullptr, *embd_fc_s = nullptr, *embd_fc_c = nullptr;   // vid_net.embd_fc with fusion.ln_out folded in
   std::vector<const float*> embd_conv, embd_ln_w, embd_ln_b;
   std::vector<EncW> stem, branch;
+  std::vector<const float*> pool_w;          // vid_net.pool_only: depthwise k3 weight [3][E] of every branch layer (video_net.py:107-109)
   HeadW cls1, cls2, reg;
   std::vector<float> reg_scales;             // host copy of reg_head.scales.{l}.scale
   const float *tcn_in_w = nullptr, *tcn_in_b = nullptr, *tcn_out_w = nullptr, *tcn_out_b = nullptr;
@@ -633,12 +637,13 @@ static int finalize(dcf_model* m, hipStream_t st) {
     if (m->gemm_terms != 0 && E % 64 == 0 && c.fusion_layers > 0 &&
         fold_ln(m, m->embd_fc_w, m->embd_fc_b, m->fus_out_w, m->fus_out_b, E, E, st, &m->embd_fc_wf, &m->embd_fc_s, &m->embd_fc_c)) return -1;
   }
-  for (int i = 0; i < c.n_embd_convs; ++i) {
+  for (int i = 0, sv = vid_stride_of(c); i < c.n_embd_convs; ++i, sv = std::max(sv / 2, 1)) {
     const std::string s = std::to_string(i);
-    GET("vid_net.embd_convs." + s + ".conv.weight", SH(E, E, 3), t);
+    const int taps = sv > 1 ? 5 : 3;                 // vid_net.stride > 1: k5 / stride 2 / padding 2 (video_net.py:62-70)
+    GET("vid_net.embd_convs." + s + ".conv.weight", SH(E, E, taps), t);
     const float* pk;
-    if (pack3(m, t, E, E, 3, 0, 2, 1, st, &pk)) return -1;
-    SPLIT(pk, E, 3 * E);
+    if (pack3(m, t, E, E, taps, 0, 2, 1, st, &pk)) return -1;
+    SPLIT(pk, E, taps * E);
     m->embd_conv.push_back(pk);
     const float *lw, *lb;
     GET("vid_net.embd_norms." + s + ".weight", SH(E), lw); GET("vid_net.embd_norms." + s + ".bias", SH(E), lb);
@@ -649,7 +654,15 @@ static int finalize(dcf_model* m, hipStream_t st) {
     if (resolve_encoder(m, "vid_net.stem." + std::to_string(i), E, st, w)) return -1;
     m->stem.push_back(w);
   }
+  m->pool_w.clear();
   for (int i = 0; i < L; ++i) {
+    if (c.pool_only) {
+      const float* pk;
+      GET("vid_net.branch." + std::to_string(i) + ".conv.weight", SH(E, 3), t);
+      if (pack3(m, t, 1, E, 3, 0, 2, 1, st, &pk)) return -1;
+      m->pool_w.push_back(pk);
+      continue;
+    }
     EncW w{};
     if (resolve_encoder(m, "vid_net.branch." + std::to_string(i), E, st, w)) return -1;
     m->branch.push_back(w);
@@ -699,6 +712,8 @@ struct Arena {
 struct Buffers {
   float *P1, *P2, *tn, *partial, *correl, *gate;
   uint8_t *mask_all, *nbr_all, *kvmask, *maskv;
+  uint8_t *mask_pre, *nbr_pre;                // vid_net.stride > 1: masks / neighbour flags of the input-resolution levels T0, T0/2, .. T0/stride
+  float* col5;                                // vid_net.stride > 1: [B*T0/2][5E] rows of a k5 / stride-2 embedding convolution
   float *X, *R[7], *H2, *HID, *F, *HA, *HB, *HC, *HD, *logits1, *tcnA, *tcnB, *kvn, *Kt, *Vt;
   unsigned short* kvimg;                      // [B] K / V^T fragment images of the projected text (dec_chain.hip)
   float* kmadd;                               // [B][64] additive key mask
@@ -708,7 +723,8 @@ struct Buffers {
 
 static void carve(Arena& a, const dcf_config& c, int T0, int B, int nq, int S, int Lk, int nvid, Buffers& b) {
   const size_t rows0 = (size_t)B * T0, rowsAll = (size_t)B * S;
-  const size_t rowsF = (c.model_kind == 1 || c.second_fusion) ? rowsAll : rows0;   // rows the fusion stack sees
+  const size_t rowsF = std::max(rows0, (c.model_kind == 1 || c.second_fusion) ? rowsAll : (size_t)0);   // rows the fusion stack sees
+  const bool strided = vid_stride_of(c) > 1;
   const int E = c.E, EH = c.E + TCN_HID;
   b.P1 = a.take<float>((size_t)nvid * T0 * E);
   b.P2 = a.take<float>((size_t)nvid * T0 * E);
@@ -719,6 +735,9 @@ static void carve(Arena& a, const dcf_config& c, int T0, int B, int nq, int S, i
   b.gate = a.take<float>(rows0);
   b.mask_all = a.take<uint8_t>(rowsAll);
   b.nbr_all = a.take<uint8_t>(rowsAll);
+  b.mask_pre = a.take<uint8_t>(strided ? 2 * rows0 : 0);
+  b.nbr_pre = a.take<uint8_t>(strided ? 2 * rows0 : 0);
+  b.col5 = a.take<float>(strided ? rows0 / 2 * 5 * E : 0);
   b.kvmask = a.take<uint8_t>((size_t)B * Lk);
   b.X = a.take<float>(rows0 * E);
   for (int i = 0; i < 7; ++i) b.R[i] = a.take<float>((i < 3 ? rowsF : rows0) * E);
@@ -1301,10 +1320,17 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
     DCF_CHECK(tot == nq, "dcf_forward_eval: query counts do not add up");
   }
   const uint8_t* vid_mask = vs.mask[0];
-  DCF_CHECK(T0 % (1 << (L - 1)) == 0, "T=%d must be a multiple of 2^(levels-1)=%d", T0, 1 << (L - 1));
+  // vid_net.stride = sv > 1 (video_net.py:59-74, worker_v2.py:285-286): vid_map and the early fusion run on the T0 input clips, the first
+  // log2(sv) embedding convolutions halve the sequence, the pyramid starts at Tp = T0 / sv
+  const int sv = vid_stride_of(c);
+  int npre = 0;
+  while ((1 << npre) < sv) ++npre;
+  DCF_CHECK(T0 % (sv << (L - 1)) == 0, "T=%d must be a multiple of vid_net.stride * 2^(levels-1)=%d", T0, sv << (L - 1));
+  const int Tp = T0 / sv;
   const int half = c.win / 2;
-  DCF_CHECK(half == 0 || (T0 >> (L - 1)) % half == 0, "T=%d: coarsest level must be a multiple of win//2=%d (blocks.py:216)", T0, half);
-  if (c.use_abs_pe) DCF_CHECK(m->pe && m->pe_T == T0, "position encoding for T=%d not set (dcf_model_set_pe)", T0);
+  DCF_CHECK(half == 0 || c.pool_only || (Tp >> (L - 1)) % half == 0, "T=%d: coarsest level must be a multiple of win//2=%d (blocks.py:216)", T0, half);
+  if (c.use_abs_pe) DCF_CHECK(m->pe && m->pe_T == Tp, "position encoding for T=%d not set (dcf_model_set_pe)", Tp);
+  DCF_CHECK(!(gate_override && sv > 1), "the externally gated (T-sharded) forward takes vid_net.stride = 1");
   const int Bmax = std::min(nq, c.max_batch > 0 ? c.max_batch : 8);
   DCF_CHECK(Bmax <= DCF_MAX_BATCH, "max_batch %d > %d", Bmax, DCF_MAX_BATCH);
   DCF_CHECK(nvid == 1 || Bmax <= 16, "several videos per forward need max_batch <= 16 (got %d)", Bmax);
@@ -1314,7 +1340,7 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
     Lk = std::max(Lk, (int)text_len[q]);
   }
   int S = 0;
-  for (int l = 0; l < L; ++l) S += T0 >> l;
+  for (int l = 0; l < L; ++l) S += Tp >> l;
 
   // ---- workspace
   Buffers b{};
@@ -1373,9 +1399,10 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
   for (int q0 = 0; q0 < nq; q0 += Bmax) {
     const int B = std::min(Bmax, nq - q0);
     Plan* pl;
-    TRY(get_plan(m, T0, B, st, &pl));
+    TRY(get_plan(m, Tp, B, st, &pl));
     const LevelTable& lt = pl->lt;
-    const int rows0 = B * T0, rowsAll = B * S;
+    const int rows0 = B * T0, rowsP = B * Tp, rowsAll = B * S;
+    uint8_t* mask_in = sv > 1 ? b.mask_pre : b.mask_all;      // validity of the T0 input clips (gate stage)
     unsigned long long vmap = 0;           // video of batch element i in nibble i (B <= 16 with several videos, <= 16 videos)
     for (int i = 0; i < B && i < 16; ++i) vmap |= (unsigned long long)video_of[q0 + i] << (4 * i);
 
@@ -1383,14 +1410,22 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
     if (gate_override) {
       // T-sharded videos: the gate was selected globally (all-gathered scores) by the caller
       hipLaunchKernelGGL(k_apply_gate, dim3((rows0 + 255) / 256), dim3(256), 0, st, gate_override + (int64_t)q0 * T0, vid_mask,
-                         b.gate, b.mask_all, T0, rows0, c.msf);
+                         b.gate, mask_in, T0, rows0, c.msf);
       DCF_HIP(hipGetLastError());
     } else {
-      GateArgs ga{b.correl, vid_mask, b.gate, b.mask_all, T0, B, q0, c.sn, c.msf, (double)c.sratio, vmap};
+      GateArgs ga{b.correl, vid_mask, b.gate, mask_in, T0, B, q0, c.sn, c.msf, (double)c.sratio, vmap};
       TRY(launch_gate(ga, st));
     }
-    TRY(launch_pyramid_masks(b.mask_all, b.nbr_all, B, T0, L, rowsAll, st));
-    const uint8_t* mask0 = b.mask_all;
+    int pre_off = 0;                              // first row of the last input-resolution level (= pyramid level 0) in mask_pre
+    if (sv > 1) {
+      int rows_pre = 0;
+      for (int j = 0; j <= npre; ++j) { if (j == npre) pre_off = rows_pre; rows_pre += B * (T0 >> j); }
+      TRY(launch_pyramid_masks(b.mask_pre, b.nbr_pre, B, T0, npre + 1, rows_pre, st));       // mask_j[i] = mask_0[i << j] (blocks.py:101-105)
+      DCF_HIP(hipMemcpyAsync(b.mask_all, b.mask_pre + pre_off, (size_t)rowsP, hipMemcpyDeviceToDevice, st));
+    }
+    TRY(launch_pyramid_masks(b.mask_all, b.nbr_all, B, Tp, L, rowsAll, st));
+    const uint8_t* mask0 = mask_in;               // input clips: vid_map, early fusion, embd_fc
+    const uint8_t* maskP = b.mask_all;            // pyramid level 0
 
     // ---- vid_map (model.py:543-555)
     TRY(launch_vidmap_combine(m->vid_w1 ? b.P1 : nullptr, m->vid_w2 ? b.P2 : nullptr, m->vid_map_b, b.gate, mask0,
@@ -1432,8 +1467,33 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
         ge.flags = G_AMASK; ge.rowmask = mask0;
         TRY(run_gemm(m, &ge, 1, A_ROWS, st));
       }   // late fusion (PtTransformer): b.X already IS embd_fc([gate*vid ; shallow] * mask), model.py:132-140
+      if (sv > 1) {
+        // vid_net.stride > 1 (video_net.py:62-73): while the sequence is longer than the pyramid's, a convolution is k5 / stride 2 /
+        // padding 2 on the masked input -- its five taps gathered into rows [B T/2][5E] and one plain GEMM --, then k3 as usual; every
+        // one followed by LayerNorm + ReLU, the last one by + pe * mask (video_net.py:136-152)
+        int Tc = T0, off = 0;
+        for (int i = 0; i < c.n_embd_convs; ++i) {
+          const bool with_pe = c.use_abs_pe && i == c.n_embd_convs - 1;
+          if (Tc > Tp) {
+            TRY(launch_im2col5s2(b.X, E, b.mask_pre + off, b.col5, B, Tc, E, st));
+            GemmArgs g = gemm(b.col5, 5 * E, m->embd_conv[i], nullptr, b.R[0], E, B * (Tc / 2), E, 5 * E);
+            TRY(run_gemm(m, &g, 1, A_ROWS, st));
+            off += B * Tc;
+            Tc /= 2;
+          } else {
+            GemmArgs g = gemm(b.X, E, m->embd_conv[i], nullptr, b.R[0], E, B * Tc, E, 3 * E);
+            g.cin = E; g.nbr = b.nbr_pre + off;
+            TRY(run_gemm(m, &g, 1, A_ROWS_TAP3, st));
+          }
+          LnArgs ln{}; ln.X = b.R[0]; ln.ldx = E; ln.Y = b.X; ln.ldy = E; ln.w = m->embd_ln_w[i]; ln.b = m->embd_ln_b[i];
+          ln.rows = B * Tc; ln.C = E; ln.relu = 1;
+          if (with_pe) { ln.pe = m->pe; ln.mask = b.mask_pre + off; ln.T = Tc; }
+          TRY(launch_ln(ln, st));
+        }
+        DCF_CHECK(Tc == Tp, "vid_net.arch[0]=%d embedding convolutions cannot divide the sequence by vid_net.stride=%d (video_net.py:53)", c.n_embd_convs, sv);
+      }
       int epend = -1, epend_w = 0;                  // embedding layer whose LayerNorm + ReLU the next convolution applies on load
-      for (int i = 0; i < c.n_embd_convs; ++i) {
+      for (int i = 0; i < c.n_embd_convs && sv == 1; ++i) {
         GemmArgs g = gemm(b.X, E, m->embd_conv[i], nullptr, b.R[0], E, rows0, E, 3 * E);
         g.cin = E; g.nbr = b.nbr_all;
         const bool with_pe = c.use_abs_pe && i == c.n_embd_convs - 1;
@@ -1477,8 +1537,8 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
       }
       for (size_t i = 0; i < m->stem.size(); ++i) {
         // stem layers work in place at level 0: out -> R[3] is free for stride 1, then copy back via swap of roles
-        TRY(run_encoder(m, m->stem[i], b, b.X, E, mask0, mask0, B, T0, 1, b.R[3], E, st));
-        DCF_HIP(hipMemcpyAsync(b.X, b.R[3], (size_t)rows0 * E * 4, hipMemcpyDeviceToDevice, st));
+        TRY(run_encoder(m, m->stem[i], b, b.X, E, maskP, maskP, B, Tp, 1, b.R[3], E, st));
+        DCF_HIP(hipMemcpyAsync(b.X, b.R[3], (size_t)rowsP * E * 4, hipMemcpyDeviceToDevice, st));
       }
       const int ldf = E + TCN_HID;
       const float* xin = b.X;
@@ -1488,14 +1548,15 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
         const uint8_t* mi = b.mask_all + lt.start[l > 0 ? l - 1 : 0];
         const uint8_t* mo = b.mask_all + lt.start[l];
         float* xo = b.F + (int64_t)lt.start[l] * ldf;
-        TRY(run_encoder(m, m->branch[l], b, xin, ldx, mi, mo, B, l > 0 ? lt.T[l - 1] : T0, stride, xo, ldf, st));
+        if (c.pool_only) TRY(launch_dwconv3(xin, ldx, mi, m->pool_w[l], xo, ldf, B, l > 0 ? lt.T[l - 1] : Tp, stride, E, st));   // video_net.py:107-109
+        else TRY(run_encoder(m, m->branch[l], b, xin, ldx, mi, mo, B, l > 0 ? lt.T[l - 1] : Tp, stride, xo, ldf, st));
         xin = xo; ldx = ldf;
       }
     }
 
     // ---- second / late fusion over the whole pyramid (model.py:443-444, :66-67; fusion.py:68-78), in place on F
     if (c.model_kind == 1 || c.second_fusion)
-      TRY(run_fusion(m, b, b.F, E + TCN_HID, B, T0, &lt, b.mask_all, b.nbr_all, dm, Lk, b.F, E + TCN_HID, st));
+      TRY(run_fusion(m, b, b.F, E + TCN_HID, B, Tp, &lt, b.mask_all, b.nbr_all, dm, Lk, b.F, E + TCN_HID, st));
 
     if (c.model_kind != 0) {
       // ---- PtTransformer / PtTransformerEarlyFusion.fuse_and_predict (model.py:65-69, :204-209): cls_head / reg_head on the pyramid
@@ -1516,7 +1577,7 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
       ra.host_b_pw = m->tcn_bp.data(); ra.host_ln_w = m->tcn_lnw.data(); ra.host_ln_b = m->tcn_lnb.data();
       ra.w_out = m->tcn_out_w; ra.b_out = m->tcn_out_b;
       ra.bufA = b.tcnA; ra.bufB = b.tcnB; ra.F = b.F; ra.ldf = E + TCN_HID; ra.E = E;
-      ra.B = B; ra.T0 = T0; ra.n_levels = L; ra.n_layers = L;
+      ra.B = B; ra.T0 = Tp; ra.n_levels = L; ra.n_layers = L;
       ra.f16 = m->gemm_terms == GEMM_F16X3; ra.status = m->status;
       TRY(launch_refine(ra, lt, st));
     }
@@ -1611,7 +1672,7 @@ static int text_encode(dcf_model* m, const float* tokens, const uint8_t* token_m
 extern "C" {
 
 const char* dcf_last_error(void) { return dcf::g_err.c_str(); }
-int dcf_abi_version(void) { return 6; }
+int dcf_abi_version(void) { return 7; }
 
 int dcf_model_create(const dcf_config* cfg, dcf_model** out) {
   DCF_CHECK(cfg && out, "dcf_model_create: null argument");
@@ -1623,6 +1684,13 @@ int dcf_model_create(const dcf_config* cfg, dcf_model** out) {
   DCF_CHECK(cfg->fusion_layers >= 0 && cfg->head_layers >= 0 && cfg->n_embd_convs >= 0 && cfg->n_stem >= 0, "negative layer count");
   DCF_CHECK(cfg->sn >= 1, "sn must be >= 1");
   DCF_CHECK(cfg->model_kind >= 0 && cfg->model_kind <= 2, "model_kind must be 0 (iterative early fusion), 1 (late fusion) or 2 (early fusion)");
+  {
+    const int sv = cfg->vid_stride > 1 ? cfg->vid_stride : 1;
+    int lg = 0;
+    while ((1 << lg) < sv) ++lg;
+    DCF_CHECK((sv & (sv - 1)) == 0 && cfg->n_embd_convs >= lg, "vid_net.stride=%d must be a power of two with arch[0]=%d >= log2(stride) (video_net.py:52-53)",
+              sv, cfg->n_embd_convs);
+  }
   int ndev = 0;
   DCF_HIP(hipGetDeviceCount(&ndev));
   DCF_CHECK(ndev > 0, "no HIP device");
@@ -1790,7 +1858,8 @@ int dcf_numerics_status_async(dcf_model* m, int32_t* host_dst, void* stream) {
 
 int64_t dcf_points_per_query(const dcf_model* m, int64_t T) {
   int64_t s = 0;
-  for (int l = 0; l < m->cfg.n_levels; ++l) s += T >> l;
+  const int64_t Tp = T / dcf::vid_stride_of(m->cfg);     // the pyramid starts behind the strided embedding convolutions
+  for (int l = 0; l < m->cfg.n_levels; ++l) s += Tp >> l;
   return s;
 }
 

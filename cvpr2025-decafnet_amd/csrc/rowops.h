@@ -77,6 +77,11 @@ struct TextLnArgs {
 int launch_rowflags(const uint8_t* mask, uint8_t* nbr, int T, int rows, hipStream_t st);
 int launch_pyramid_masks(uint8_t* mask_all, uint8_t* nbr_all, int B, int T0, int L, int rows_all, hipStream_t st);
 int launch_mask_down(const uint8_t* in, uint8_t* out, int rows_out, hipStream_t st);
+// vid_net.stride > 1: the row matrix [B*T/2][5 C] of a k5 / stride 2 / padding 2 MaskedConv1D's masked input (video_net.py:62-70)
+int launch_im2col5s2(const float* X, int64_t ldx, const uint8_t* mask, float* col, int B, int T, int C, hipStream_t st);
+// vid_net.pool_only: depthwise k3 MaskedConv1D, stride 1 / 2, w [3][C], output not masked (video_net.py:107-109, blocks.py:99)
+int launch_dwconv3(const float* X, int64_t ldx, const uint8_t* mask, const float* w, float* Y, int64_t ldy, int B, int T, int stride,
+                   int C, hipStream_t st);
 int launch_vidmap_combine(const float* P1, const float* P2, const float* bias, const float* gate, const uint8_t* mask,
                           const float* w3, const float* correl, float* X, int T, int rows, int E, unsigned long long vmap,
                           hipStream_t st);

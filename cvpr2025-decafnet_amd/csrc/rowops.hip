@@ -482,6 +482,46 @@ __global__ void k_rows_to_chanmajor(const float* __restrict__ X, float* __restri
   out[i] = X[(int64_t)r * C + c];
 }
 
+// A operand of a k5 / stride 2 / padding 2 MaskedConv1D (vid_net.stride > 1, video_net.py:62-70) as rows:
+// col[b * T/2 + t][j * C + c] = (x * mask)[b][2 t - 2 + j][c], zero outside the sequence.  One thread per 4 channels of a tap.
+__global__ void k_im2col5s2(const float* __restrict__ X, int64_t ldx, const uint8_t* __restrict__ mask, float* __restrict__ col,
+                            int B, int T, int C) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = C / 4, To = T / 2;
+  if (i >= (int64_t)B * To * 5 * c4) return;
+  const int c = (int)(i % c4) * 4;
+  const int j = (int)((i / c4) % 5);
+  const int64_t ro = i / (5 * c4);
+  const int b = (int)(ro / To), t = (int)(ro - (int64_t)b * To);
+  const int u = 2 * t - 2 + j;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (u >= 0 && u < T && mask[(int64_t)b * T + u]) v = *reinterpret_cast<const float4*>(X + ((int64_t)b * T + u) * ldx + c);
+  *reinterpret_cast<float4*>(col + ro * 5 * C + (int64_t)j * C + c) = v;
+}
+
+// a pool_only branch layer (video_net.py:107-109): depthwise k3 MaskedConv1D, stride 1 or 2, padding 1, no bias; the output is
+// NOT masked (blocks.py:99), the mask is sampled at the stride (blocks.py:101-105).  w: [3][C] (tap-major).
+__global__ void k_dwconv3(const float* __restrict__ X, int64_t ldx, const uint8_t* __restrict__ mask, const float* __restrict__ w,
+                          float* __restrict__ Y, int64_t ldy, int B, int T, int stride, int C) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = C / 4, To = T / stride;
+  if (i >= (int64_t)B * To * c4) return;
+  const int c = (int)(i % c4) * 4;
+  const int64_t ro = i / c4;
+  const int b = (int)(ro / To), t = (int)(ro - (int64_t)b * To);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int u = stride * t - 1 + j;
+    if (u < 0 || u >= T || !mask[(int64_t)b * T + u]) continue;
+    const float4 x = *reinterpret_cast<const float4*>(X + ((int64_t)b * T + u) * ldx + c);
+    const float4 ww = *reinterpret_cast<const float4*>(w + (int64_t)j * C + c);
+    acc.x = __builtin_fmaf(x.x, ww.x, acc.x); acc.y = __builtin_fmaf(x.y, ww.y, acc.y);
+    acc.z = __builtin_fmaf(x.z, ww.z, acc.z); acc.w = __builtin_fmaf(x.w, ww.w, acc.w);
+  }
+  *reinterpret_cast<float4*>(Y + ro * ldy + c) = acc;
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
@@ -589,6 +629,26 @@ int launch_text_embed(const TextEmbedArgs& a, hipStream_t st) {
   const int Lk = a.Lq + ((a.bkgd || a.pool) ? 1 : 0);
   DCF_CHECK(a.W || a.Ct == a.TE, "text_embed: no embedding weight needs in_dim == embd_dim");
   hipLaunchKernelGGL(k_text_embed, dim3(Lk), dim3(256), 0, st, a);
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_im2col5s2(const float* X, int64_t ldx, const uint8_t* mask, float* col, int B, int T, int C, hipStream_t st) {
+  DCF_CHECK(B > 0 && T > 0 && T % 2 == 0 && C % 4 == 0 && ldx % 4 == 0, "launch_im2col5s2: T must be even, C and the row pitch multiples of 4");
+  const int64_t n = (int64_t)B * (T / 2) * 5 * (C / 4);
+  ProfScope prof("im2col5s2", st, 0.0, 4.0 * (double)B * T * C * 3.5);
+  hipLaunchKernelGGL(k_im2col5s2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, X, ldx, mask, col, B, T, C);
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_dwconv3(const float* X, int64_t ldx, const uint8_t* mask, const float* w, float* Y, int64_t ldy, int B, int T, int stride,
+                   int C, hipStream_t st) {
+  DCF_CHECK(B > 0 && T > 0 && (stride == 1 || stride == 2) && T % stride == 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0,
+            "launch_dwconv3: stride 1 or 2 dividing T, C and the row pitches multiples of 4");
+  const int64_t n = (int64_t)B * (T / stride) * (C / 4);
+  ProfScope prof("dwconv3", st, 6.0 * (double)B * (T / stride) * C, 4.0 * (double)B * T * C * (1.0 + 1.0 / stride));
+  hipLaunchKernelGGL(k_dwconv3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, X, ldx, mask, w, Y, ldy, B, T, stride, C);
   DCF_HIP(hipGetLastError());
   return 0;
 }

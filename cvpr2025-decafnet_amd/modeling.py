@@ -157,22 +157,31 @@ class XAttNFusion(nn.Module):
 
 
 class VideoTransformer(nn.Module):
-    """video_net.py:20-121 (stride 1)."""
+    """video_net.py:20-121.  ``stride`` = s > 1: the first log2(s) embedding convolutions are k5 / stride 2 / padding 2
+    (:59-74); ``pool_only``: a branch layer is one depthwise k3 MaskedConv1D (:98-111)."""
 
     def __init__(self, in_dim, embd_dim, max_seq_len, n_heads, mha_win_size, stride=1, arch=(2, 1, 6),
                  use_abs_pe=False, pool_only=False, **_):
         super().__init__()
-        if stride != 1 or pool_only:
-            raise NotImplementedError('vid_net.stride != 1 / pool_only are not on the hot path')
         assert len(arch) == 3
+        assert stride >= 1 and stride & (stride - 1) == 0 and arch[0] >= int(math.log2(stride))      # video_net.py:52-53
         self.max_seq_len, self.embd_dim, self.arch = max_seq_len, embd_dim, tuple(arch)
         self.n_heads, self.mha_win_size, self.use_abs_pe = n_heads, mha_win_size, use_abs_pe
+        self.stride, self.pool_only = int(stride), bool(pool_only)
         self.embd_fc = MaskedConv1D(in_dim, embd_dim, 1)
-        self.embd_convs = nn.ModuleList(MaskedConv1D(embd_dim, embd_dim, 3, 1, 1, bias=False) for _ in range(arch[0]))
+        convs, s = [], int(stride)
+        for _i in range(arch[0]):
+            convs.append(MaskedConv1D(embd_dim, embd_dim, 5 if s > 1 else 3, 2 if s > 1 else 1, 2 if s > 1 else 1, bias=False))
+            s = max(s // 2, 1)
+        self.embd_convs = nn.ModuleList(convs)
         self.embd_norms = nn.ModuleList(LayerNorm(embd_dim) for _ in range(arch[0]))
         self.stem = nn.ModuleList(TransformerEncoder(embd_dim, 1, n_heads, mha_win_size) for _ in range(arch[1]))
-        self.branch = nn.ModuleList(TransformerEncoder(embd_dim, 2 if i > 0 else 1, n_heads, mha_win_size)
-                                    for i in range(arch[2]))
+        if pool_only:
+            self.branch = nn.ModuleList(MaskedConv1D(embd_dim, embd_dim, 3, 2 if i > 0 else 1, 1, groups=embd_dim, bias=False)
+                                        for i in range(arch[2]))
+        else:
+            self.branch = nn.ModuleList(TransformerEncoder(embd_dim, 2 if i > 0 else 1, n_heads, mha_win_size)
+                                        for i in range(arch[2]))
         for mod in self.modules():
             if isinstance(mod, nn.Conv1d) and mod.bias is not None:
                 nn.init.zeros_(mod.bias)
@@ -550,8 +559,9 @@ class PtTransformerEarlyFusionIterative(nn.Module):
             q += sizes[b]
         pe = None
         if self.vid_net.use_abs_pe:
-            pe = self._position_encoding(T, dev)
-            _lib.check(lib.dcf_model_set_pe(eng.handle, _lib.ptr(pe), T), 'dcf_model_set_pe')
+            Tp = T // self.vid_net.stride            # the pyramid (and its position encoding) starts behind the strided convolutions
+            pe = self._position_encoding(Tp, dev)
+            _lib.check(lib.dcf_model_set_pe(eng.handle, _lib.ptr(pe), Tp), 'dcf_model_set_pe')
         S = lib.dcf_points_per_query(eng.handle, T)
         logits1 = torch.empty(nq, S, device=dev, dtype=torch.float32)
         logits2 = torch.empty(nq, S, device=dev, dtype=torch.float32)
@@ -563,7 +573,7 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         self._last_inputs = (keep, pe, enc, enc_mask)
         self._last_flat = (logits2, offsets, masks)
         self._probe_numerics()
-        sizes_l = [T >> l for l in range(self.vid_net.arch[2])]
+        sizes_l = [(T // self.vid_net.stride) >> l for l in range(self.vid_net.arch[2])]
         return (tuple(logits1.split(sizes_l, 1)), tuple(logits2.split(sizes_l, 1)), tuple(offsets.split(sizes_l, 1)),
                 tuple(masks.split(sizes_l, 1)))
 
@@ -607,6 +617,7 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         c.gemm_mode = self.gemm_mode
         c.model_kind, c.second_fusion = self.MODEL_KIND, int(bool(self.second_fusion))
         c.xattn_affine = int(len(self.fusion.layers) > 0 and self.fusion.layers[0].xattn_mode == 'affine')
+        c.vid_stride, c.pool_only = vn.stride, int(vn.pool_only)
         _text_config(c, self.text_net)
         return c
 
@@ -710,8 +721,9 @@ class PtTransformerEarlyFusionIterative(nn.Module):
             tptr[q], mptr[q], tlen[q] = t.data_ptr(), m.data_ptr(), t.size(1)
         pe = None
         if self.vid_net.use_abs_pe:
-            pe = self._position_encoding(T, dev)
-            _lib.check(lib.dcf_model_set_pe(eng.handle, _lib.ptr(pe), T), 'dcf_model_set_pe')
+            Tp = T // self.vid_net.stride            # the pyramid (and its position encoding) starts behind the strided convolutions
+            pe = self._position_encoding(Tp, dev)
+            _lib.check(lib.dcf_model_set_pe(eng.handle, _lib.ptr(pe), Tp), 'dcf_model_set_pe')
         S = lib.dcf_points_per_query(eng.handle, T)
         okey = (nq, S, dev)
         if self.reuse_output_buffers and okey in self._out_cache:
@@ -728,7 +740,7 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         self._last_flat = (logits, offsets, masks)
         self._probe_numerics()
         L = self.vid_net.arch[2]
-        sizes = [T >> l for l in range(L)]
+        sizes = [(T // self.vid_net.stride) >> l for l in range(L)]
         out, q = [], 0
         for v in range(nv):
             n = nqs[v]
@@ -776,9 +788,10 @@ class PtTransformerEarlyFusionIterative(nn.Module):
             keep += [t, m]
             tptr[q], mptr[q], tlen[q] = t.data_ptr(), m.data_ptr(), t.size(1)
         if self.vid_net.use_abs_pe:
-            pe = self._position_encoding(T, dev) if pe_tokens is None else pe_tokens.contiguous().float()
-            assert pe.shape == (T, self.E)
-            _lib.check(lib.dcf_model_set_pe(eng.handle, _lib.ptr(pe), T), 'dcf_model_set_pe')
+            Tp = T // self.vid_net.stride
+            pe = self._position_encoding(Tp, dev) if pe_tokens is None else pe_tokens.contiguous().float()
+            assert pe.shape == (Tp, self.E)
+            _lib.check(lib.dcf_model_set_pe(eng.handle, _lib.ptr(pe), Tp), 'dcf_model_set_pe')
         else:
             pe = None
         S = lib.dcf_points_per_query(eng.handle, T)
@@ -800,7 +813,7 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         self._last_flat = (logits, offsets, masks)
         self._probe_numerics()
         L = self.vid_net.arch[2]
-        sizes = [T >> l for l in range(L)]
+        sizes = [(T // self.vid_net.stride) >> l for l in range(L)]
         lg = [tuple(x.unsqueeze(0) for x in logits[q].split(sizes)) for q in range(nq)]
         of = [tuple(x.unsqueeze(0) for x in offsets[q].split(sizes)) for q in range(nq)]
         mk = [tuple(x.unsqueeze(0) for x in masks[q].split(sizes)) for q in range(nq)]

@@ -69,6 +69,11 @@ typedef struct dcf_config {
   /* ABI version 5 */
   int32_t xattn_affine;   /* opt.model.fusion.xattn_mode: 0 = 'adaln' (the decoder modulates LayerNorm(q), blocks.py:623-624,643),
                            * 1 = 'affine' (it modulates q itself: nn.Identity, blocks.py:625-626)   */
+  /* ABI version 7 */
+  int32_t vid_stride;     /* opt.model.vid_net.stride (video_net.py:39,59-74): a power of two; the first log2(stride) embedding
+                           * convolutions are k5 / stride 2 / padding 2 and the pyramid starts at T / stride.  0 reads as 1 */
+  int32_t pool_only;      /* opt.model.vid_net.pool_only (video_net.py:98-111): a branch layer is one depthwise k3 MaskedConv1D
+                           * (vid_net.branch.{i}.conv.weight, stride 1 at level 0, 2 above) instead of a TransformerEncoder */
 } dcf_config;
 
 int dcf_model_create(const dcf_config* cfg, dcf_model** out);

@@ -267,16 +267,24 @@ def xattn_fusion_pyramid(sd: SD, cfg, fpn, fpn_masks, text: Tensor, text_mask: T
 
 
 def video_transformer(sd: SD, cfg, x: Tensor, mask: Tensor, p: str = 'vid_net', pe_override=None):
-    """VideoTransformer.forward video_net.py:123-164 (eval, stride-1 embedding convs).
+    """VideoTransformer.forward video_net.py:123-164 (eval).  ``cfg.stride`` = s > 1: the first log2(s) embedding convolutions are
+    k5 / stride 2 / padding 2 (video_net.py:62-73), each halving the sequence and its mask; ``cfg.pool_only``: a branch layer is one
+    depthwise k3 MaskedConv1D (stride 1 at level 0, 2 above) instead of a TransformerEncoder (video_net.py:98-111).
     ``pe_override`` (E, T): a window's slice of a longer video's position encoding (T-sharding tests)."""
     if mask.ndim == 2:
         mask = mask.unsqueeze(1)
-    assert cfg.get('stride', 1) == 1, 'only vid_net.stride == 1 is on the hot path'
+    stride = int(cfg.get('stride', 1))
+    assert stride >= 1 and stride & (stride - 1) == 0
     n_convs, n_stem, n_branch = cfg['arch']
     x, _ = masked_conv1d(x, mask, sd[p + '.embd_fc.conv.weight'], sd[p + '.embd_fc.conv.bias'])
     for i in range(n_convs):
-        x, mask = masked_conv1d(x, mask, sd[f'{p}.embd_convs.{i}.conv.weight'], None, 1, 1)
+        if stride > 1:
+            x, mask = masked_conv1d(x, mask, sd[f'{p}.embd_convs.{i}.conv.weight'], None, 2, 2)
+        else:
+            x, mask = masked_conv1d(x, mask, sd[f'{p}.embd_convs.{i}.conv.weight'], None, 1, 1)
         x = F.relu(_ln(sd, f'{p}.embd_norms.{i}', x))
+        stride = max(stride // 2, 1)
+    assert stride == 1, 'vid_net.arch[0] < log2(vid_net.stride) (video_net.py:53)'
     t = x.size(-1)
     if cfg['use_abs_pe']:
         if pe_override is None:
@@ -288,8 +296,11 @@ def video_transformer(sd: SD, cfg, x: Tensor, mask: Tensor, p: str = 'vid_net', 
         x, mask = transformer_encoder(sd, f'{p}.stem.{i}', x, mask, 1, cfg['n_heads'], cfg['mha_win_size'])
     fpn, fpn_masks = tuple(), tuple()
     for i in range(n_branch):
-        x, mask = transformer_encoder(sd, f'{p}.branch.{i}', x, mask, 2 if i > 0 else 1,
-                                      cfg['n_heads'], cfg['mha_win_size'])
+        if cfg.get('pool_only', False):
+            x, mask = masked_conv1d(x, mask, sd[f'{p}.branch.{i}.conv.weight'], None, 2 if i > 0 else 1, 1, x.size(1))
+        else:
+            x, mask = transformer_encoder(sd, f'{p}.branch.{i}', x, mask, 2 if i > 0 else 1,
+                                          cfg['n_heads'], cfg['mha_win_size'])
         fpn += (x,)
         fpn_masks += (mask,)
     return fpn, fpn_masks

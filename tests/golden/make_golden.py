@@ -309,6 +309,22 @@ E2E_CASES = {
     'affine': dict(opt=dict(D=64, E=64, TE=32, text_in=32, n_levels=4, win=5, n_heads=4, sn=16, sratio=0.3, msf=True, norm=True,
                             max_seq_len=128, text_layers=1, text_max_len=24, xattn_mode='affine'),
                    T=256, vid_len=251, nq=2, lq=6, wseed=33, iseed=34),
+    # opt.model.vid_net.stride = 2 (video_net.py:59-74): the first embedding convolution is k5 / stride 2 / padding 2, the pyramid
+    # starts at T / 2 (worker_v2.py:285-286: input_vid_len = max_vid_len * vid_stride); position encoding on the halved sequence
+    'stride2': dict(opt=dict(D=64, E=64, TE=32, text_in=32, n_levels=3, win=5, n_heads=4, sn=16, sratio=0.3, msf=True, norm=True,
+                             max_seq_len=128, text_layers=1, text_max_len=24, vid_stride=2),
+                    T=256, vid_len=243, nq=2, lq=6, wseed=101, iseed=102),
+    # stride 4: both embedding convolutions downsample; the resampled position encoding (T / 4 > max_seq_len)
+    'stride4': dict(opt=dict(D=64, E=64, TE=32, text_in=32, n_levels=3, win=5, n_heads=2, sn=16, sratio=0.4, msf=True, norm=True,
+                             max_seq_len=64, text_layers=1, text_max_len=24, vid_stride=4),
+                    T=512, vid_len=489, nq=2, lq=5, wseed=103, iseed=104),
+    # opt.model.vid_net.pool_only (video_net.py:98-111): every branch layer is one depthwise k3 MaskedConv1D (stride 1, then 2)
+    'pool': dict(opt=dict(D=64, E=64, TE=32, text_in=32, n_levels=4, win=5, n_heads=4, sn=16, sratio=0.3, msf=True, norm=True,
+                          max_seq_len=128, text_layers=1, text_max_len=24, pool_only=True),
+                 T=256, vid_len=250, nq=2, lq=7, wseed=105, iseed=106),
+    'pool_stride2': dict(opt=dict(D=64, E=64, TE=32, text_in=32, n_levels=3, win=5, n_heads=4, sn=8, sratio=0.5, msf=False, norm=True,
+                                  max_seq_len=128, text_layers=1, text_max_len=24, pool_only=True, vid_stride=2, n_stem=1),
+                         T=256, vid_len=231, nq=2, lq=4, wseed=107, iseed=108),
 }
 ONLY = set(filter(None, os.environ.get('ONLY', '').split(',')))
 

@@ -49,7 +49,8 @@ def test_config_struct_layout():
     assert fields == [f[0] for f in pkg._lib.DcfConfig._fields_]
 
 
-@pytest.mark.parametrize('name', ['c1', 'pe', 'nomsf', 'scat', 'sfonly', 'affine', 'late', 'second', 'late_scat', 'early', 'early_single'])
+@pytest.mark.parametrize('name', ['c1', 'pe', 'nomsf', 'scat', 'sfonly', 'affine', 'late', 'second', 'late_scat', 'early', 'early_single',
+                                  'stride2', 'stride4', 'pool', 'pool_stride2'])
 def test_parameter_abi_matches_reference(name):
     """state_dict keys and shapes == the reference model's (captured in the fixture)"""
     pkg = load_pkg()

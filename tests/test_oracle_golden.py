@@ -146,7 +146,7 @@ def test_gate_cases():
 
 
 # ------------------------------------------------------------------ G3
-@pytest.mark.parametrize('name', ['c1', 'pe', 'nomsf', 'scat', 'sfonly', 'affine'])
+@pytest.mark.parametrize('name', ['c1', 'pe', 'nomsf', 'scat', 'sfonly', 'affine', 'stride2', 'stride4', 'pool', 'pool_stride2'])
 def test_end_to_end(name):
     g = Golden(f'e2e_{name}.npz')
     pkg = load_pkg()
