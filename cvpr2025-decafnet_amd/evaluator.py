@@ -191,7 +191,9 @@ class GroundingEvaluator:
         the launch latency of the next forward overlap with GPU work (``run`` does)."""
         logits, offsets, masks = flat
         t0 = time.perf_counter()
-        segs, scores, counts = _nms.collect_segments(logits, offsets, masks, T, self.num_fpn_levels, self.pre_nms_thresh,
+        # the pyramid (and its points) starts at T / vid_stride (video_net.py:59-74); segments go back to input clips in finish_proposals
+        assert window_ext is None or self.vid_stride == 1, 'ext_scores are per input clip: the reference multiplies them at level 0 (worker_v2.py:1150-1156)'
+        segs, scores, counts = _nms.collect_segments(logits, offsets, masks, T // self.vid_stride, self.num_fpn_levels, self.pre_nms_thresh,
                                                      self.pre_nms_topk, self.seg_len_thresh, ext_scores=window_ext)
         self.time_dict['post_process'].append(time.perf_counter() - t0)
         cfg = self.nms_cfg
