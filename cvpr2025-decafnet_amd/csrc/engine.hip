@@ -809,6 +809,7 @@ static int run_gemm(dcf_model* m, GemmArgs* g, int count, GemmAMode mode, hipStr
   }
   if (split && mode == A_CHANMAJOR && (g[0].N % 128 != 0 || g[0].M % 4 != 0)) split = false;
   for (int i = 0; i < count; ++i) DCF_CHECK(split || !(g[i].flags & G_ADALN), "internal: G_ADALN needs the split-operand GEMM");
+  for (int i = 0; i < count; ++i) DCF_CHECK(split || !g[i].score_out, "internal: scores on the side need the split-operand GEMM");
   return split ? launch_gemm_split(g, count, mode, terms, st) : launch_gemm(g, count, mode, st);
 }
 
@@ -910,6 +911,11 @@ static bool can_chain_enc(dcf_model* m, const EncW& w, int rows, int stride, int
          enc_chain_supports(c.E, c.vid_heads, c.win > 0 ? c.win : 99) && rows >= enc_chain_min_rows() && ldx % 4 == 0;
 }
 
+// the sidekick scores as a by-product of the shallow vid_map GEMM (dcf_debug_set_option("fuse_scores", 0) = the scoring kernels)
+static bool fuse_scores_on() {
+  static const bool off = getenv("DCF_NO_FUSE_SCORES") != nullptr;
+  return !off && debug_option("fuse_scores", 1) != 0;
+}
 static int enc_attn_min_rows() {
   const int o = debug_option("enc_attn_min_rows", -1);
   if (o >= 0) return o;
@@ -1361,14 +1367,22 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
   }
   // ---- per video: sidekick scores and the query-independent halves of vid_map
   DCF_CHECK(!(gate_override && c.scat), "opt.model.scat needs the sidekick scores: the externally gated (T-sharded) forward does not take them");
-  if (!gate_override) {                              // the scores of every video's queries: three launches in all
+  // The sidekick scores ride on the shallow half of vid_map where they can: that GEMM streams exactly the (D, T) matrix the scores
+  // are a reduction of, so the scoring pass's read of it (4 KB per clip) disappears; otherwise three launches of their own.
+  bool scores_on_gemm = !gate_override && fuse_scores_on() && m->vid_w2 && m->gemm_terms != 0 && m->wsplit.count(m->vid_w2) &&
+                        m->wsplit_ldw[m->vid_w2] == m->vid_ldw && E % 128 == 0 && T0 % 4 == 0;
+  for (int v = 0; v < nvid; ++v) scores_on_gemm = scores_on_gemm && vs.nq[v] <= GEMM_SCORE_MAXQ;
+  int q_of[DCF_MAX_VIDEOS];                          // first query row of video v in tn / correl
+  for (int v = 0, q_off = 0; v < nvid; q_off += vs.nq[v], ++v) q_of[v] = q_off;
+  if (!gate_override) {                              // the scores of every video's queries
     DCF_CHECK(nvid <= SCORE_MAXVID, "%d videos per forward > %d", nvid, SCORE_MAXVID);
     ScoreArgs sa{};
-    for (int v = 0, q_off = 0; v < nvid; q_off += vs.nq[v], ++v) {
-      sa.shallow[v] = vs.shallow[v]; sa.text_cls[v] = vs.text_cls[v]; sa.nq[v] = vs.nq[v]; sa.qoff[v] = q_off;
+    for (int v = 0; v < nvid; ++v) {
+      sa.shallow[v] = vs.shallow[v]; sa.text_cls[v] = vs.text_cls[v]; sa.nq[v] = vs.nq[v]; sa.qoff[v] = q_of[v];
     }
     sa.nvid = nvid; sa.tn = b.tn; sa.partial = b.partial; sa.correl = b.correl; sa.D = D; sa.T = T0; sa.NQ = nq; sa.norm = c.norm;
-    TRY(launch_sidekick(sa, st));
+    if (scores_on_gemm) TRY(launch_text_cls_norm(sa, st));
+    else TRY(launch_sidekick(sa, st));
   }
   {
     // the deep and shallow halves of vid_map of every video have the same shape: three of them share a grid (blockIdx.z
@@ -1384,7 +1398,14 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
     };
     for (int v = 0; v < nvid; ++v) {
       if (m->vid_w1) { g[ng++] = gemm(vs.vid[v], T0, m->vid_w1, nullptr, b.P1 + (size_t)v * T0 * E, E, T0, E, D); if (ng == 3) TRY(flush()); }
-      if (m->vid_w2) { g[ng++] = gemm(vs.shallow[v], T0, m->vid_w2, nullptr, b.P2 + (size_t)v * T0 * E, E, T0, E, D); if (ng == 3) TRY(flush()); }
+      if (m->vid_w2) {
+        g[ng] = gemm(vs.shallow[v], T0, m->vid_w2, nullptr, b.P2 + (size_t)v * T0 * E, E, T0, E, D);
+        if (scores_on_gemm) {
+          g[ng].score_tn = b.tn + (size_t)q_of[v] * D; g[ng].score_out = b.correl + (size_t)q_of[v] * T0;
+          g[ng].score_nq = vs.nq[v]; g[ng].score_norm = c.norm;
+        }
+        if (++ng == 3) TRY(flush());
+      }
     }
     TRY(flush());
     if (nvid > 1) {                               // the videos' masks side by side: one launch (it was one copy node per video)
@@ -1933,7 +1954,7 @@ int dcf_graph_active(const dcf_model* m) { return m ? m->last_launch : 0; }
 
 int dcf_debug_set_option(const char* name, int32_t value) {
   DCF_CHECK(name && *name, "dcf_debug_set_option: empty name");
-  static const char* known[] = {"dec_chain_min_rows", "enc_chain_min_rows", "enc_attn_min_rows"};
+  static const char* known[] = {"dec_chain_min_rows", "enc_chain_min_rows", "enc_attn_min_rows", "fuse_scores"};
   bool ok = false;
   for (const char* k : known) ok = ok || strcmp(k, name) == 0;
   DCF_CHECK(ok, "dcf_debug_set_option: unknown option '%s'", name);

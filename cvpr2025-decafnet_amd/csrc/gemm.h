@@ -75,6 +75,14 @@ struct GemmArgs {
   int a_stats_slots;
   const float* a_ln_g;
   const float* a_ln_b;
+  // A_CHANMAJOR, split tile kernels only: the sidekick scores of the clips (model.py:500-505) computed on the side while the A tile
+  // of the shallow features is staged (the vid_map product W[:, D:] . shallow streams exactly the (D, T) matrix the scores need):
+  //   score_out[q][m] = sum_k A[m][k] score_tn[q][k] / (||A[m][:]|| + 1e-4)       (score_norm; the plain dot product without)
+  // score_tn = the (already normalised) text vectors [score_nq][K], score_nq <= GEMM_SCORE_MAXQ.  Written by the workgroups of
+  // the first column tile, sums in a fixed order (deterministic: the gate is a discrete decision).  nullptr = off.
+  const float* score_tn;
+  float* score_out;
+  int score_nq, score_norm;
   // f16x3 mode: sticky device word, bit 0 is set when an accumulator leaves the finite range (an operand overflowed the
   // fp16 range, or the inputs already held inf / NaN); nullptr = not reported
   unsigned* status;
@@ -82,6 +90,8 @@ struct GemmArgs {
   // 1 widens the range to |a| < 65504 at an absolute representation floor of 2^-25
   float a_scale;
 };
+
+constexpr int GEMM_SCORE_MAXQ = 4;     // queries whose sidekick scores one channel-major GEMM carries (GemmArgs::score_out)
 
 // Launch up to 3 independent GEMMs of identical (M, N, K, mode) in one grid (blockIdx.z).
 int launch_gemm(const GemmArgs* g, int count, GemmAMode mode, hipStream_t stream);

@@ -151,7 +151,8 @@ int launch_split_planes(const float* W, unsigned short* out, int N, int K, int64
 // the prefetch distance hides that latency.  Buffers are indexed statically (steps unrolled in groups of NST).
 // STATS = true: the instantiation whose epilogue writes / consumes row statistics (GemmArgs::stats_out / stats_in)
 // ALN = true (A_ROWS_TAP3): the A rows get LayerNorm + ReLU while they are staged (GemmArgs::a_stats)
-template <int WM, int WN, int TM, int TN, int AMODE, int NTERMS, bool LN = false, int NST = 3, bool STATS = false, bool ALN = false>
+// SCORE = true (A_CHANMAJOR): the sidekick scores of the rows on the side (GemmArgs::score_out)
+template <int WM, int WN, int TM, int TN, int AMODE, int NTERMS, bool LN = false, int NST = 3, bool STATS = false, bool ALN = false, bool SCORE = false>
 __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4 || (NST > 2 && TM * TN >= 4)) ? 2 : 3)) void gemm_bf16s_kernel(GemmBatch batch) {
   constexpr int NT = WM * WN * 64;                    // 4 or 8 wavefronts
   constexpr int BM = WM * TM * 32;
@@ -200,6 +201,22 @@ __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4 || (NST > 2
       aln_row[2 * t + 1] = -mean * rstd;
     }
     for (int c = tid; c < p.cin; c += NT) { aln_g[c] = p.a_ln_g[c]; aln_g[p.cin + c] = p.a_ln_b[c]; }
+  }
+  // SCORE: the text vectors in LDS behind the statistics block (read from the first store_a on, behind the K loop's first barrier);
+  // per thread the partial sums of its 4 rows over its k pairs: sum of squares + one dot product per query
+  static_assert(!SCORE || (AMODE == A_CHANMAJOR && !ALN && !LN), "SCORE is a channel-major mode");
+  float* sc_tn = wg_stats + stats_lds_floats<WM, WN, TM>();
+  const bool do_score = SCORE && p.score_out != nullptr && n0 == 0;         // uniform: the first column tile carries the scores
+  f32x4 sc_ss[ACH], sc_dot[ACH][GEMM_SCORE_MAXQ];
+  if constexpr (SCORE) {
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) {
+      sc_ss[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < GEMM_SCORE_MAXQ; ++q) sc_dot[i][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (do_score)
+      for (int c = tid; c < p.score_nq * K; c += NT) sc_tn[c] = p.score_tn[c];
   }
 
   // K-invariant addressing (see gemm.hip: nothing but 16-byte loads inside the K loop)
@@ -297,6 +314,25 @@ __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4 || (NST > 2
         x1.z = fmaxf(__builtin_fmaf(__builtin_fmaf(x1.z, rs, sh), g1.z, b1.z), 0.f);
         x1.w = fmaxf(__builtin_fmaf(__builtin_fmaf(x1.w, rs, sh), g1.w, b1.w), 0.f);
         araw[i][0] = x0; araw[i][1] = x1;
+      }
+    }
+    if constexpr (SCORE) {
+      if (do_score) {
+        const int kk = phys_kt(kt_) * SBK + 2 * (tid & 15);            // pk = id & 15 = tid & 15 (NT is a multiple of 16)
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+          const f32x4 x0 = araw[i][0], x1 = araw[i][1];                // rows m .. m + 3 at k and k + 1 (zeros beyond M)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sc_ss[i][e] = __builtin_fmaf(x1[e], x1[e], __builtin_fmaf(x0[e], x0[e], sc_ss[i][e]));
+#pragma unroll
+          for (int q = 0; q < GEMM_SCORE_MAXQ; ++q) {
+            if (q < p.score_nq) {                                      // uniform
+              const float2 t2 = *reinterpret_cast<const float2*>(sc_tn + q * K + kk);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) sc_dot[i][q][e] = __builtin_fmaf(x1[e], t2.y, __builtin_fmaf(x0[e], t2.x, sc_dot[i][q][e]));
+            }
+          }
+        }
       }
     }
 #pragma unroll
@@ -406,6 +442,37 @@ __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4 || (NST > 2
     if constexpr (NST >= 4) step(kt + 3, std::integral_constant<int, 3 % NST>{});
   }
   group(kt, KT - kt);                   // the last KT % NST tiles
+  if constexpr (SCORE) {
+    if (do_score) {
+      // the 16 lanes of a k-pair group hold the partial sums of the same 4 rows: butterfly over them (fixed order), lane 0 writes
+#pragma unroll
+      for (int i = 0; i < ACH; ++i) {
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sc_ss[i][e] += __shfl_xor(sc_ss[i][e], off);
+#pragma unroll
+          for (int q = 0; q < GEMM_SCORE_MAXQ; ++q)
+            if (q < p.score_nq) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) sc_dot[i][q][e] += __shfl_xor(sc_dot[i][q][e], off);
+            }
+        }
+        const int id = i * NT + tid;
+        const int m = m0 + (id >> 4) * 4;
+        if ((id & 15) == 0 && m < M) {
+          f32x4 inv = {1.f, 1.f, 1.f, 1.f};
+          if (p.score_norm) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) inv[e] = 1.0f / (sqrtf(sc_ss[i][e]) + 1e-4f);
+          }
+#pragma unroll
+          for (int q = 0; q < GEMM_SCORE_MAXQ; ++q)
+            if (q < p.score_nq) *reinterpret_cast<f32x4*>(p.score_out + (int64_t)q * M + m) = sc_dot[i][q] * inv;
+        }
+      }
+    }
+  }
   if constexpr (NTERMS == T_F16) {
     bool bad = false;
 #pragma unroll
@@ -681,7 +748,25 @@ static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterm
   else if (mode == A_ROWS_TAP3) { if (nterms == 6) LS(A_ROWS_TAP3, 6); else LS(A_ROWS_TAP3, T_F16); }
   else {
     // channel-major A is only instantiated for the 64-row tiles the vid_map shapes use
-    if constexpr (WM == 1 && WN == 4 && TM == 2) { if (nterms == 6) LS(A_CHANMAJOR, 6); else LS(A_CHANMAJOR, T_F16); }
+    if constexpr (WM == 1 && WN == 4 && TM == 2) {
+      bool want_score = false;
+      int score_q = 0;
+      for (int i = 0; i < count; ++i) {
+        if (!b.g[i].score_out) continue;
+        want_score = true;
+        DCF_CHECK(b.g[i].score_tn && b.g[i].score_nq >= 1 && b.g[i].score_nq <= GEMM_SCORE_MAXQ && b.g[i].M % 4 == 0 &&
+                  (reinterpret_cast<uintptr_t>(b.g[i].score_out) & 15) == 0, "launch_gemm_split: bad score arguments (1 .. %d queries)", GEMM_SCORE_MAXQ);
+        score_q = b.g[i].score_nq > score_q ? b.g[i].score_nq : score_q;
+      }
+      if (want_score) {
+        const size_t lds_sc = lds + (size_t)score_q * p.K * sizeof(float);
+        constexpr int NST_ = DEEP ? 3 : 2;
+        if (nterms == 6) hipLaunchKernelGGL((gemm_bf16s_kernel<WM, WN, TM, TN, A_CHANMAJOR, 6, false, 2, false, false, true>), grid, dim3(WM * WN * 64), lds_sc, stream, b);
+        else hipLaunchKernelGGL((gemm_bf16s_kernel<WM, WN, TM, TN, A_CHANMAJOR, T_F16, false, NST_, false, false, true>), grid, dim3(WM * WN * 64), lds_sc, stream, b);
+      } else {
+        if (nterms == 6) LS(A_CHANMAJOR, 6); else LS(A_CHANMAJOR, T_F16);
+      }
+    }
     else DCF_CHECK(false, "launch_gemm_split: channel-major A needs a 64-row tile");
   }
 #undef LS

@@ -24,6 +24,7 @@ struct ScoreArgs {
   int D, T, NQ, norm;
 };
 int launch_sidekick(const ScoreArgs& a, hipStream_t st);
+int launch_text_cls_norm(const ScoreArgs& a, hipStream_t st);     // tn only (the scores come out of the vid_map GEMMs)
 // one video
 inline ScoreArgs score_args(const float* shallow, const float* text_cls, float* tn, float* partial, float* correl, int D, int T,
                             int nq, int norm) {

@@ -117,6 +117,15 @@ __global__ __launch_bounds__(256) void k_sidekick_final(ScoreArgs p) {
   }
 }
 
+// the normalised text vectors alone (tn): the scores themselves then ride on the channel-major vid_map GEMMs (GemmArgs::score_out)
+int launch_text_cls_norm(const ScoreArgs& a, hipStream_t st) {
+  if (a.NQ <= 0 || a.nvid <= 0) return 0;
+  DCF_CHECK(a.nvid <= SCORE_MAXVID, "sidekick: %d videos per launch > %d", a.nvid, SCORE_MAXVID);
+  hipLaunchKernelGGL(k_text_cls_norm, dim3(a.NQ), dim3(256), 0, st, a);
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_sidekick(const ScoreArgs& a, hipStream_t st) {
   if (a.NQ <= 0 || a.T <= 0 || a.nvid <= 0) return 0;
   DCF_CHECK(a.nvid <= SCORE_MAXVID, "sidekick: %d videos per launch > %d", a.nvid, SCORE_MAXVID);
