@@ -33,11 +33,11 @@ def collect(path, counter):
 
 
 def last_forward(path, counter):
-    """per-kernel counter sums (KiB) over the LAST forward of the run: dispatches from the last sidekick-scoring kernel (the
-    first kernel of a forward) to the end of the trace"""
+    """per-kernel counter sums (KiB) over the LAST forward of the run: dispatches from the last k_text_cls_norm (the first kernel of a
+    forward, whether the scores ride on the vid_map GEMM or not) to the end of the trace"""
     rows = [r for r in csv.DictReader(open(path)) if r['Counter_Name'] == counter]
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
-    starts = [i for i, r in enumerate(rows) if 'k_sidekick_partial' in r['Kernel_Name']]
+    starts = [i for i, r in enumerate(rows) if 'k_text_cls_norm' in r['Kernel_Name']]
     if not starts:
         return {}, 0
     per = {}
@@ -76,7 +76,7 @@ if ff and nf == nw:
     by = dict(sorted(by.items(), key=lambda kv: -kv[1]['hbm_bytes']))
     videos = int(sys.argv[3]) if len(sys.argv) > 3 else 8
     out['forward'] = {'videos': videos, 'dispatches': nf, 'hbm_bytes': sum(v['hbm_bytes'] for v in by.values()), 'by_kernel': by,
-                      'note': 'FETCH_SIZE x2 + WRITE_SIZE of every dispatch of the LAST forward of the run (from its sidekick-scoring kernel '
+                      'note': 'FETCH_SIZE x2 + WRITE_SIZE of every dispatch of the LAST forward of the run (from its first kernel, k_text_cls_norm, '
                               'to the end of the trace), summed by kernel; HBM / Infinity-Fabric side of L2, i.e. what the kernels miss in L2'}
 import bench  # noqa: E402  (csrc_hash: bench.py only quotes this summary for the same kernel sources)
 out['csrc_sha16'] = bench.csrc_hash()

@@ -4,8 +4,8 @@ import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
-# one step starts at the sidekick partial kernel
-starts = [i for i, n in enumerate(names) if 'k_sidekick_partial' in n]
+# one step starts at k_text_cls_norm (the first kernel of a forward)
+starts = [i for i, n in enumerate(names) if 'k_text_cls_norm' in n]
 if len(starts) < 3:
     print('not enough steps', len(starts)); sys.exit(1)
 # steady-state = the step with the smallest wall time (graph replay inside the timed region)
