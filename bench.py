@@ -233,27 +233,6 @@ def run_sharded(args, pkg, dist, rank, world, dev):
                                        'tests/test_gpu_e2e.py::test_config4_unsharded_T65536_vs_oracle)',
                             'max_abs_logit': dl, 'max_abs_offset': do, 'masks_equal': mk}
         assert mk and dl < 2e-4 and do < 2e-4, f'sharded forward differs from the unsharded one: {dl} {do} {mk}'
-        # the north star's other thresholds, inside the object the driver keeps whole
-        chk = {}
-        if 'xattn_config2' in result:
-            chk['xattn_config2'] = {k: result['xattn_config2'][k] for k in ('frac', 'us_per_launch', 'achieved', 'unit')}
-        if 'hbm_budget' in result:
-            chk['hbm_bytes_per_clip'] = result['hbm_budget']['bytes_per_clip']
-        if 'one_video_per_call' in result:
-            o1 = result['one_video_per_call']
-            chk['one_video_per_call'] = {'ms_per_forward': o1['ms_per_forward'], 'clips_per_s': o1['value'],
-                                         'gemm_frac': o1.get('roofline', {}).get('frac'),
-                                         'dispatches_per_forward': o1.get('roofline', {}).get('dispatches_per_forward')}
-        if 'post' in result:
-            chk['nms_index_match'] = result['post']['nms_index_match']
-            chk['softnms_index_match'] = result['post']['softnms_index_match']
-        if 'parity' in result:
-            chk['parity_max_abs_logit'] = result['parity']['max_abs_logit']
-            chk['parity_max_abs_offset'] = result['parity']['max_abs_offset']
-        if 'cpu_baseline' in result:
-            chk['gpu_over_cpu'] = result['value'] / result['cpu_baseline']['value']
-        if 'roofline' in result:
-            result['roofline']['checks'] = chk
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
@@ -704,6 +683,27 @@ def main():
             result['cpu_baseline']['crosscheck'] = ('build container, 8 threads, T=16384, warm, 11 interleaved repetitions (profiles/r03_cpu_crosscheck.json, '
                                                     'tools/cpu_crosscheck.py): oracle / real reference = 0.96x by the medians, 1.08x by the best runs (shared cores: single '
                                                     'runs spread 1.0 .. 4.0 s, which is where round 2\'s 0.76x from two blocks of three came from); outputs agree to 1.3e-6')
+        # the north star's other thresholds, inside the object the driver keeps whole
+        chk = {}
+        if 'xattn_config2' in result:
+            chk['xattn_config2'] = {k: result['xattn_config2'][k] for k in ('frac', 'us_per_launch', 'achieved', 'unit')}
+        if 'hbm_budget' in result:
+            chk['hbm_bytes_per_clip'] = result['hbm_budget']['bytes_per_clip']
+        if 'one_video_per_call' in result:
+            o1 = result['one_video_per_call']
+            chk['one_video_per_call'] = {'ms_per_forward': o1['ms_per_forward'], 'clips_per_s': o1['value'],
+                                         'gemm_frac': o1.get('roofline', {}).get('frac'),
+                                         'dispatches_per_forward': o1.get('roofline', {}).get('dispatches_per_forward')}
+        if 'post' in result:
+            chk['nms_index_match'] = result['post']['nms_index_match']
+            chk['softnms_index_match'] = result['post']['softnms_index_match']
+        if 'parity' in result:
+            chk['parity_max_abs_logit'] = result['parity']['max_abs_logit']
+            chk['parity_max_abs_offset'] = result['parity']['max_abs_offset']
+        if 'cpu_baseline' in result:
+            chk['gpu_over_cpu'] = result['value'] / result['cpu_baseline']['value']
+        if 'roofline' in result:
+            result['roofline']['checks'] = chk
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

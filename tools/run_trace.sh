@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (on the GPU box, via gpurun): bash tools/run_trace.sh <tag> [bench args]   -> gpurun_out/step_<tag>.txt
-# (a forward is delimited by its sidekick kernel: pass --videos 1 --batch 1 so that every forward holds ONE video)
+# (a forward is delimited by its first kernel, k_text_cls_norm: pass --videos 1 --batch 1 so that every forward holds ONE video)
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/trace_$tag -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-post "$@" > /dev/null 2>&1
