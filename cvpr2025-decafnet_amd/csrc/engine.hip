@@ -236,6 +236,7 @@ struct dcf_model {
   std::vector<float> reg_scales;             // host copy of reg_head.scales.{l}.scale
   const float *tcn_in_w = nullptr, *tcn_in_b = nullptr, *tcn_out_w = nullptr, *tcn_out_b = nullptr;
   std::vector<const float*> tcn_wd, tcn_bd, tcn_wp, tcn_bp, tcn_lnw, tcn_lnb;
+  std::vector<const unsigned short*> tcn_frag;   // f16x3: MFMA fragment image of every TCN layer (launch_tcn_frag_image)
   // text_net (TextTransformer, text_net.py:92-188); empty when cfg.text_layers == 0
   const float *text_embd_w = nullptr, *text_embd_b = nullptr, *text_bkgd = nullptr;
   TextEncW text_pool{};                      // TextIdentity: attn_pool.attn.{query,key,value,proj} (text_net.py:50-53)
@@ -480,6 +481,16 @@ static int resolve_tcn(dcf_model* m, const std::string& pre, int n_in, int n_lay
   if (pack3(m, t, 1, TCN_HID, TCN_HID, 0, 2, 1, st, &m->tcn_out_w)) return -1;
   if (m->gemm_terms == GEMM_F16X3 && launch_f16_weight_range(m->tcn_out_w, TCN_HID * TCN_HID, m->status ? m->status + 1 : nullptr, st)) return -1;
   GET(pre + ".conv_out.bias", SH(TCN_HID), m->tcn_out_b);
+  m->tcn_frag.clear();
+  if (m->gemm_terms == GEMM_F16X3) {                     // the layers' weight fragments once per model, not once per workgroup
+    for (int i = 0; i < n_layers; ++i) {
+      unsigned short* img = nullptr;
+      DCF_HIP(hipMalloc(&img, (size_t)TCN_FRAG_HALFS * sizeof(unsigned short)));
+      m->owned.push_back(reinterpret_cast<float*>(img));
+      if (launch_tcn_frag_image(m->tcn_wd[i], m->tcn_wp[i], i + 1 == n_layers ? m->tcn_out_w : nullptr, img, st)) return -1;
+      m->tcn_frag.push_back(img);
+    }
+  }
   return 0;
 }
 
@@ -1597,6 +1608,7 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
       ra.host_w_dil = m->tcn_wd.data(); ra.host_b_dil = m->tcn_bd.data(); ra.host_w_pw = m->tcn_wp.data();
       ra.host_b_pw = m->tcn_bp.data(); ra.host_ln_w = m->tcn_lnw.data(); ra.host_ln_b = m->tcn_lnb.data();
       ra.w_out = m->tcn_out_w; ra.b_out = m->tcn_out_b;
+      ra.host_frag = (!m->tcn_frag.empty() && debug_option("tcn_frag", 1) != 0) ? m->tcn_frag.data() : nullptr;
       ra.bufA = b.tcnA; ra.bufB = b.tcnB; ra.F = b.F; ra.ldf = E + TCN_HID; ra.E = E;
       ra.B = B; ra.T0 = Tp; ra.n_levels = L; ra.n_layers = L;
       ra.f16 = m->gemm_terms == GEMM_F16X3; ra.status = m->status;
@@ -1954,7 +1966,7 @@ int dcf_graph_active(const dcf_model* m) { return m ? m->last_launch : 0; }
 
 int dcf_debug_set_option(const char* name, int32_t value) {
   DCF_CHECK(name && *name, "dcf_debug_set_option: empty name");
-  static const char* known[] = {"dec_chain_min_rows", "enc_chain_min_rows", "enc_attn_min_rows", "fuse_scores"};
+  static const char* known[] = {"dec_chain_min_rows", "enc_chain_min_rows", "enc_attn_min_rows", "fuse_scores", "tcn_frag"};
   bool ok = false;
   for (const char* k : known) ok = ok || strcmp(k, name) == 0;
   DCF_CHECK(ok, "dcf_debug_set_option: unknown option '%s'", name);
@@ -2511,6 +2523,7 @@ int dcf_op_tcn(dcf_model* m, const char* prefix, const float* x, const uint8_t* 
     ra.host_w_dil = m->tcn_wd.data(); ra.host_b_dil = m->tcn_bd.data(); ra.host_w_pw = m->tcn_wp.data();
     ra.host_b_pw = m->tcn_bp.data(); ra.host_ln_w = m->tcn_lnw.data(); ra.host_ln_b = m->tcn_lnb.data();
     ra.w_out = m->tcn_out_w; ra.b_out = m->tcn_out_b;
+    ra.host_frag = (!m->tcn_frag.empty() && dcf::debug_option("tcn_frag", 1) != 0) ? m->tcn_frag.data() : nullptr;
     ra.bufA = buf; ra.bufB = buf + (size_t)B * T * TCN_HID; ra.F = Y; ra.ldf = TCN_HID; ra.E = 0;
     ra.B = B; ra.T0 = T; ra.n_levels = n_in; ra.n_layers = n_layers;
     ra.f16 = m->gemm_terms == GEMM_F16X3; ra.status = m->status;

@@ -45,6 +45,8 @@ struct RefineArgs {
   const float* const* host_w_pw; const float* const* host_b_pw;
   const float* const* host_ln_w; const float* const* host_ln_b;
   const float* w_out; const float* b_out;
+  const unsigned short* const* host_frag;   // optional HOST array [n_layers] of device pointers: the layers' MFMA fragment images
+                                            // (launch_tcn_frag_image; the last layer's with w_out); null = built per workgroup
   float* bufA; float* bufB;           // [B*T0][32] ping-pong
   float* F; int64_t ldf; int E;       // pyramid feature buffer; refined logits go to columns [E, E+32)
   int B, T0, n_levels, n_layers;
@@ -57,5 +59,9 @@ struct RefineArgs {
 int launch_refine(const RefineArgs& a, const LevelTable& host_lt, hipStream_t st);
 // raises *flag if a weight of the TCN does not fit the scaled fp16 range of the f16 mode (|w| < 255.9)
 int launch_f16_weight_range(const float* w, int n, unsigned* flag, hipStream_t st);
+// fp16 hi / lo MFMA fragments of one TCN layer's weights (dilated conv [3][32][32], conv_1x1 [32][32], optionally refine.conv_out
+// [32][32] for the last layer) in the order k_tcn_layer_mfma consumes them: img [10][2][64][8] halfs (20 KiB)
+constexpr int TCN_FRAG_HALFS = 10 * 2 * 64 * 8;
+int launch_tcn_frag_image(const float* wd, const float* wp, const float* wo, unsigned short* img, hipStream_t st);
 
 }  // namespace dcf

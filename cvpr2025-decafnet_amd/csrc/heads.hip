@@ -545,8 +545,42 @@ __device__ __forceinline__ void chan4(const float* __restrict__ v, int h, f32x4 
   for (int q = 0; q < 4; ++q) out[q] = *reinterpret_cast<const f32x4*>(v + 8 * q + 4 * h);
 }
 
+// fragment pair f of a TCN layer (6 dilated-conv chunks, 2 chunks of conv_1x1, 2 of refine.conv_out) for lane (n, h)
+__device__ __forceinline__ void tcn_frag(int f, const float* __restrict__ wd, const float* __restrict__ wp, const float* __restrict__ wo,
+                                         int n, int h, h16x8& fh, h16x8& fl) {
+  float x[8];
+  if (f < 6) {                                           // chunk f = (tap, 16-channel half): k position i = channel 16 cc + 8 h + i
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = wd[((f >> 1) * TCN_HID + 16 * (f & 1) + 8 * h + i) * TCN_HID + n];
+  } else {                                               // chained products: k position i of chunk c = channel 8 (2c + i / 4) + 4 h + i % 4
+    const float* __restrict__ wsrc = f < 8 ? wp : wo;
+    const int c = f & 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = wsrc[(8 * (2 * c + i / 4) + 4 * h + i % 4) * TCN_HID + n];
+  }
+  split8(x, TCN_SW, fh, fl);
+}
+
+// the fragments of a layer once per model instead of once per workgroup (img [10][2][64] h16x8; pairs 8, 9 only with wo)
+__global__ __launch_bounds__(64) void k_tcn_frag_image(const float* __restrict__ wd, const float* __restrict__ wp, const float* __restrict__ wo,
+                                                        h16x8* __restrict__ img) {
+  const int lane = threadIdx.x, f = blockIdx.x;
+  if (f >= 8 && !wo) return;
+  h16x8 fh, fl;
+  tcn_frag(f, wd, wp, wo, lane & 31, lane >> 5, fh, fl);
+  img[(f * 2 + 0) * 64 + lane] = fh;
+  img[(f * 2 + 1) * 64 + lane] = fl;
+}
+int launch_tcn_frag_image(const float* wd, const float* wp, const float* wo, unsigned short* img, hipStream_t st) {
+  DCF_CHECK(wd && wp && img, "launch_tcn_frag_image: null argument");
+  hipLaunchKernelGGL(k_tcn_frag_image, dim3(10), dim3(64), 0, st, wd, wp, wo, reinterpret_cast<h16x8*>(img));
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
+// frag != nullptr: the layer's fragment image (launch_tcn_frag_image); otherwise the workgroup builds the fragments itself
 template <bool LAST>
-__global__ __launch_bounds__(256) void k_tcn_layer_mfma(const float* __restrict__ X, float* __restrict__ Y,
+__global__ __launch_bounds__(256) void k_tcn_layer_mfma(const float* __restrict__ X, float* __restrict__ Y, const h16x8* __restrict__ frag,
                                                          const float* __restrict__ wd, const float* __restrict__ bd,
                                                          const float* __restrict__ wp, const float* __restrict__ bp,
                                                          const float* __restrict__ lnw, const float* __restrict__ lnb,
@@ -562,34 +596,36 @@ __global__ __launch_bounds__(256) void k_tcn_layer_mfma(const float* __restrict_
   // building all of them per wave cost as much as the wave's tile
   constexpr int NPAIR = LAST ? 10 : 8;                   // (hi, lo) fragment pairs: 6 dilated-conv chunks, 2 + 2 chained ones
   __shared__ h16x8 s_frag[NPAIR][2][64];
-#pragma unroll
-  for (int f = 0; f < NPAIR; ++f) {
-    if ((f & 3) != wv) continue;
-    float x[8];
-    if (f < 6) {                                         // chunk f = (tap, 16-channel half): k position i = channel 16 cc + 8 h + i
-#pragma unroll
-      for (int i = 0; i < 8; ++i) x[i] = wd[((f >> 1) * TCN_HID + 16 * (f & 1) + 8 * h + i) * TCN_HID + n];
-    } else {                                             // chained products: k position i of chunk c = channel 8 (2c + i / 4) + 4 h + i % 4
-      const float* __restrict__ wsrc = f < 8 ? wp : wo;
-      const int c = f & 1;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) x[i] = wsrc[(8 * (2 * c + i / 4) + 4 * h + i % 4) * TCN_HID + n];
-    }
-    h16x8 fh, fl;
-    split8(x, TCN_SW, fh, fl);
-    s_frag[f][0][lane] = fh;
-    s_frag[f][1][lane] = fl;
-  }
-  __syncthreads();
-  if (wave * tiles_per_wave * 32 >= rows) return;
   h16x8 wd_h[6], wd_l[6], wp_h[2], wp_l[2], wo_h[2], wo_l[2];
+  if (frag) {                                            // uniform
+    if (wave * tiles_per_wave * 32 >= rows) return;
 #pragma unroll
-  for (int kc = 0; kc < 6; ++kc) { wd_h[kc] = s_frag[kc][0][lane]; wd_l[kc] = s_frag[kc][1][lane]; }
+    for (int kc = 0; kc < 6; ++kc) { wd_h[kc] = frag[(kc * 2) * 64 + lane]; wd_l[kc] = frag[(kc * 2 + 1) * 64 + lane]; }
 #pragma unroll
-  for (int c = 0; c < 2; ++c) { wp_h[c] = s_frag[6 + c][0][lane]; wp_l[c] = s_frag[6 + c][1][lane]; }
-  if constexpr (LAST) {
+    for (int c = 0; c < 2; ++c) { wp_h[c] = frag[((6 + c) * 2) * 64 + lane]; wp_l[c] = frag[((6 + c) * 2 + 1) * 64 + lane]; }
+    if constexpr (LAST) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) { wo_h[c] = s_frag[8 + c][0][lane]; wo_l[c] = s_frag[8 + c][1][lane]; }
+      for (int c = 0; c < 2; ++c) { wo_h[c] = frag[((8 + c) * 2) * 64 + lane]; wo_l[c] = frag[((8 + c) * 2 + 1) * 64 + lane]; }
+    }
+  } else {
+#pragma unroll
+    for (int f = 0; f < NPAIR; ++f) {
+      if ((f & 3) != wv) continue;
+      h16x8 fh, fl;
+      tcn_frag(f, wd, wp, wo, n, h, fh, fl);
+      s_frag[f][0][lane] = fh;
+      s_frag[f][1][lane] = fl;
+    }
+    __syncthreads();
+    if (wave * tiles_per_wave * 32 >= rows) return;
+#pragma unroll
+    for (int kc = 0; kc < 6; ++kc) { wd_h[kc] = s_frag[kc][0][lane]; wd_l[kc] = s_frag[kc][1][lane]; }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { wp_h[c] = s_frag[6 + c][0][lane]; wp_l[c] = s_frag[6 + c][1][lane]; }
+    if constexpr (LAST) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) { wo_h[c] = s_frag[8 + c][0][lane]; wo_l[c] = s_frag[8 + c][1][lane]; }
+    }
   }
   f32x4 bd4[4], bp4[4], lw4[4], lb4[4], bo4[4];
   chan4(bd, h, bd4); chan4(bp, h, bp4); chan4(lnw, h, lw4); chan4(lnb, h, lb4);
@@ -835,15 +871,16 @@ int launch_refine(const RefineArgs& a, const LevelTable& lt, hipStream_t st) {
                                                          // 4 -> 0.193, 8 -> 0.302: a tile is one dependent load -> split -> MFMA chain, more waves hide it best)
   const dim3 gm((((tiles + tpw - 1) / tpw) + 3) / 4);
   bool out_done = false;
+  auto fimg = [&](int i) { return a.host_frag && a.host_frag[i] ? reinterpret_cast<const h16x8*>(a.host_frag[i]) : (const h16x8*)nullptr; };
   for (int i = 0; i < a.n_layers; ++i) {
     DCF_CHECK(a.host_w_dil && a.host_w_dil[i], "refine: missing TCN layer %d", i);
     if (a.f16) {
       if (i + 1 < a.n_layers) {
-        hipLaunchKernelGGL(k_tcn_layer_mfma<false>, gm, dim3(256), 0, st, (const float*)cur, nxt, a.host_w_dil[i], a.host_b_dil[i],
+        hipLaunchKernelGGL(k_tcn_layer_mfma<false>, gm, dim3(256), 0, st, (const float*)cur, nxt, fimg(i), a.host_w_dil[i], a.host_b_dil[i],
                            a.host_w_pw[i], a.host_b_pw[i], a.host_ln_w[i], a.host_ln_b[i], a.mask_all, a.B, a.T0, 1 << i, tpw,
                            (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (int64_t)0, 0, a.status);
       } else {
-        hipLaunchKernelGGL(k_tcn_layer_mfma<true>, gm, dim3(256), 0, st, (const float*)cur, nxt, a.host_w_dil[i], a.host_b_dil[i],
+        hipLaunchKernelGGL(k_tcn_layer_mfma<true>, gm, dim3(256), 0, st, (const float*)cur, nxt, fimg(i), a.host_w_dil[i], a.host_b_dil[i],
                            a.host_w_pw[i], a.host_b_pw[i], a.host_ln_w[i], a.host_ln_b[i], a.mask_all, a.B, a.T0, 1 << i, tpw,
                            a.w_out, a.b_out, a.F, a.ldf, a.E, a.status);
         out_done = true;

@@ -706,9 +706,17 @@ def test_tcn_golden(L):
     x, mask = ops.t('tcn/x'), ops.t('mask')
     bs, n_in, T = x.shape
     h = scratch_model(pkg, lib, ops.sub('tcn/w/'), 'r')
-    Y = torch.empty(bs * T, 32, device='cuda')
-    pkg._lib.check(lib.dcf_op_tcn(h, b'r', P(tok(x)), P(mask.reshape(-1).contiguous().cuda()), bs, T, n_in, 4, P(Y), st()), 'dcf_op_tcn')
-    torch.testing.assert_close(untok(Y, bs, T), ops.t('tcn/y'), rtol=1e-5, atol=1e-5)
+    outs = []
+    try:
+        for frag in (1, 0):       # the layers' weight fragments from the per-model image / built by every workgroup: the same bits
+            pkg._lib.check(lib.dcf_debug_set_option(b'tcn_frag', frag))
+            Y = torch.empty(bs * T, 32, device='cuda')
+            pkg._lib.check(lib.dcf_op_tcn(h, b'r', P(tok(x)), P(mask.reshape(-1).contiguous().cuda()), bs, T, n_in, 4, P(Y), st()), 'dcf_op_tcn')
+            torch.testing.assert_close(untok(Y, bs, T), ops.t('tcn/y'), rtol=1e-5, atol=1e-5)
+            outs.append(Y.clone())
+    finally:
+        pkg._lib.check(lib.dcf_debug_set_option(b'tcn_frag', -1))
+    assert torch.equal(outs[0], outs[1])
     lib.dcf_model_destroy(h)
 
 
