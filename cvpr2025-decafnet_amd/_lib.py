@@ -53,6 +53,10 @@ SIGNATURES = {
     'dcf_ctr_iou_loss': (i32, [c_f32p, c_f32p, c_u8p, i64, i32, f32, c_f32p, c_f32p, c_i32p, vp]),
     'dcf_forward_eval_gated': (i32, [vp, c_f32p, c_f32p, c_u8p, i64, i32, ctypes.POINTER(vp), ctypes.POINTER(vp),
                                      ctypes.POINTER(i32), c_f32p, c_f32p, c_f32p, c_u8p, vp]),
+    'dcf_hybrid_phase1': (i32, [vp, i32, c_f32p, c_f32p, c_u8p, i64, i64, i32, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(i32),
+                                c_f32p, c_f32p, vp]),
+    'dcf_hybrid_phase2': (i32, [vp, c_f32p, c_u8p, i64, c_f32p, vp]),
+    'dcf_hybrid_phase3': (i32, [vp, c_f32p, c_f32p, c_f32p, c_u8p, c_f32p, c_f32p, c_u8p, vp]),
     'dcf_debug_copy': (i32, [vp, i32, c_f32p, i64, vp]),
     'dcf_graph_active': (i32, [vp]),
     'dcf_debug_set_option': (i32, [ctypes.c_char_p, i32]),

@@ -196,8 +196,8 @@ struct HeadW {
 // opt.model.vid_net.stride (video_net.py:39): the embedding convolutions divide the sequence by it; 0 (older callers) reads as 1
 static inline int vid_stride_of(const dcf_config& c) { return c.vid_stride > 1 ? c.vid_stride : 1; }
 
-struct Plan {    // geometry for one (T0, B)
-  int T0 = 0, B = 0;
+struct Plan {    // geometry for one (T0, B, levels)
+  int T0 = 0, B = 0, L = 0;
   LevelTable lt{};
   LevelTable* d_lt = nullptr;
 };
@@ -205,6 +205,9 @@ struct Plan {    // geometry for one (T0, B)
 }  // namespace dcf
 
 using namespace dcf;
+
+namespace dcf { struct HybridState; }
+using dcf::HybridState;
 
 struct dcf_model {
   dcf_config cfg{};
@@ -270,6 +273,11 @@ struct dcf_model {
     float *correl = nullptr, *gate = nullptr, *vidmap = nullptr, *fused = nullptr, *F = nullptr;
     int nq = 0, T0 = 0, B = 0, S = 0;
   } dbg;
+  struct HybridState* hyb = nullptr;         // one long video sharded at pyramid level k (dcf_hybrid_phase1 / 2 / 3)
+  int hyb_levels = 0;                        // > 0 while phase 1 runs: the forward builds levels 0 .. hyb_levels - 1 and stops behind the encoder
+  size_t hyb_extra = 0;                      // bytes of workspace behind the forward's own buffers (the coarse pyramid)
+  char* hyb_extra_ptr = nullptr;
+  float* hyb_feat_out = nullptr;
   float* dbg_vidmap = nullptr;
   float* dbg_fused = nullptr;
   int64_t dbg_cap = 0;                        // capacity (floats) of the armed tap destinations
@@ -277,6 +285,8 @@ struct dcf_model {
 };
 
 namespace dcf {
+
+static void free_hybrid(dcf_model* m);
 
 static void drop_graph(dcf_model* m, bool keep_last_key = false) {
   if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
@@ -298,6 +308,7 @@ static int free_model(dcf_model* m) {
   m->wsplit_terms.clear();
   for (auto& pl : m->plans) if (pl.d_lt) (void)hipFree(pl.d_lt);
   m->plans.clear();
+  free_hybrid(m);                             // (the level-cut state of dcf_hybrid_phase1 / 2 / 3)
   if (m->arena) (void)hipFree(m->arena);
   if (m->text_ws) (void)hipFree(m->text_ws);
   if (m->ev_in) (void)hipEventDestroy(m->ev_in);
@@ -690,7 +701,8 @@ static int finalize(dcf_model* m, hipStream_t st) {
   if (c.model_kind == 0 && resolve_tcn(m, "refine", L, L, st)) return -1;
   DCF_HIP(hipStreamSynchronize(st));
   for (auto& pl : m->plans) if (pl.d_lt) (void)hipFree(pl.d_lt);
-  m->plans.clear();                           // reg scales live in the level tables
+  m->plans.clear();
+  free_hybrid(m);                             // reg scales live in the level tables
   drop_graph(m);
   if (m->gemm_terms == GEMM_F16X3) {
     // did every weight fit the scaled fp16 range (|w| < 255.9)?  If not, rebuild the images for bf16x6.
@@ -771,13 +783,13 @@ static void carve(Arena& a, const dcf_config& c, int T0, int B, int nq, int S, i
   b.kmadd = a.take<float>((size_t)B * 64);
 }
 
-static int get_plan(dcf_model* m, int T0, int B, hipStream_t st, Plan** out) {
+static int get_plan(dcf_model* m, int T0, int B, int L, hipStream_t st, Plan** out) {
   for (auto& p : m->plans)
-    if (p.T0 == T0 && p.B == B) { *out = &p; return 0; }
+    if (p.T0 == T0 && p.B == B && p.L == L) { *out = &p; return 0; }
   Plan p;
-  p.T0 = T0; p.B = B;
+  p.T0 = T0; p.B = B; p.L = L;
   LevelTable& lt = p.lt;
-  lt.n_levels = m->cfg.n_levels; lt.B = B;
+  lt.n_levels = L; lt.B = B;
   int acc = 0;
   for (int l = 0; l < lt.n_levels; ++l) {
     lt.T[l] = T0 >> l;
@@ -1317,13 +1329,198 @@ __global__ void k_gather_masks(MaskPtrs mp, uint8_t* __restrict__ dst, int T0) {
   if (t < T0) dst[(size_t)blockIdx.y * T0 + t] = mp.p[blockIdx.y][t];
 }
 
+
+// =============================================================================================
+// One long video cut at pyramid level k (dist.py hybrid_forward, SURVEY 8e: the NQ = 1 corner of T-sharding).
+// A rank holds TWO ordinary power-of-two pyramids: the NARROW one, levels 0 .. k on a window of Tn clips (everything a forward
+// does in front of level k + 1), and the COARSE one, levels k .. L - 1 on a window of Tc level-k rows whose level 0 is the
+// all-gathered level-k feature map.  Three phases with one exchange between each two:
+//   phase 1  narrow window: vid_map, early fusion, embedding, levels 0 .. k           -> level-k features (narrow window)
+//   phase 2  coarse window: levels k + 1 .. L - 1; cls_head on both pyramids; the refinement TCN on the narrow window's clips over the
+//            stacked logits of ALL levels (model.py:449-458); pooled down to level k    -> refined level-k map (narrow window)
+//   phase 3  refined map pooled down the coarse pyramid; cls_head2 / reg_head on both    -> outputs of levels <= k (narrow) and > k (coarse)
+// Windows are treated as sequences (zero padding at their ends); the halos of dist.hybrid_plan absorb that.
+// =============================================================================================
+struct HybridState {
+  bool valid = false;
+  int k = 0, Tn = 0, Tc = 0, B = 0, Lk = 0;
+  Buffers bn{};
+  Plan pn{}, pc{}, pch{};                     // narrow pyramid; coarse pyramid (levels k .. L-1); its levels k+1 .. (what the heads see)
+  float *Fc = nullptr, *logits1c = nullptr, *stacked = nullptr;
+  uint8_t *maskc = nullptr, *nbrc = nullptr;
+};
+
+static void free_hybrid(dcf_model* m) {
+  if (!m->hyb) return;
+  for (Plan* p : {&m->hyb->pn, &m->hyb->pc, &m->hyb->pch}) if (p->d_lt) (void)hipFree(p->d_lt);
+  delete m->hyb;
+  m->hyb = nullptr;
+}
+
+static int make_plan(dcf_model* m, Plan& p, const int* Tl, int n, int B, const float* scales, hipStream_t st) {
+  p.T0 = Tl[0]; p.B = B; p.L = n;
+  LevelTable& lt = p.lt;
+  lt = LevelTable{};
+  lt.n_levels = n; lt.B = B;
+  int acc = 0;
+  for (int l = 0; l < n; ++l) {
+    lt.T[l] = Tl[l]; lt.off[l] = acc; lt.start[l] = B * acc; lt.scale[l] = scales ? scales[l] : 1.f;
+    acc += Tl[l];
+  }
+  lt.S = acc; lt.start[n] = B * acc;
+  if (!p.d_lt) DCF_HIP(hipMalloc(&p.d_lt, sizeof(LevelTable)));
+  DCF_HIP(hipMemcpyAsync(p.d_lt, &p.lt, sizeof(LevelTable), hipMemcpyHostToDevice, st));
+  DCF_HIP(hipStreamSynchronize(st));
+  (void)m;
+  return 0;
+}
+
+// size of the coarse pyramid's own buffers behind the forward's workspace (phase 1 reserves them: no reallocation between phases)
+static size_t hybrid_extra_bytes(const dcf_config& c, int B, int Tc, int LC, int Tn, int L) {
+  size_t rows = 0;
+  for (int j = 0; j < LC; ++j) rows += (size_t)B * (Tc >> j);
+  const size_t EH = c.E + TCN_HID;
+  return rows * EH * 4 + 2 * (rows + 256) + rows * 4 + (size_t)B * Tn * L * 4 + 8 * 256;
+}
+
+static int hybrid_take(dcf_model* m, const Buffers& b, const Plan& pl, int B, int Lk, hipStream_t st) {
+  HybridState& h = *m->hyb;
+  const dcf_config& c = m->cfg;
+  const int E = c.E, ldf = E + TCN_HID, k = h.k;
+  h.bn = b; h.B = B; h.Lk = Lk;
+  h.pn.lt = pl.lt; h.pn.T0 = pl.T0; h.pn.B = pl.B; h.pn.L = pl.L;
+  if (!h.pn.d_lt) DCF_HIP(hipMalloc(&h.pn.d_lt, sizeof(LevelTable)));
+  DCF_HIP(hipMemcpyAsync(h.pn.d_lt, pl.d_lt, sizeof(LevelTable), hipMemcpyDeviceToDevice, st));
+  // the coarse pyramid's buffers
+  const int LC = c.n_levels - k;
+  Arena a{m->hyb_extra_ptr, 0, m->hyb_extra, false};
+  size_t rows = 0;
+  for (int j = 0; j < LC; ++j) rows += (size_t)B * (h.Tc >> j);
+  h.Fc = a.take<float>(rows * ldf);
+  h.maskc = a.take<uint8_t>(rows);
+  h.nbrc = a.take<uint8_t>(rows);
+  h.logits1c = a.take<float>(rows);
+  h.stacked = a.take<float>((size_t)B * h.Tn * c.n_levels);
+  DCF_CHECK(a.off <= m->hyb_extra, "internal: hybrid workspace");
+  // level-k features of the narrow window -> caller (B, Tn >> k, E)
+  DCF_HIP(hipMemcpy2DAsync(m->hyb_feat_out, (size_t)E * 4, b.F + (int64_t)pl.lt.start[k] * ldf, (size_t)ldf * 4, (size_t)E * 4,
+                           (size_t)B * pl.lt.T[k], hipMemcpyDeviceToDevice, st));
+  h.valid = true;
+  return 0;
+}
+
+// u[b][t][l] = logits1 of level l at the narrow window's clip t (nearest: index t >> l), times the clip's mask for l > 0 (model.py:449-455);
+// levels > k come from the coarse pyramid: its level j = l - k at index (((t >> k) + off_k) >> j)
+__global__ void k_hybrid_stack(const float* __restrict__ l1n, const LevelTable* __restrict__ ltn, const float* __restrict__ l1c,
+                               const LevelTable* __restrict__ ltc, const uint8_t* __restrict__ mask0, float* __restrict__ out,
+                               int B, int Tn, int k, int L, int off_k) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= B * Tn) return;
+  const int b = r / Tn, t = r - b * Tn;
+  const float m0 = mask0[r] ? 1.f : 0.f;
+  for (int l = 0; l < L; ++l) {
+    float u;
+    if (l <= k) u = l1n[ltn->start[l] + b * ltn->T[l] + (t >> l)];
+    else {
+      const int j = l - k - 1;                                    // level of the heads' coarse table (levels k + 1 ..)
+      int i = ((t >> k) + off_k) >> (j + 1);
+      i = i < 0 ? 0 : (i < ltc->T[j] ? i : ltc->T[j] - 1);
+      u = l1c[ltc->start[j] + b * ltc->T[j] + i];
+    }
+    out[(int64_t)r * L + l] = l > 0 ? u * m0 : u;
+  }
+}
+
+static RefineArgs refine_args(dcf_model* m) {
+  RefineArgs ra{};
+  ra.w_in = m->tcn_in_w; ra.b_in = m->tcn_in_b;
+  ra.host_w_dil = m->tcn_wd.data(); ra.host_b_dil = m->tcn_bd.data(); ra.host_w_pw = m->tcn_wp.data();
+  ra.host_b_pw = m->tcn_bp.data(); ra.host_ln_w = m->tcn_lnw.data(); ra.host_ln_b = m->tcn_lnb.data();
+  ra.w_out = m->tcn_out_w; ra.b_out = m->tcn_out_b;
+  ra.host_frag = (!m->tcn_frag.empty() && debug_option("tcn_frag", 1) != 0) ? m->tcn_frag.data() : nullptr;
+  ra.f16 = m->gemm_terms == GEMM_F16X3; ra.status = m->status;
+  return ra;
+}
+
+// Buffers of the coarse pyramid's HEAD levels (k + 1 ..): the narrow pyramid's scratch with F / masks / logits re-based
+static Buffers hybrid_coarse_heads(const HybridState& h, int ldf) {
+  Buffers bc = h.bn;
+  const int s1 = h.pc.lt.start[1];
+  bc.F = h.Fc + (int64_t)s1 * ldf; bc.mask_all = h.maskc + s1; bc.nbr_all = h.nbrc + s1; bc.logits1 = h.logits1c;
+  return bc;
+}
+
+static int hybrid_phase2(dcf_model* m, const float* featk_c, const uint8_t* maskk_c, int off_k, float* refk_out, hipStream_t st) {
+  HybridState& h = *m->hyb;
+  const dcf_config& c = m->cfg;
+  const int E = c.E, ldf = E + TCN_HID, k = h.k, L = c.n_levels, LC = L - k, B = h.B;
+  // ---- the coarse pyramid: level 0 = the gathered level-k features, its masks from the level-k validity of the window
+  DCF_HIP(hipMemcpy2DAsync(h.Fc, (size_t)ldf * 4, featk_c, (size_t)E * 4, (size_t)E * 4, (size_t)B * h.Tc, hipMemcpyDeviceToDevice, st));
+  for (int b = 0; b < B; ++b) DCF_HIP(hipMemcpyAsync(h.maskc + (size_t)b * h.Tc, maskk_c, (size_t)h.Tc, hipMemcpyDeviceToDevice, st));
+  TRY(launch_pyramid_masks(h.maskc, h.nbrc, B, h.Tc, LC, h.pc.lt.start[LC], st));
+  const LevelTable& lc = h.pc.lt;
+  for (int j = 1; j < LC; ++j) {
+    const float* xin = h.Fc + (int64_t)lc.start[j - 1] * ldf;
+    float* xo = h.Fc + (int64_t)lc.start[j] * ldf;
+    if (c.pool_only) TRY(launch_dwconv3(xin, ldf, h.maskc + lc.start[j - 1], m->pool_w[k + j], xo, ldf, B, lc.T[j - 1], 2, E, st));
+    else TRY(run_encoder(m, m->branch[k + j], h.bn, xin, ldf, h.maskc + lc.start[j - 1], h.maskc + lc.start[j], B, lc.T[j - 1], 2, xo, ldf, st));
+  }
+  // ---- cls_head on both pyramids (level-major rows)
+  TRY(run_head(m, m->cls1, h.bn, h.pn, E, 1, 0, 0, h.bn.logits1, st));
+  Buffers bc = hybrid_coarse_heads(h, ldf);
+  if (LC > 1) TRY(run_head(m, m->cls1, bc, h.pch, E, 1, 0, 0, h.logits1c, st));
+  // ---- the refinement TCN on the narrow window's clips over the stacked logits of all levels
+  const int rows0 = B * h.Tn;
+  hipLaunchKernelGGL(k_hybrid_stack, dim3((rows0 + 255) / 256), dim3(256), 0, st, (const float*)h.bn.logits1, (const LevelTable*)h.pn.d_lt,
+                     (const float*)h.logits1c, (const LevelTable*)h.pch.d_lt, (const uint8_t*)h.bn.mask_all, h.stacked, B, h.Tn, k, L, off_k);
+  DCF_HIP(hipGetLastError());
+  RefineArgs ra = refine_args(m);
+  ra.stacked = h.stacked; ra.mask_all = h.bn.mask_all;
+  ra.bufA = h.bn.tcnA; ra.bufB = h.bn.tcnB; ra.F = h.bn.F; ra.ldf = ldf; ra.E = E;
+  ra.B = B; ra.T0 = h.Tn; ra.n_levels = L; ra.n_layers = L;
+  TRY(launch_refine(ra, h.pn.lt, st));
+  const LevelTable& ln = h.pn.lt;
+  for (int l = 1; l <= k; ++l)
+    TRY(launch_refine_pool(h.bn.F, ldf, E, h.bn.mask_all + ln.start[l - 1], ln.start[l - 1], ln.start[l], B, ln.T[l - 1], st));
+  DCF_HIP(hipMemcpy2DAsync(refk_out, (size_t)TCN_HID * 4, h.bn.F + (int64_t)ln.start[k] * ldf + E, (size_t)ldf * 4, (size_t)TCN_HID * 4,
+                           (size_t)B * ln.T[k], hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+static int hybrid_phase3(dcf_model* m, const float* refk_c, float* logits_n, float* offsets_n, uint8_t* masks_n, float* logits_c,
+                         float* offsets_c, uint8_t* masks_c, hipStream_t st) {
+  HybridState& h = *m->hyb;
+  const dcf_config& c = m->cfg;
+  const int E = c.E, ldf = E + TCN_HID, LC = c.n_levels - h.k, B = h.B;
+  const LevelTable& lc = h.pc.lt;
+  DCF_HIP(hipMemcpy2DAsync(h.Fc + E, (size_t)ldf * 4, refk_c, (size_t)TCN_HID * 4, (size_t)TCN_HID * 4, (size_t)B * h.Tc, hipMemcpyDeviceToDevice, st));
+  for (int j = 1; j < LC; ++j)
+    TRY(launch_refine_pool(h.Fc, ldf, E, h.maskc + lc.start[j - 1], lc.start[j - 1], lc.start[j], B, lc.T[j - 1], st));
+  TRY(run_head_pair(m, m->cls2, m->reg, h.bn, h.pn, E + TCN_HID, 1, 0, logits_n, 2, 1, offsets_n, st));
+  const int rows_n = h.pn.lt.start[h.pn.lt.n_levels];
+  hipLaunchKernelGGL(k_masks_out, dim3((rows_n + 255) / 256), dim3(256), 0, st, (const uint8_t*)h.bn.mask_all, masks_n,
+                     (const LevelTable*)h.pn.d_lt, (const unsigned*)m->status, logits_n);
+  DCF_HIP(hipGetLastError());
+  if (LC > 1) {
+    Buffers bc = hybrid_coarse_heads(h, ldf);
+    TRY(run_head_pair(m, m->cls2, m->reg, bc, h.pch, E + TCN_HID, 1, 0, logits_c, 2, 1, offsets_c, st));
+    const int rows_c = h.pch.lt.start[h.pch.lt.n_levels];
+    hipLaunchKernelGGL(k_masks_out, dim3((rows_c + 255) / 256), dim3(256), 0, st, (const uint8_t*)bc.mask_all, masks_c,
+                       (const LevelTable*)h.pch.d_lt, (const unsigned*)m->status, logits_c);
+    DCF_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
 static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
                    const float* const* text, const uint8_t* const* text_mask, const int32_t* text_len,
                    const float* gate_override, float* logits_out, float* offsets_out,
                    uint8_t* masks_out, hipStream_t st) {
   const dcf_config& c = m->cfg;
-  const int E = c.E, D = c.D, L = c.n_levels;
+  const int E = c.E, D = c.D;
+  const int L = m->hyb_levels > 0 ? m->hyb_levels : c.n_levels;      // dcf_hybrid_phase1: the pyramid up to the split level only
   const int nvid = vs.nvid;
+  if (m->hyb) m->hyb->valid = false;              // the phases of a level-cut forward live in this workspace
   DCF_CHECK(m->finalized, "dcf_forward_eval: model not finalized");
   DCF_CHECK(T0 > 0 && nq > 0 && nvid >= 1 && nvid <= DCF_MAX_VIDEOS, "dcf_forward_eval: empty input");
   DCF_CHECK(!(gate_override && nvid != 1), "the externally gated forward takes one video");
@@ -1364,6 +1561,7 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
   {
     Arena dry{nullptr, 0, 0, true};
     carve(dry, c, T0, Bmax, nq, S, Lk, nvid, b);
+    (void)dry.take<char>(m->hyb_extra);
     if (dry.off > m->arena_bytes) {
       DCF_CHECK(!m->capturing, "internal: workspace growth during graph capture");
       drop_graph(m, true);                       // the eager call that grows the workspace still counts as the first sighting
@@ -1375,6 +1573,7 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
     }
     Arena real{m->arena, 0, m->arena_bytes, false};
     carve(real, c, T0, Bmax, nq, S, Lk, nvid, b);
+    m->hyb_extra_ptr = real.take<char>(m->hyb_extra);
   }
   // ---- per video: sidekick scores and the query-independent halves of vid_map
   DCF_CHECK(!(gate_override && c.scat), "opt.model.scat needs the sidekick scores: the externally gated (T-sharded) forward does not take them");
@@ -1431,7 +1630,7 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
   for (int q0 = 0; q0 < nq; q0 += Bmax) {
     const int B = std::min(Bmax, nq - q0);
     Plan* pl;
-    TRY(get_plan(m, Tp, B, st, &pl));
+    TRY(get_plan(m, Tp, B, L, st, &pl));
     const LevelTable& lt = pl->lt;
     const int rows0 = B * T0, rowsP = B * Tp, rowsAll = B * S;
     uint8_t* mask_in = sv > 1 ? b.mask_pre : b.mask_all;      // validity of the T0 input clips (gate stage)
@@ -1586,6 +1785,11 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
       }
     }
 
+    if (m->hyb_levels > 0) {                      // dcf_hybrid_phase1: the pyramid stands up to level k; hand it over and stop
+      TRY(hybrid_take(m, b, *pl, B, Lk, st));
+      continue;
+    }
+
     // ---- second / late fusion over the whole pyramid (model.py:443-444, :66-67; fusion.py:68-78), in place on F
     if (c.model_kind == 1 || c.second_fusion)
       TRY(run_fusion(m, b, b.F, E + TCN_HID, B, Tp, &lt, b.mask_all, b.nbr_all, dm, Lk, b.F, E + TCN_HID, st));
@@ -1705,7 +1909,7 @@ static int text_encode(dcf_model* m, const float* tokens, const uint8_t* token_m
 extern "C" {
 
 const char* dcf_last_error(void) { return dcf::g_err.c_str(); }
-int dcf_abi_version(void) { return 7; }
+int dcf_abi_version(void) { return 8; }
 
 int dcf_model_create(const dcf_config* cfg, dcf_model** out) {
   DCF_CHECK(cfg && out, "dcf_model_create: null argument");
@@ -1960,6 +2164,59 @@ int dcf_forward_eval_gated(dcf_model* m, const float* vid, const float* shallow_
   vs.nvid = 1; vs.vid[0] = vid; vs.shallow[0] = shallow_vid; vs.mask[0] = vid_mask; vs.text_cls[0] = nullptr; vs.nq[0] = nq;
   return dcf::forward_maybe_graph(m, vs, (int)T, nq, text, text_mask, text_len, gate,
                                   logits_out, offsets_out, masks_out, (hipStream_t)stream);
+}
+
+// ---- one long video cut at pyramid level k (see HybridState): three phases, an exchange between each two (dist.py hybrid_forward)
+int dcf_hybrid_phase1(dcf_model* m, int32_t k, const float* vid_w, const float* shallow_w, const uint8_t* mask_w, int64_t Tn, int64_t Tc,
+                      int32_t nq, const float* const* text, const uint8_t* const* text_mask, const int32_t* text_len, const float* gate_w,
+                      float* featk_out, void* stream) {
+  DCF_CHECK(m && vid_w && shallow_w && mask_w && text && text_len && gate_w && featk_out, "dcf_hybrid_phase1: null argument");
+  const dcf_config& c = m->cfg;
+  DCF_CHECK(m->finalized, "dcf_hybrid_phase1: model not finalized");
+  DCF_CHECK(c.model_kind == 0 && !c.second_fusion && c.msf && !c.scat && dcf::vid_stride_of(c) == 1,
+            "dcf_hybrid_phase1: the iterative early-fusion model with msf, without second_fusion / scat / vid_net.stride > 1");
+  const int L = c.n_levels, LC = L - k, half = c.win / 2 > 0 ? c.win / 2 : 1;
+  DCF_CHECK(k >= 0 && k < L, "dcf_hybrid_phase1: split level %d outside 0 .. %d", k, L - 1);
+  DCF_CHECK(Tn > 0 && Tn < (1ll << 24) && Tn % ((int64_t)half << k) == 0, "dcf_hybrid_phase1: the narrow window (%lld clips) must be a multiple of %d", (long long)Tn, half << k);
+  DCF_CHECK(Tc > 0 && Tc < (1ll << 24) && Tc % ((int64_t)half << (LC - 1)) == 0, "dcf_hybrid_phase1: the coarse window (%lld level-%d rows) must be a multiple of %d", (long long)Tc, k, half << (LC - 1));
+  const int Bmax = c.max_batch > 0 ? c.max_batch : 8;
+  DCF_CHECK(nq >= 1 && nq <= Bmax, "dcf_hybrid_phase1: 1 .. max_batch = %d queries per call", Bmax);
+  hipStream_t st = (hipStream_t)stream;
+  if (!m->hyb) m->hyb = new dcf::HybridState();
+  dcf::HybridState& h = *m->hyb;
+  h.valid = false; h.k = k; h.Tn = (int)Tn; h.Tc = (int)Tc;
+  int Tl[DCF_MAX_LEVELS];
+  for (int j = 0; j < LC; ++j) Tl[j] = (int)(Tc >> j);
+  if (dcf::make_plan(m, h.pc, Tl, LC, nq, m->reg_scales.data() + k, st)) return -1;
+  if (LC > 1 && dcf::make_plan(m, h.pch, Tl + 1, LC - 1, nq, m->reg_scales.data() + k + 1, st)) return -1;
+  dcf::VideoSet vs;
+  vs.nvid = 1; vs.vid[0] = vid_w; vs.shallow[0] = shallow_w; vs.mask[0] = mask_w; vs.text_cls[0] = nullptr; vs.nq[0] = nq;
+  m->hyb_levels = k + 1;
+  m->hyb_extra = dcf::hybrid_extra_bytes(c, nq, (int)Tc, LC, (int)Tn, L);
+  m->hyb_feat_out = featk_out;
+  const int rc = dcf::forward(m, vs, (int)Tn, nq, text, text_mask, text_len, gate_w, nullptr, nullptr, nullptr, st);
+  m->hyb_levels = 0;
+  m->hyb_extra = 0;
+  m->hyb_feat_out = nullptr;
+  if (rc == 0) DCF_CHECK(h.valid, "internal: hybrid phase 1 did not reach the hand-over");
+  return rc;
+}
+
+int dcf_hybrid_phase2(dcf_model* m, const float* featk_c, const uint8_t* maskk_c, int64_t off_k, float* refk_out, void* stream) {
+  DCF_CHECK(m && featk_c && maskk_c && refk_out, "dcf_hybrid_phase2: null argument");
+  DCF_CHECK(m->hyb && m->hyb->valid, "dcf_hybrid_phase2: no phase 1 on this model (or another forward ran since)");
+  DCF_CHECK(off_k >= 0 && off_k + (m->hyb->Tn >> m->hyb->k) <= m->hyb->Tc, "dcf_hybrid_phase2: the narrow window must lie inside the coarse one");
+  return dcf::hybrid_phase2(m, featk_c, maskk_c, (int)off_k, refk_out, (hipStream_t)stream);
+}
+
+int dcf_hybrid_phase3(dcf_model* m, const float* refk_c, float* logits_n, float* offsets_n, uint8_t* masks_n, float* logits_c,
+                      float* offsets_c, uint8_t* masks_c, void* stream) {
+  DCF_CHECK(m && refk_c && logits_n && offsets_n && masks_n, "dcf_hybrid_phase3: null argument");
+  DCF_CHECK(m->hyb && m->hyb->valid, "dcf_hybrid_phase3: no phase 1 / 2 on this model (or another forward ran since)");
+  DCF_CHECK(m->cfg.n_levels - m->hyb->k <= 1 || (logits_c && offsets_c && masks_c), "dcf_hybrid_phase3: null coarse outputs");
+  const int rc = dcf::hybrid_phase3(m, refk_c, logits_n, offsets_n, masks_n, logits_c, offsets_c, masks_c, (hipStream_t)stream);
+  m->hyb->valid = false;
+  return rc;
 }
 
 int dcf_graph_active(const dcf_model* m) { return m ? m->last_launch : 0; }

@@ -57,6 +57,9 @@ struct RefineArgs {
   unsigned* status;                   // f16: sticky numerics word (bit 0 raised on a non-finite intermediate), may be null
 };
 int launch_refine(const RefineArgs& a, const LevelTable& host_lt, hipStream_t st);
+// masked max-pool (k3, s2) of the 32 refined channels (columns [E, E + 32) of F) from the rows of one level to the next
+int launch_refine_pool(float* F, int64_t ldf, int E, const uint8_t* mask_in, int64_t in_row0, int64_t out_row0, int B, int T_in,
+                       hipStream_t st);
 // raises *flag if a weight of the TCN does not fit the scaled fp16 range of the f16 mode (|w| < 255.9)
 int launch_f16_weight_range(const float* w, int n, unsigned* flag, hipStream_t st);
 // fp16 hi / lo MFMA fragments of one TCN layer's weights (dilated conv [3][32][32], conv_1x1 [32][32], optionally refine.conv_out

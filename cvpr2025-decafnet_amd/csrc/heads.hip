@@ -856,6 +856,16 @@ __global__ __launch_bounds__(256) void k_refine_pool_all(float* __restrict__ F, 
   }
 }
 
+// one level of the refined map's pooling chain by itself (dcf_hybrid_phase2 / 3: two pyramids, an exchange in the middle)
+int launch_refine_pool(float* F, int64_t ldf, int E, const uint8_t* mask_in, int64_t in_row0, int64_t out_row0, int B, int T_in,
+                       hipStream_t st) {
+  const int n = B * (T_in / 2) * 8;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_refine_pool, dim3((n + 255) / 256), dim3(256), 0, st, F, ldf, E, mask_in, in_row0, out_row0, B, T_in);
+  DCF_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_refine(const RefineArgs& a, const LevelTable& lt, hipStream_t st) {
   const int rows0 = a.B * a.T0;
   if (rows0 <= 0) return 0;

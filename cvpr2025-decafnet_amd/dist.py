@@ -174,6 +174,20 @@ class HipBackend:
         return self.model._last_flat          # (nq, S_w), (nq, S_w, 2), (nq, S_w)
 
 
+    # the three phases of ``hybrid_forward`` (dcf_hybrid_phase1 / 2 / 3 through the model)
+    def hybrid_phase1(self, vid_w, shallow_w, mask_w, texts, tmasks, gate_w, T_global, n_lo, k, Tc):
+        pe = None
+        if self.model.vid_net.use_abs_pe:
+            pe = self.model.full_position_encoding(T_global, vid_w.device)[n_lo:n_lo + vid_w.shape[-1]]
+        return self.model.hybrid_phase1(vid_w, shallow_w, mask_w, texts, tmasks, gate_w, k, Tc, pe)
+
+    def hybrid_phase2(self, featk_c, maskk_c, off_k):
+        return self.model.hybrid_phase2(featk_c, maskk_c, off_k)
+
+    def hybrid_phase3(self, refk_c):
+        return self.model.hybrid_phase3(refk_c)
+
+
 def _gather_static(x: torch.Tensor, sizes: Sequence[int], group=None) -> List[torch.Tensor]:
     """ONE all-gather of per-rank pieces whose lengths along the LAST-but-k layout are known to every rank from the shard
     plan (no size exchange): ``x`` is this rank's piece flattened to (n_r, ...) rows with n_r = sizes[rank]; pieces are
@@ -303,6 +317,142 @@ def sharded_forward(backend, vid_w, shallow_w, mask_full, plan, rank, T, n_level
             lv.append(pieces[r][offs[r]:offs[r] + n])
             offs[r] += n
         lv = torch.cat(lv, 0).transpose(0, 1)                                              # (nq, T_l, 4)
+        out_l.append(lv[..., 0])
+        out_o.append(lv[..., 1:3])
+        out_m.append(lv[..., 3] != 0)
+    mark('done')
+    lg = [tuple(x[q][None] for x in out_l) for q in range(nq)]
+    of = [tuple(x[q][None] for x in out_o) for q in range(nq)]
+    mk = [tuple(x[q][None] for x in out_m) for q in range(nq)]
+    return lg, of, mk
+
+
+# ---------------------------------------------------------------------------------------------
+# T-sharding WITHOUT recomputing the top of the pyramid: the pyramid cut at level k
+# ---------------------------------------------------------------------------------------------
+def hybrid_halos(n_levels: int, win: int, k: int, fusion_layers: int = 2, n_embd_convs: int = 2, n_stem: int = 0, head_layers: int = 2):
+    """(hA, hB): one-sided halo of the NARROW window in clips (levels 0..k: early fusion, embedding, the encoder up to level k, cls_head on
+    the level-k grid, the refinement TCN's 2^L - 1 clips, the pooling chain down to level k, cls_head2 / reg_head) and of the COARSE window in
+    level-k rows (it must cover the narrow window -- the TCN stacks the logits of every level at the narrow window's clips -- plus the
+    encoder reach of levels k+1..L-1 on the level-k grid, the heads' three rows of the top level and the pooling chain), each rounded up to
+    the window alignment of its pyramid (blocks.py:216: every level a multiple of win // 2)."""
+    L, hw = n_levels, win // 2
+    hw1 = max(hw, 1)
+    LC = L - k
+    r_enc = fusion_layers + n_embd_convs + n_stem * (1 + hw) + (1 + hw) + sum(2 ** (l - 1) + hw * 2 ** l for l in range(1, k + 1))
+    hA = r_enc + 2 * (head_layers + 1) * 2 ** k + (2 ** L - 1) + 2 ** k
+    an = 2 ** k * hw1
+    hA = -(-hA // an) * an
+    encC = sum(2 ** (j - 1) + hw * 2 ** j for j in range(1, LC))
+    hB = hA // 2 ** k + encC + (head_layers + 2) * 2 ** (LC - 1)
+    ac = 2 ** (LC - 1) * hw1
+    hB = -(-hB // ac) * ac
+    return hA, hB
+
+
+def hybrid_plan(T: int, world: int, n_levels: int, win: int, k: int = None, **arch):
+    """Per rank: owned clips [lo, hi), narrow window [n_lo, n_hi) (clips), coarse window [c_lo, c_hi) (level-k rows); ``k`` = None picks
+    the split level with the fewest rows per rank.  Everything is a function of (T, world, L, w, arch): nothing is negotiated at run
+    time.  Returns dict(k, ranks=[dict(lo, hi, n_lo, n_hi, c_lo, c_hi)], rows_factor)."""
+    L = n_levels
+    a = alignment(L, win)
+    assert T % a == 0, f'T={T} must be a multiple of {a}'
+    units = T // a
+
+    def build(kk):
+        hA, hB = hybrid_halos(L, win, kk, **arch)
+        Tk = T >> kk
+        ranks, worst = [], 0
+        for r in range(world):
+            lo, hi = (units * r // world) * a, (units * (r + 1) // world) * a
+            n_lo, n_hi = max(0, lo - hA), min(T, hi + hA)
+            c_lo, c_hi = max(0, (lo >> kk) - hB), min(Tk, (hi >> kk) + hB)
+            assert (n_lo >> kk) >= c_lo and (n_hi >> kk) <= c_hi
+            rows = sum((n_hi - n_lo) >> l for l in range(kk + 1)) + sum((c_hi - c_lo) >> j for j in range(1, L - kk))
+            worst = max(worst, rows)
+            ranks.append(dict(lo=lo, hi=hi, n_lo=n_lo, n_hi=n_hi, c_lo=c_lo, c_hi=c_hi))
+        even = sum((T // world) >> l for l in range(L))
+        return dict(k=kk, ranks=ranks, rows_factor=worst / even)
+
+    if k is not None:
+        return build(k)
+    return min((build(kk) for kk in range(1, L - 1)), key=lambda p: (p['rows_factor'], p['k']))
+
+
+def hybrid_forward(backend, vid_w, shallow_w, mask_full, plan, rank, T, n_levels, texts, text_cls, tmasks, group=None, timings=None):
+    """Eval forward of ONE video sharded over the ranks of ``group`` with the pyramid cut at level ``plan['k']`` (``hybrid_plan``).
+
+    vid_w, shallow_w : (D, n_hi - n_lo) this rank's NARROW window of the features
+    Returns the whole video's outputs on every rank, exactly like ``model(..., eval=True)`` (and like ``sharded_forward``).
+
+    Four collectives, each ONE all-gather with plan-derived static sizes:
+      AG-1  raw sidekick scores of the owned clips (as ``sharded_forward``)
+      AG-F  the owned slice of the level-k features, (own >> k, NQ, E) fp32       (8 MB in all at T = 65 536, k = 3, E = 256)
+      AG-R  the owned slice of the refined level-k map, (own >> k, NQ, 32) fp32
+      AG-2  the owned slice of every level's outputs, packed (logit, offset0, offset1, mask)
+    """
+    k, me = plan['k'], plan['ranks'][rank]
+    ranks = plan['ranks']
+    lo, hi, n_lo, n_hi, c_lo, c_hi = (me[x] for x in ('lo', 'hi', 'n_lo', 'n_hi', 'c_lo', 'c_hi'))
+    nq = text_cls.shape[0]
+    L = n_levels
+    mark = timings.mark if timings is not None else (lambda name: None)
+    # AG-1
+    mark('scores')
+    sc = backend.scores(shallow_w[:, lo - n_lo:hi - n_lo], text_cls)
+    mark('ag1')
+    pieces = _gather_static(sc.t().contiguous(), [p['hi'] - p['lo'] for p in ranks], group)
+    correl = torch.cat(pieces, 0).t().contiguous()
+    mark('gate')
+    gate_full = backend.gate(correl, mask_full)
+    # phase 1 + AG-F
+    mark('phase1')
+    featk_w = backend.hybrid_phase1(vid_w, shallow_w, mask_full[n_lo:n_hi].contiguous(), texts, tmasks,
+                                    gate_full[:, n_lo:n_hi].contiguous(), T, n_lo, k, c_hi - c_lo)             # (nq, Tn >> k, E)
+    own_k = [(p['hi'] - p['lo']) >> k for p in ranks]
+    mark('agF')
+    pieces = _gather_static(featk_w[:, (lo - n_lo) >> k:(hi - n_lo) >> k].transpose(0, 1).contiguous(), own_k, group)
+    featk_c = torch.cat(pieces, 0)[c_lo:c_hi].transpose(0, 1).contiguous()                                        # (nq, Tc, E)
+    # phase 2 + AG-R
+    mark('phase2')
+    maskk_c = mask_full[::2 ** k][c_lo:c_hi].contiguous()
+    refk_w = backend.hybrid_phase2(featk_c, maskk_c, (n_lo >> k) - c_lo)                                          # (nq, Tn >> k, 32)
+    mark('agR')
+    pieces = _gather_static(refk_w[:, (lo - n_lo) >> k:(hi - n_lo) >> k].transpose(0, 1).contiguous(), own_k, group)
+    refk_c = torch.cat(pieces, 0)[c_lo:c_hi].transpose(0, 1).contiguous()
+    # phase 3
+    mark('phase3')
+    (lg_n, of_n, mk_n), (lg_c, of_c, mk_c) = backend.hybrid_phase3(refk_c)
+    mark('pack')
+    Tn, Tc = n_hi - n_lo, c_hi - c_lo
+
+    def owned_rows(xn, xc):                     # -> (S_own, nq, ...): the owned slice of every level, levels concatenated
+        parts, off = [], 0
+        for l in range(k + 1):
+            parts.append(xn[:, off + ((lo - n_lo) >> l):off + ((hi - n_lo) >> l)])
+            off += Tn >> l
+        off = 0
+        for j in range(1, L - k):
+            a_, b_ = ((lo >> k) - c_lo) >> j, ((hi >> k) - c_lo) >> j
+            parts.append(xc[:, off + a_:off + b_])
+            off += Tc >> j
+        return torch.cat(parts, 1).transpose(0, 1)
+
+    packed = torch.cat((owned_rows(lg_n, lg_c).unsqueeze(-1), owned_rows(of_n, of_c),
+                        owned_rows(mk_n, mk_c).unsqueeze(-1).to(lg_n.dtype)), -1)
+    s_own = [sum((p['hi'] - p['lo']) >> l for l in range(L)) for p in ranks]
+    mark('ag2')
+    pieces = _gather_static(packed.contiguous(), s_own, group)
+    mark('unpack')
+    out_l, out_o, out_m = [], [], []
+    offs = [0] * len(ranks)
+    for l in range(L):
+        lv = []
+        for r, p in enumerate(ranks):
+            n = (p['hi'] - p['lo']) >> l
+            lv.append(pieces[r][offs[r]:offs[r] + n])
+            offs[r] += n
+        lv = torch.cat(lv, 0).transpose(0, 1)
         out_l.append(lv[..., 0])
         out_o.append(lv[..., 1:3])
         out_m.append(lv[..., 3] != 0)

@@ -672,6 +672,77 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         return self._drop_forward_eval(vid, shallow_vid, vid_masks, text, None, text_masks, eval=True, gate=gate,
                                        pe_tokens=pe_tokens)
 
+    # -- one long video cut at pyramid level k (dist.hybrid_forward; dcf_hybrid_phase1 / 2 / 3) --------------------------------
+    def hybrid_phase1(self, vid_w, shallow_w, mask_w, text, text_masks, gate_w, k, Tc, pe_tokens=None):
+        """Levels 0..k on the narrow window (vid_w, shallow_w: (D, Tn); mask_w: (Tn,); gate_w: (NQ, Tn) the externally selected gate;
+        pe_tokens: (Tn, E) the window's slice of the video's position encoding; Tc: level-k rows of the coarse window the later phases
+        will use).  Returns the window's level-k features (NQ, Tn >> k, E)."""
+        dev = vid_w.device
+        if self._engine is None:
+            self._engine = _Engine(self._config())
+        self._raise_if_flagged()
+        eng = self._engine
+        eng.bind(self)
+        lib = eng.lib
+        Tn = vid_w.size(-1)
+        vid_c, sh_c = vid_w.contiguous().float(), shallow_w.contiguous().float()
+        mask_c = mask_w.reshape(-1).to(torch.bool).contiguous()
+        nq = len(text)
+        gate_c = gate_w.contiguous().float()
+        assert vid_c.shape == sh_c.shape == (self.D, Tn) and mask_c.numel() == Tn and gate_c.shape == (nq, Tn)
+        keep = []
+        tptr, mptr, tlen = (ctypes.c_void_p * nq)(), (ctypes.c_void_p * nq)(), (ctypes.c_int32 * nq)()
+        for q in range(nq):
+            t = text[q][0].contiguous().float()
+            m = text_masks[q].reshape(-1).to(torch.bool).contiguous()
+            keep += [t, m]
+            tptr[q], mptr[q], tlen[q] = t.data_ptr(), m.data_ptr(), t.size(1)
+        pe = None
+        if self.vid_net.use_abs_pe:
+            pe = pe_tokens.contiguous().float()
+            assert pe.shape == (Tn, self.E)
+            _lib.check(lib.dcf_model_set_pe(eng.handle, _lib.ptr(pe), Tn), 'dcf_model_set_pe')
+        featk = torch.empty(nq, Tn >> k, self.E, device=dev, dtype=torch.float32)
+        _lib.check(lib.dcf_hybrid_phase1(eng.handle, k, _lib.ptr(vid_c), _lib.ptr(sh_c), _lib.ptr(mask_c), Tn, Tc, nq, tptr, mptr, tlen,
+                                         _lib.ptr(gate_c), _lib.ptr(featk), _lib.current_stream()), 'dcf_hybrid_phase1')
+        self._last_inputs = (vid_c, sh_c, mask_c, gate_c, keep, pe)
+        self._hybrid = (k, Tn, Tc, nq)
+        return featk
+
+    def hybrid_phase2(self, featk_c, maskk_c, off_k):
+        """featk_c (NQ, Tc, E), maskk_c (Tc,): the gathered level-k features / level-k validity on the coarse window; off_k: first level-k
+        row of the narrow window inside it.  Returns the refined map at level k on the narrow window (NQ, Tn >> k, 32)."""
+        k, Tn, Tc, nq = self._hybrid
+        lib, eng = self._engine.lib, self._engine
+        f = featk_c.contiguous().float()
+        mk = maskk_c.reshape(-1).to(torch.bool).contiguous()
+        assert f.shape == (nq, Tc, self.E) and mk.numel() == Tc
+        refk = torch.empty(nq, Tn >> k, 32, device=f.device, dtype=torch.float32)
+        _lib.check(lib.dcf_hybrid_phase2(eng.handle, _lib.ptr(f), _lib.ptr(mk), int(off_k), _lib.ptr(refk), _lib.current_stream()),
+                   'dcf_hybrid_phase2')
+        self._last_inputs = self._last_inputs + (f, mk)
+        return refk
+
+    def hybrid_phase3(self, refk_c):
+        """refk_c (NQ, Tc, 32): the gathered refined level-k map on the coarse window.  Returns ((logits, offsets, masks) of levels 0..k
+        on the narrow window, the same of levels k+1.. on the coarse window), each flat over its levels like ``_last_flat``."""
+        k, Tn, Tc, nq = self._hybrid
+        lib, eng = self._engine.lib, self._engine
+        r = refk_c.contiguous().float()
+        assert r.shape == (nq, Tc, 32)
+        L = self.vid_net.arch[2]
+        Sn = sum(Tn >> l for l in range(k + 1))
+        Sc = sum(Tc >> j for j in range(1, L - k))
+        dev = r.device
+        ln, on, mn = (torch.empty(nq, Sn, device=dev), torch.empty(nq, Sn, 2, device=dev), torch.empty(nq, Sn, device=dev, dtype=torch.bool))
+        lc, oc, mc = (torch.empty(nq, max(Sc, 1), device=dev), torch.empty(nq, max(Sc, 1), 2, device=dev),
+                      torch.empty(nq, max(Sc, 1), device=dev, dtype=torch.bool))
+        _lib.check(lib.dcf_hybrid_phase3(eng.handle, _lib.ptr(r), _lib.ptr(ln), _lib.ptr(on), _lib.ptr(mn), _lib.ptr(lc), _lib.ptr(oc),
+                                         _lib.ptr(mc), _lib.current_stream()), 'dcf_hybrid_phase3')
+        self._last_inputs = self._last_inputs + (r,)
+        self._probe_numerics()
+        return (ln, on, mn), (lc[:, :Sc], oc[:, :Sc], mc[:, :Sc])
+
     def full_position_encoding(self, T, device):
         """vid_net.pe for a video of T clips, token-major (T, E)"""
         if self._engine is None:

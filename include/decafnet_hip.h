@@ -186,6 +186,26 @@ int dcf_forward_eval_videos(dcf_model* m, int32_t nvid, const float* const* vid,
  * hold max_floats >= B*T*E floats (checked by that forward). */
 int dcf_debug_copy(dcf_model* m, int32_t what, float* dst, int64_t max_floats, void* stream);
 
+/* One long video with few queries, T-sharded over ranks WITHOUT recomputing the top of the pyramid (extension; the reference's eval is
+ * single-GPU, libs/worker_v2.py:922-924).  The pyramid is cut at level k: a rank runs levels 0..k on a NARROW window of Tn clips and levels
+ * k+1..L-1 on a COARSE window of Tc level-k rows taken from the all-gathered level-k feature map; the refinement TCN (model.py:449-458)
+ * couples the levels, hence a second exchange (the refined level-k map).  cvpr2025-decafnet_amd/dist.py `hybrid_plan` / `hybrid_forward`
+ * derive the windows and run the collectives; windows are treated as sequences, their halos absorb the ends.  ABI version 8.
+ *   phase 1: vid_map, early fusion, embedding, levels 0..k on the narrow window with the caller's gate (as dcf_forward_eval_gated; set the
+ *            window's position-encoding slice with dcf_model_set_pe first) -> featk_out (nq, Tn >> k, E)
+ *   phase 2: featk_c (nq, Tc, E) / maskk_c (Tc): the gathered level-k features and level-k validity on the coarse window; off_k = first
+ *            level-k row of the narrow window inside the coarse one -> refk_out (nq, Tn >> k, 32): the refined map at level k
+ *   phase 3: refk_c (nq, Tc, 32): the gathered refined map on the coarse window -> outputs of levels 0..k on the narrow window
+ *            (logits_n (nq, Sn), offsets_n (nq, Sn, 2), masks_n (nq, Sn), Sn = sum_{l<=k} Tn >> l) and of levels k+1.. on the coarse one
+ *            (.._c, Sc = sum_{j>=1} Tc >> j), levels concatenated as in dcf_forward_eval.
+ * Any other forward on the model between the phases invalidates them (they share its workspace). */
+int dcf_hybrid_phase1(dcf_model* m, int32_t k, const float* vid_w, const float* shallow_w, const uint8_t* mask_w, int64_t Tn, int64_t Tc,
+                      int32_t nq, const float* const* text, const uint8_t* const* text_mask, const int32_t* text_len, const float* gate_w,
+                      float* featk_out, void* stream);
+int dcf_hybrid_phase2(dcf_model* m, const float* featk_c, const uint8_t* maskk_c, int64_t off_k, float* refk_out, void* stream);
+int dcf_hybrid_phase3(dcf_model* m, const float* refk_c, float* logits_n, float* offsets_n, uint8_t* masks_n, float* logits_c,
+                      float* offsets_c, uint8_t* masks_c, void* stream);
+
 /* How the last dcf_forward_eval* call on this model was issued: 0 = eager kernel launches, 1 = replay of the captured HIP
  * graph, 2 = the call that captured the graph (and launched it).  A forward called on the NULL (legacy default) stream,
  * which cannot be captured, runs on an engine-owned stream ordered after / before the caller's by events.  ABI version 4. */

@@ -43,6 +43,103 @@ class OracleBackend:
         return cat(lg, 0), cat(of, 0), cat(mk, 0)
 
 
+class OracleHybridBackend(OracleBackend):
+    """the three phases of dist.hybrid_forward on the CPU oracle: the specification the engine's dcf_hybrid_phase1 / 2 / 3 follow"""
+
+    def hybrid_phase1(self, vid_w, shallow_w, mask_w, texts, tmasks, gate_w, T_global, n_lo, k, Tc):
+        R, cfg, sd = self.R, self.cfg, self.sd
+        vn = dict(cfg['vid_net'])
+        pe = R.position_encoding(vn['max_seq_len'], vn['embd_dim'])
+        pe = R.resample_pe(pe, T_global, vn['max_seq_len'])[:, n_lo:n_lo + vid_w.shape[-1]]
+        vn['arch'] = (vn['arch'][0], vn['arch'][1], k + 1)
+        self.k, self.L, self.narrow, self.texts = k, cfg['vid_net']['arch'][2], [], (texts, tmasks)
+        feats = []
+        for b in range(len(texts)):
+            x = torch.cat([vid_w[None] * gate_w[b][None, None, :], shallow_w[None]], dim=1)
+            m = mask_w[None, None, :]
+            x, m = R.masked_conv1d(x, m, sd['vid_map.conv.weight'], sd['vid_map.conv.bias'])
+            fused, fm = R.xattn_fusion(sd, cfg['fusion'], x, m, texts[b], tmasks[b])
+            fpn, fpn_masks = R.video_transformer(sd, vn, fused, fm, pe_override=pe)
+            self.narrow.append((list(fpn), list(fpn_masks)))
+            feats.append(fpn[k][0].t())
+        return torch.stack(feats, 0)                                     # (nq, Tn >> k, E)
+
+    def hybrid_phase2(self, featk_c, maskk_c, off_k):
+        R, cfg, sd, k, L = self.R, self.cfg, self.sd, self.k, self.L
+        hl = cfg['cls_head'].get('n_layers', 2)
+        vn = cfg['vid_net']
+        self.coarse, refs = [], []
+        for b in range(featk_c.shape[0]):
+            x, m = featk_c[b].t()[None], maskk_c[None, None, :]
+            fpn_c, masks_c = [x], [m]                                    # coarse level 0 = the gathered level-k features
+            for j in range(1, L - k):
+                x, m = R.transformer_encoder(sd, f'vid_net.branch.{k + j}', x, m, 2, vn['n_heads'], vn['mha_win_size'])
+                fpn_c.append(x)
+                masks_c.append(m)
+            fpn_n, masks_n = self.narrow[b]
+            l1n, _ = R.cls_head(sd, 'cls_head', fpn_n, masks_n, hl)
+            l1c, _ = R.cls_head(sd, 'cls_head', fpn_c[1:], masks_c[1:], hl)
+            Tn = l1n[0].shape[1]
+            t = torch.arange(Tn)
+            rows = [l1n[0][0]]
+            for l in range(1, k + 1):
+                rows.append(l1n[l][0][t >> l] * masks_n[0][0, 0])
+            for j in range(1, L - k):
+                idx = (((t >> k) + off_k) >> j).clamp(0, l1c[j - 1].shape[1] - 1)
+                rows.append(l1c[j - 1][0][idx] * masks_n[0][0, 0])
+            expand = R.tcn_refine(sd, 'refine', torch.stack(rows, 0)[None], masks_n[0], L)
+            ref = [expand]
+            for l in range(1, k + 1):
+                ref.append(R.masked_max_pool1d(ref[-1], masks_n[l - 1])[0])
+            self.narrow[b] = (fpn_n, masks_n, ref)
+            self.coarse.append((fpn_c, masks_c))
+            refs.append(ref[k][0].t())
+        return torch.stack(refs, 0)                                      # (nq, Tn >> k, 32)
+
+    def hybrid_phase3(self, refk_c):
+        R, cfg, sd, k, L = self.R, self.cfg, self.sd, self.k, self.L
+        hl = cfg['cls_head'].get('n_layers', 2)
+        outs_n, outs_c = [], []
+        for b in range(refk_c.shape[0]):
+            fpn_n, masks_n, ref_n = self.narrow[b]
+            fpn_c, masks_c = self.coarse[b]
+            ref_c = [refk_c[b].t()[None]]
+            for j in range(1, L - k):
+                ref_c.append(R.masked_max_pool1d(ref_c[-1], masks_c[j - 1])[0])
+            new_n = [torch.cat([f, r], 1) for f, r in zip(fpn_n, ref_n)]
+            new_c = [torch.cat([f, r], 1) for f, r in zip(fpn_c[1:], ref_c[1:])]
+
+            def heads(fpn, masks, first_level):
+                lg, _ = R.cls_head(sd, 'cls_head2', fpn, masks, hl)
+                raw = R.conv_head(sd, 'reg_head', 'reg_head', fpn, masks, cfg['reg_head'].get('n_layers', 2))
+                of = [torch.relu(o * sd[f'reg_head.scales.{first_level + i}.scale']).transpose(1, 2) for i, o in enumerate(raw)]
+                cat = lambda xs: torch.cat([x[0] for x in xs], 0)      # noqa: E731
+                return cat(lg), cat(of), torch.cat([m[0, 0] for m in masks], 0)
+            outs_n.append(heads(new_n, masks_n, 0))
+            outs_c.append(heads(new_c, masks_c[1:], k + 1))
+        st = lambda outs, i: torch.stack([o[i] for o in outs], 0)      # noqa: E731
+        return (st(outs_n, 0), st(outs_n, 1), st(outs_n, 2)), (st(outs_c, 0), st(outs_c, 1), st(outs_c, 2))
+
+
+def _worker_hybrid(rank, world, port, outdir, k):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        pkg, opt, sd, inp, texts, tmasks = _setup()
+        d = pkg.dist
+        plan = d.hybrid_plan(T, world, KW['n_levels'], KW['win'], k)
+        me = plan['ranks'][rank]
+        backend = OracleHybridBackend(sd, opt.model)
+        with torch.no_grad():
+            out = d.hybrid_forward(backend, inp['vid'][0][:, me['n_lo']:me['n_hi']], inp['shallow_vid'][0][:, me['n_lo']:me['n_hi']],
+                                   inp['vid_masks'][0], plan, rank, T, KW['n_levels'], texts, inp['text_cls'], tmasks)
+        torch.save((rank, [list(lv) for lv in out[0]], [list(lv) for lv in out[1]], [list(lv) for lv in out[2]], plan),
+                   os.path.join(outdir, f'rank{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
 def _setup():
     pkg = load_pkg()
     opt = pkg.config.make_opt(**KW)
@@ -185,6 +282,55 @@ def test_sharded_forward_matches_unsharded_world2():
         want = R.forward_eval(sd, opt.model, inp['vid'], inp['shallow_vid'], inp['vid_masks'], texts, inp['text_cls'], tmasks)
     plan = results[0][4]
     assert plan[0][3] < T or plan[1][2] > 0, 'the test must really cut the video (windows smaller than T)'
+    for rank, lg, of, mk, _ in results:
+        for qi in range(NQ):
+            for l in range(KW['n_levels']):
+                assert torch.equal(mk[qi][l], want[2][qi][l]), (rank, qi, l)
+                torch.testing.assert_close(lg[qi][l], want[0][qi][l], rtol=1e-5, atol=2e-5)
+                torch.testing.assert_close(of[qi][l], want[1][qi][l], rtol=1e-5, atol=2e-5)
+
+
+def test_hybrid_plan_rows():
+    """the pyramid cut at level k: rows a rank computes over an even share (BASELINE config 4 sizes, one query), window alignments"""
+    d = load_pkg().dist
+    p = d.hybrid_plan(65536, 8, 8, 9)
+    assert p['k'] == 3 and p['rows_factor'] <= 1.15, p['rows_factor']            # VERDICT r03 item 7's bar (the pure T-shard: 1.56)
+    assert d.hybrid_plan(65536, 4, 8, 9)['rows_factor'] <= 1.07
+    for world in (2, 4, 8):
+        for k in (1, 2, 3, 4, 5):
+            q = d.hybrid_plan(65536, world, 8, 9, k)
+            prev = 0
+            for r in q['ranks']:
+                assert r['lo'] == prev and r['hi'] > r['lo']
+                prev = r['hi']
+                assert (r['n_hi'] - r['n_lo']) % (4 << k) == 0 and r['n_lo'] % (1 << k) == 0
+                assert (r['c_hi'] - r['c_lo']) % (4 << (8 - k - 1)) == 0 and r['c_lo'] % (1 << (8 - k - 1)) == 0
+                assert (r['n_lo'] >> k) >= r['c_lo'] and (r['n_hi'] >> k) <= r['c_hi']
+            assert prev == 65536
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('world,k', [(2, 1), (2, 2), (4, 1)])
+def test_hybrid_forward_matches_unsharded(world, k):
+    """hybrid_forward over `world` gloo ranks (pyramid cut at level k: narrow windows for levels <= k, coarse windows above, four
+    static-size all-gathers): every rank ends with the whole video's outputs = the unsharded oracle"""
+    import tempfile
+    ctx = mp.get_context('spawn')
+    port = 29300 + (os.getpid() + 13 * world + k) % 250
+    with tempfile.TemporaryDirectory() as outdir:
+        procs = [ctx.Process(target=_worker_hybrid, args=(r, world, port, outdir, k)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(800)
+            assert p.exitcode == 0
+        results = [torch.load(os.path.join(outdir, f'rank{r}.pt')) for r in range(world)]
+    pkg, opt, sd, inp, texts, tmasks = _setup()
+    from oracle import decafnet_ref as R
+    with torch.no_grad():
+        want = R.forward_eval(sd, opt.model, inp['vid'], inp['shallow_vid'], inp['vid_masks'], texts, inp['text_cls'], tmasks)
+    plan = results[0][4]
+    assert any(r['n_hi'] - r['n_lo'] < T for r in plan['ranks']), 'the test must really cut the video'
     for rank, lg, of, mk, _ in results:
         for qi in range(NQ):
             for l in range(KW['n_levels']):
