@@ -62,6 +62,7 @@ def parse():
     ap.add_argument('--debug-gloo-one-gpu', action='store_true',
                     help='flow check of the multi-rank path on a one-GPU box: gloo rendezvous, every rank on cuda:0 (timings meaningless)')
     ap.add_argument('--no-post', action='store_true')
+    ap.add_argument('--no-hybrid', action='store_true', help='--shard-T: clip chunks as recompute windows only (no pyramid cut)')
     ap.add_argument('--cpu-T', type=int, default=0, help='T of the CPU-baseline sample (default: same T)')
     return ap.parse_args()
 
@@ -168,7 +169,10 @@ def run_sharded(args, pkg, dist, rank, world, dev):
     L, win = kw['n_levels'], kw['win']
     halo = d.receptive_field(L, win, kw['fusion_layers'])
     # queries first, clips second (dist.shard_plan_2d): with NQ = 1 this is the pure T-shard of BASELINE configs[3]
-    grid = d.shard_plan_2d(T, world, nq, L, win, halo)
+    # ... and the clip axis itself with the pyramid cut at a level k where that computes fewer rows (dist.hybrid_plan; --no-hybrid: windows only)
+    harch = None if args.no_hybrid else dict(fusion_layers=kw['fusion_layers'], n_embd_convs=2, n_stem=0, head_layers=2)
+    grid = d.shard_plan_2d(T, world, nq, L, win, halo, hybrid_arch=harch)
+    hyb = grid.get('hybrid')
     groups = d.make_grid_groups(grid['t_shards'], grid['q_groups']) if dist is not None else None
     plan = grid['plan']
     lo, hi, w_lo, w_hi = plan[rank % grid['t_shards']]
@@ -215,15 +219,18 @@ def run_sharded(args, pkg, dist, rank, world, dev):
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
         'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'BASELINE configs[3]: ONE video of T={T} clips (D=1024, probe hyper-parameters, NQ={nq}) over {world} rank(s) as '
-                               f'{grid["q_groups"]} query group(s) x {grid["t_shards"]} clip chunk(s): owned chunk + {halo}-clip recompute halo per side, '
-                               f'RCCL all-gather of the sidekick scores (AG-1) and of the packed per-level outputs (AG-2) inside a clip-chunk group, '
-                               f'one more of the full-length outputs across the query groups (AG-3)',
+                               f'{grid["q_groups"]} query group(s) x {grid["t_shards"]} clip chunk(s): ' +
+                               (f'pyramid cut at level {hyb["k"]} (levels <= k on a narrow window, levels above on a coarse window of the all-gathered '
+                                f'level-k features: AG-F, AG-R), ' if hyb else f'owned chunk + {halo}-clip recompute halo per side, ') +
+                               'RCCL all-gather of the sidekick scores (AG-1) and of the packed per-level outputs (AG-2) inside a clip-chunk group, '
+                               'one more of the full-length outputs across the query groups (AG-3)',
                    'T': T, 'vid_len': vid_len, 'nq': nq, 'window_clips_rank0': plan[0][3] - plan[0][2], 'window_clips_max': max(p[3] - p[2] for p in plan),
                    'owned_clips': plan[0][1] - plan[0][0], 'halo': halo, 'parallelism': f'query groups x{grid["q_groups"]}, T-shard x{grid["t_shards"]}',
-                   'rows_per_rank_over_even_share': grid['rows_factor'],
+                   'rows_per_rank_over_even_share': grid['rows_factor'], 'split_level': hyb['k'] if hyb else None,
                    'backend': 'gloo (flow check)' if args.debug_gloo_one_gpu else ('nccl = RCCL' if world > 1 else 'single rank')},
         'phases_us_rank0': phases,
-        'collectives_us_rank0': {'ag1_scores': phases.get('ag1'), 'ag2_outputs': phases.get('ag2'), 'ag3_query_groups': phases.get('ag3')},
+        'collectives_us_rank0': {'ag1_scores': phases.get('ag1'), 'ag2_outputs': phases.get('ag2'), 'ag3_query_groups': phases.get('ag3'),
+                                 'agF_level_k_features': phases.get('agF'), 'agR_refined_map': phases.get('agR')},
     }
     # the sharded result against the unsharded forward of the same video on rank 0
     if rank == 0:

@@ -102,7 +102,7 @@ def shard_plan(T: int, world: int, n_levels: int, win: int, halo: int) -> List[T
     return plan
 
 
-def shard_plan_2d(T: int, world: int, nq: int, n_levels: int, win: int, halo: int):
+def shard_plan_2d(T: int, world: int, nq: int, n_levels: int, win: int, halo: int, hybrid_arch: dict = None):
     """Queries first, clips second.  The (video, query) pairs of ONE video are independent after the (query-independent)
     vid_map products, so the ranks form a grid of ``q_groups`` query groups x ``t_shards`` clip chunks: rank r = qg * t_shards + t
     computes the window of clip chunk t for the queries of group qg.  Overlap-recompute costs rows only along the clip axis:
@@ -110,6 +110,10 @@ def shard_plan_2d(T: int, world: int, nq: int, n_levels: int, win: int, halo: in
     T = 65 536), NQ = 1 is the pure T-shard (1.625x).  Returns the dict of the plan with the smallest number of rows per rank
     (ties: fewer clip chunks):
       t_shards, q_groups, plan (``shard_plan`` of the clip axis), queries (per group: (q_lo, q_hi)), rows_factor.
+    ``hybrid_arch`` (dict of ``hybrid_halos``' layer counts, or {}): the clip axis may also be cut with the pyramid split at a level k
+    (``hybrid_plan``: no recomputed pyramid top, 1.12x instead of 1.56x at T = 65 536 on 8 clip chunks); the candidate then carries
+    ``hybrid`` = that plan, its ``plan`` entries are (lo, hi, n_lo, n_hi) -- the NARROW window, what a caller slices its features to --
+    and ``sharded_forward_2d`` runs ``hybrid_forward`` inside a clip-chunk group.
     Everything is a function of (T, world, nq, L, w): nothing is negotiated at run time."""
     best = None
     for ts in range(1, world + 1):
@@ -121,7 +125,14 @@ def shard_plan_2d(T: int, world: int, nq: int, n_levels: int, win: int, halo: in
         plan = shard_plan(T, ts, n_levels, win, halo) if ts > 1 else [(0, T, 0, T)]
         per = [(nq * g // qs, nq * (g + 1) // qs) for g in range(qs)]
         rows = max(p[3] - p[2] for p in plan) * max(b - a for a, b in per)
-        cand = dict(t_shards=ts, q_groups=qs, plan=plan, queries=per, rows_factor=rows / (T * nq / world))
+        hyb = None
+        if hybrid_arch is not None and ts > 1 and n_levels > 2:
+            hp = hybrid_plan(T, ts, n_levels, win, None, **hybrid_arch)
+            hrows = hp['rows_factor'] * (T / ts) * max(b - a for a, b in per)       # in level-0 clips of an even share, like `rows`
+            if hrows < rows:
+                hyb, rows = hp, hrows
+                plan = [(r['lo'], r['hi'], r['n_lo'], r['n_hi']) for r in hp['ranks']]
+        cand = dict(t_shards=ts, q_groups=qs, plan=plan, queries=per, rows_factor=rows / (T * nq / world), hybrid=hyb)
         if best is None or rows < best[0] or (rows == best[0] and ts < best[1]['t_shards']):
             best = (rows, cand)
     assert best is not None, f'no (query, clip) grid for world={world}, nq={nq}'
@@ -224,7 +235,10 @@ def sharded_forward_2d(backend, vid_w, shallow_w, mask_full, grid, groups, rank,
     tg, qgs = groups if groups is not None else ([None] * qs, [None] * ts)
     mark = timings.mark if timings is not None else (lambda name: None)
     sub_t, sub_m, sub_c = list(texts[q_lo:q_hi]), list(tmasks[q_lo:q_hi]), text_cls[q_lo:q_hi]
-    if ts > 1:
+    if ts > 1 and grid.get('hybrid') is not None:
+        lg, of, mk = hybrid_forward(backend, vid_w, shallow_w, mask_full, grid['hybrid'], t, T, n_levels, sub_t, sub_c, sub_m,
+                                    group=tg[qg], timings=timings)
+    elif ts > 1:
         lg, of, mk = sharded_forward(backend, vid_w, shallow_w, mask_full, grid['plan'], t, T, n_levels, sub_t, sub_c, sub_m,
                                      group=tg[qg], timings=timings)
     else:

@@ -171,7 +171,7 @@ def _worker(rank, world, port, outdir):
         dist.destroy_process_group()
 
 
-def _worker_2d(rank, world, port, outdir, nq):
+def _worker_2d(rank, world, port, outdir, nq, hybrid=False):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
@@ -179,11 +179,12 @@ def _worker_2d(rank, world, port, outdir, nq):
         pkg, opt, sd, inp, texts, tmasks = _setup()
         d = pkg.dist
         halo = d.receptive_field(KW['n_levels'], KW['win'])
-        grid = d.shard_plan_2d(T, world, nq, KW['n_levels'], KW['win'], halo)
+        grid = d.shard_plan_2d(T, world, nq, KW['n_levels'], KW['win'], halo, hybrid_arch={} if hybrid else None)
+        assert (grid['hybrid'] is not None) == (hybrid and grid['t_shards'] > 1)
         groups = d.make_grid_groups(grid['t_shards'], grid['q_groups'])
         t = rank % grid['t_shards']
         lo, hi, w_lo, w_hi = grid['plan'][t]
-        backend = OracleBackend(sd, opt.model)
+        backend = OracleHybridBackend(sd, opt.model) if hybrid else OracleBackend(sd, opt.model)
         with torch.no_grad():
             out = d.sharded_forward_2d(backend, inp['vid'][0][:, w_lo:w_hi], inp['shallow_vid'][0][:, w_lo:w_hi], inp['vid_masks'][0],
                                        grid, groups, rank, T, KW['n_levels'], texts[:nq], inp['text_cls'][:nq], tmasks[:nq])
@@ -208,15 +209,15 @@ def test_shard_plan_2d_prefers_queries():
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('world,nq,grid', [(2, 2, (1, 2)), (4, 2, (2, 2))])
-def test_sharded_forward_2d_matches_unsharded(world, nq, grid):
+@pytest.mark.parametrize('world,nq,grid,hybrid', [(2, 2, (1, 2), False), (4, 2, (2, 2), False), (4, 2, (2, 2), True)])
+def test_sharded_forward_2d_matches_unsharded(world, nq, grid, hybrid):
     """query groups x clip chunks over `world` gloo ranks: (2 ranks, 2 queries) is pure query sharding, (4 ranks, 2 queries) cuts T
     in two for each of two query groups; every rank must end with all queries' full-length outputs = the unsharded oracle"""
     import tempfile
     ctx = mp.get_context('spawn')
-    port = 29700 + (os.getpid() + 7 * world) % 250
+    port = 29700 + (os.getpid() + 7 * world + 3 * int(hybrid)) % 250
     with tempfile.TemporaryDirectory() as outdir:
-        procs = [ctx.Process(target=_worker_2d, args=(r, world, port, outdir, nq)) for r in range(world)]
+        procs = [ctx.Process(target=_worker_2d, args=(r, world, port, outdir, nq, hybrid)) for r in range(world)]
         for p in procs:
             p.start()
         for p in procs:

@@ -1,0 +1,85 @@
+"""What ONE rank of an 8-way T-shard of a T = 65 536 video computes, on one GPU (no collectives: their payloads come from a full
+forward of the same video): the recompute-window plan (dist.shard_plan: owned chunk + 2 560-clip halo) against the pyramid cut at
+level k (dist.hybrid_plan: narrow window + coarse window of the gathered level-k features), and the unsharded forward.
+    python tools/shard_cost.py [T] [world] [rank]
+Prints one JSON line: ms per forward of the rank's share in both plans, the unsharded forward, and the strong-scaling bound they imply."""
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module('cvpr2025-decafnet_amd')
+
+
+def timeit(fn, reps=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / reps
+
+
+def main():
+    T = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+    world = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    rank = int(sys.argv[3]) if len(sys.argv) > 3 else world // 2 - 1
+    kw = dict(D=1024, E=256, TE=256, text_in=512, n_levels=8, win=9, n_heads=4, sn=60, sratio=0.3, msf=True, norm=True,
+              max_seq_len=2304, text_layers=5, text_max_len=48, fusion_layers=2)
+    opt = pkg.config.make_opt(**kw)
+    model = pkg.modeling.create_model(opt)
+    model.load_state_dict(pkg.synth.make_state_dict({k: list(v.shape) for k, v in model.state_dict().items()}, 2025))
+    model = model.cuda().eval().requires_grad_(False)
+    inp = pkg.synth.make_inputs(kw['D'], T, T - 300, 1, kw['text_in'], 32, 2029)
+    texts, tmasks = zip(*[model.encode_text(t[None].cuda(), torch.ones(1, 1, t.size(-1), dtype=torch.bool, device='cuda')) for t in inp['tokens']])
+    vid, sh, mask, cls = inp['vid'].cuda(), inp['shallow_vid'].cuda(), inp['vid_masks'].cuda(), inp['text_cls'].cuda()
+    d = pkg.dist
+    L, win = kw['n_levels'], kw['win']
+    be = d.HipBackend(model)
+    gate = be.gate(be.scores(sh[0], cls), mask[0])
+    t_full = timeit(lambda: model(vid, sh, mask, texts, cls, tmasks, eval=True))
+    # recompute windows
+    plan = d.shard_plan(T, world, L, win, d.receptive_field(L, win))
+    lo, hi, w_lo, w_hi = plan[rank]
+    vw, sw, mw, gw = vid[0][:, w_lo:w_hi].contiguous(), sh[0][:, w_lo:w_hi].contiguous(), mask[0][w_lo:w_hi].contiguous(), gate[:, w_lo:w_hi].contiguous()
+    t_win = timeit(lambda: be.forward_window(vw, sw, mw, texts, tmasks, gw, T, w_lo))
+    # pyramid cut at level k: the exchanged tensors taken from one pass of every rank's phases
+    hp = d.hybrid_plan(T, world, L, win)
+    k = hp['k']
+    bes = [be] + [d.HipBackend(model.replica()) for _ in range(world - 1)]
+    sl = lambda r: (vid[0][:, r['n_lo']:r['n_hi']].contiguous(), sh[0][:, r['n_lo']:r['n_hi']].contiguous(),   # noqa: E731
+                    mask[0][r['n_lo']:r['n_hi']].contiguous(), gate[:, r['n_lo']:r['n_hi']].contiguous())
+    feat = torch.cat([b_.hybrid_phase1(*sl(r)[:3], texts, tmasks, sl(r)[3], T, r['n_lo'], k, r['c_hi'] - r['c_lo'])
+                      [:, (r['lo'] - r['n_lo']) >> k:(r['hi'] - r['n_lo']) >> k] for r, b_ in zip(hp['ranks'], bes)], 1)
+    maskk = mask[0][::2 ** k]
+    ref = torch.cat([b_.hybrid_phase2(feat[:, r['c_lo']:r['c_hi']].contiguous(), maskk[r['c_lo']:r['c_hi']].contiguous(), (r['n_lo'] >> k) - r['c_lo'])
+                     [:, (r['lo'] - r['n_lo']) >> k:(r['hi'] - r['n_lo']) >> k] for r, b_ in zip(hp['ranks'], bes)], 1)
+    r = hp['ranks'][rank]
+    a = sl(r)
+    fc, mc, rc = feat[:, r['c_lo']:r['c_hi']].contiguous(), maskk[r['c_lo']:r['c_hi']].contiguous(), ref[:, r['c_lo']:r['c_hi']].contiguous()
+
+    def hyb():
+        be.hybrid_phase1(a[0], a[1], a[2], texts, tmasks, a[3], T, r['n_lo'], k, r['c_hi'] - r['c_lo'])
+        be.hybrid_phase2(fc, mc, (r['n_lo'] >> k) - r['c_lo'])
+        be.hybrid_phase3(rc)
+    t_hyb = timeit(hyb)
+    E = kw['E']
+    print(json.dumps({'T': T, 'world': world, 'rank': rank, 'unsharded_ms': t_full,
+                      'window_plan': {'window_clips': w_hi - w_lo, 'rows_factor': (w_hi - w_lo) / (T / world), 'ms': t_win, 'compute_bound_speedup': t_full / t_win},
+                      'level_cut_plan': {'k': k, 'narrow_clips': r['n_hi'] - r['n_lo'], 'coarse_level_k_rows': r['c_hi'] - r['c_lo'],
+                                         'rows_factor': hp['rows_factor'], 'ms': t_hyb, 'compute_bound_speedup': t_full / t_hyb,
+                                         'all_gather_bytes_total': {'AG-F': (T >> k) * E * 4, 'AG-R': (T >> k) * 32 * 4,
+                                                                    'AG-2': sum(T >> l for l in range(L)) * 16}},
+                      'note': 'one rank, compute only (one GPU; the exchanged tensors were produced beforehand); speedup = unsharded / per-rank time, the '
+                              'bound strong scaling cannot exceed before collective time'}))
+
+
+if __name__ == '__main__':
+    main()
