@@ -217,8 +217,10 @@ int dcf_model_set_graph_mode(dcf_model* m, int32_t mode);
 /* Test / developer switch (process wide): override a built-in dispatch threshold so that the operator tests can send small
  * reference fixtures through the kernels the engine only picks for large grids.  Names: "dec_chain_min_rows" (level-0 rows from
  * which the attention half of a fusion layer runs as one kernel, csrc/dec_chain.hip), "enc_chain_min_rows" / "enc_attn_min_rows" (the same for
- * the two halves of the encoder layers' attention, csrc/enc_chain.hip).  value < 0 restores the built-in value.  Not a reference interface; results do not depend on it beyond
- * rounding.  ABI version 6. */
+ * the two halves of the encoder layers' attention, csrc/enc_chain.hip), "fuse_scores" (0: the sidekick scores by their own kernels instead
+ * of on the shallow vid_map GEMM), "tcn_frag" (0: every workgroup of a TCN layer builds its weight fragments itself instead of reading the
+ * per-model image).  value < 0 restores the built-in value.  Not a reference interface; results do not depend on it beyond
+ * rounding.  ABI version 6 (the last two names: 8). */
 int dcf_debug_set_option(const char* name, int32_t value);
 
 /* --------------------------------------------------------------------------------------------
