@@ -38,7 +38,8 @@ typedef struct dcf_config {
   int32_t n_embd_convs;   /* opt.model.vid_net.arch[0]                                             */
   int32_t n_stem;         /* opt.model.vid_net.arch[1]                                             */
   int32_t n_levels;       /* opt.model.vid_net.arch[2]  (= number of FPN levels = TCN depth)       */
-  int32_t win;            /* opt.model.vid_net.mha_win_size (odd; 0 = global clip attention)      */
+  int32_t win;            /* opt.model.vid_net.mha_win_size (odd; 0 = global clip attention: a correctness-first fp32
+                           * O(T^2) vector-ALU kernel, csrc/attn.hip k_global_attn -- no reference default uses it)  */
   int32_t head_layers;    /* opt.model.cls_head.n_layers (= reg_head.n_layers)                     */
   int32_t sn;             /* opt.model.sn     (clips per scoring block)                            */
   float sratio;           /* opt.model.sratio (fraction of blocks that keep expert features)       */
