@@ -2187,8 +2187,12 @@ int dcf_hybrid_phase1(dcf_model* m, int32_t k, const float* vid_w, const float* 
   h.valid = false; h.k = k; h.Tn = (int)Tn; h.Tc = (int)Tc;
   int Tl[DCF_MAX_LEVELS];
   for (int j = 0; j < LC; ++j) Tl[j] = (int)(Tc >> j);
-  if (dcf::make_plan(m, h.pc, Tl, LC, nq, m->reg_scales.data() + k, st)) return -1;
-  if (LC > 1 && dcf::make_plan(m, h.pch, Tl + 1, LC - 1, nq, m->reg_scales.data() + k + 1, st)) return -1;
+  // (the level tables of the coarse pyramid are rebuilt -- a synchronising upload -- only when its geometry changes)
+  const bool same = h.pc.d_lt && h.pc.L == LC && h.pc.T0 == (int)Tc && h.pc.B == nq && (LC == 1 || (h.pch.d_lt && h.pch.L == LC - 1));
+  if (!same) {
+    if (dcf::make_plan(m, h.pc, Tl, LC, nq, m->reg_scales.data() + k, st)) return -1;
+    if (LC > 1 && dcf::make_plan(m, h.pch, Tl + 1, LC - 1, nq, m->reg_scales.data() + k + 1, st)) return -1;
+  }
   dcf::VideoSet vs;
   vs.nvid = 1; vs.vid[0] = vid_w; vs.shallow[0] = shallow_w; vs.mask[0] = mask_w; vs.text_cls[0] = nullptr; vs.nq[0] = nq;
   m->hyb_levels = k + 1;
