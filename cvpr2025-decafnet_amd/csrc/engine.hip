@@ -2181,6 +2181,7 @@ int dcf_hybrid_phase1(dcf_model* m, int32_t k, const float* vid_w, const float* 
   DCF_CHECK(Tc > 0 && Tc < (1ll << 24) && Tc % ((int64_t)half << (LC - 1)) == 0, "dcf_hybrid_phase1: the coarse window (%lld level-%d rows) must be a multiple of %d", (long long)Tc, k, half << (LC - 1));
   const int Bmax = c.max_batch > 0 ? c.max_batch : 8;
   DCF_CHECK(nq >= 1 && nq <= Bmax, "dcf_hybrid_phase1: 1 .. max_batch = %d queries per call", Bmax);
+  DCF_CHECK(Tc <= Tn, "dcf_hybrid_phase1: the coarse window (%lld level-%d rows) must not exceed the narrow one (%lld clips): the coarse levels run in its scratch", (long long)Tc, k, (long long)Tn);
   hipStream_t st = (hipStream_t)stream;
   if (!m->hyb) m->hyb = new dcf::HybridState();
   dcf::HybridState& h = *m->hyb;

@@ -376,7 +376,7 @@ def hybrid_plan(T: int, world: int, n_levels: int, win: int, k: int = None, **ar
     def build(kk):
         hA, hB = hybrid_halos(L, win, kk, **arch)
         Tk = T >> kk
-        ranks, worst = [], 0
+        ranks, worst, fits = [], 0, True
         for r in range(world):
             lo, hi = (units * r // world) * a, (units * (r + 1) // world) * a
             n_lo, n_hi = max(0, lo - hA), min(T, hi + hA)
@@ -384,13 +384,18 @@ def hybrid_plan(T: int, world: int, n_levels: int, win: int, k: int = None, **ar
             assert (n_lo >> kk) >= c_lo and (n_hi >> kk) <= c_hi
             rows = sum((n_hi - n_lo) >> l for l in range(kk + 1)) + sum((c_hi - c_lo) >> j for j in range(1, L - kk))
             worst = max(worst, rows)
+            fits = fits and (c_hi - c_lo) <= (n_hi - n_lo)           # the coarse levels run in the narrow pyramid's scratch (dcf_hybrid_phase1)
             ranks.append(dict(lo=lo, hi=hi, n_lo=n_lo, n_hi=n_hi, c_lo=c_lo, c_hi=c_hi))
         even = sum((T // world) >> l for l in range(L))
-        return dict(k=kk, ranks=ranks, rows_factor=worst / even)
+        return dict(k=kk, ranks=ranks, rows_factor=worst / even, fits=fits)
 
     if k is not None:
-        return build(k)
-    return min((build(kk) for kk in range(1, L - 1)), key=lambda p: (p['rows_factor'], p['k']))
+        p = build(k)
+        assert p['fits'], f'split level {k}: a coarse window is longer than its narrow window (small shards): pick a higher level'
+        return p
+    cands = [p for p in (build(kk) for kk in range(1, L - 1)) if p['fits']]
+    assert cands, f'no split level fits T={T} on {world} ranks'
+    return min(cands, key=lambda p: (p['rows_factor'], p['k']))
 
 
 def hybrid_forward(backend, vid_w, shallow_w, mask_full, plan, rank, T, n_levels, texts, text_cls, tmasks, group=None, timings=None):
