@@ -206,6 +206,14 @@ def test_shard_plan_2d_prefers_queries():
         assert g['queries'][0][0] == 0 and g['queries'][-1][1] == nq
         assert all(a[1] == b[0] for a, b in zip(g['queries'], g['queries'][1:]))
     assert d.shard_plan_2d(65536, 8, 4, 8, 9, rf)['rows_factor'] <= 1.15      # VERDICT r02 item 5's bar, met from NQ = 4 on
+    # with the pyramid cut allowed inside a clip-chunk group the NQ = 1 corner meets the bar too, and the plan's
+    # windows are the narrow ones
+    g1 = d.shard_plan_2d(65536, 8, 1, 8, 9, rf, hybrid_arch={})
+    assert g1['t_shards'] == 8 and g1['hybrid'] is not None and g1['hybrid']['k'] == 3 and g1['rows_factor'] <= 1.15
+    assert all(p[3] - p[2] <= 8192 + 2 * 384 for p in g1['plan']) and g1['plan'][3][3] - g1['plan'][3][2] == 8960
+    g2 = d.shard_plan_2d(65536, 8, 2, 8, 9, rf, hybrid_arch={})
+    assert (g2['t_shards'], g2['q_groups']) == (4, 2) and g2['hybrid'] is not None and g2['rows_factor'] <= 1.07
+    assert d.shard_plan_2d(65536, 8, 8, 8, 9, rf, hybrid_arch={})['hybrid'] is None      # whole videos per rank: nothing to cut
 
 
 @pytest.mark.timeout(900)
