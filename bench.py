@@ -2,6 +2,7 @@
 """Throughput of the DeCafNet grounding forward on MI355X (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--nq NQ] [--T 16384]
+    python bench.py --gpus N ...                      # no WORLD_SIZE set: starts its own N ranks (one per GPU, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
     ... bench.py --gpus N --shard-T 65536        # BASELINE configs[3]: ONE long video sharded over the N ranks (RCCL)
 
@@ -246,13 +247,56 @@ def run_sharded(args, pkg, dist, rank, world, dev):
         dist.destroy_process_group()
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: the parent starts N fresh child processes (one per
+    GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set -- what torch.distributed.run would set), relays their output and
+    exits with the worst child's return code.  The parent has touched no GPU at this point (importing torch does not
+    initialise HIP), and it never exec()s: the children are ordinary subprocesses (train.py:42-46 is the reference's launch)."""
+    import socket
+    with socket.socket() as s:                           # a free rendezvous port on the loopback interface
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env0 = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(args.gpus),
+                LOCAL_WORLD_SIZE=str(args.gpus), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    procs = []
+    for r in range(args.gpus):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)   # rank 0 prints the ONE JSON line
+    reader.start()
+    failed_at = None
+    while any(p.poll() is None for p in procs):          # a rank that dies leaves the others at a barrier: end them after a grace period
+        if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
+            failed_at = time.time()
+        if failed_at is not None and time.time() - failed_at > 60:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.2)
+    reader.join(timeout=10)
+    sys.stdout.write(b''.join(chunks).decode(errors='replace'))
+    sys.stdout.flush()
+    worst = 0
+    for p in procs:
+        rc = p.returncode
+        if rc != 0 and (worst == 0 or abs(rc) > abs(worst)):
+            worst = rc
+    sys.exit(worst if worst >= 0 else 128 - worst)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return spawn_ranks(args)                         # before any GPU call in this process
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     if args.gpus != world:
-        sys.stderr.write(f'bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}.  One process per GPU: launch with\n'
+        sys.stderr.write(f'bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}.  One process per GPU: either plain\n'
+                         f'  python bench.py --gpus {args.gpus} ...          (starts its own {args.gpus} ranks), or\n'
                          f'  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 '
                          f'--master-port 29511 bench.py --gpus {args.gpus} ...\n')
         sys.exit(2)
