@@ -208,17 +208,31 @@ __device__ __forceinline__ void row_layernorm(Row<NCH>& r, int C, int lane, cons
   }
 }
 
+// exact (erf) GELU, nn.GELU default (libs/modeling/blocks.py:531): 0.5 x (1 + erf(x / sqrt 2)) = max(x, 0) - |x| P(|x|) with
+// P = 0.5 (1 - erf(|x| / sqrt 2)) = 0.5 poly(t) e^{-z^2}, z = |x| / sqrt 2, t = 1 / (1 + 0.3275911 z): erf by Abramowitz & Stegun
+// 7.1.26 (|error| <= 1.5e-7, i.e. fp32 rounding level) on one v_exp_f32 and one v_rcp_f32 instead of ocml's erff (~40
+// instructions; it was 10-13 % of the FFN fc GEMM).  In this form there is no sign select and no cancellation on either side
+// (P <= 0.5), and the whole function is 15 vector instructions: z carries the sqrt(log2 e) of the exponential, the 0.5 rides in the
+// polynomial's coefficients, and the last step is one fma on max(x, 0).  The FFN kernels (ffn_chain.hip) run the same steps on
+// 16 x (their operand scale); scaling by a power of two commutes with every rounding here, so they agree with this function bit
+// for bit.
+constexpr float GELU_CZ = 0.849321800288019f;          // sqrt(log2(e) / 2): zs = |x| GELU_CZ = z sqrt(log2 e)
+constexpr float GELU_CT = 0.2727374808792225f;         // 0.3275911 / sqrt(log2 e): 1 + 0.3275911 z = 1 + GELU_CT zs
+constexpr float GELU_A1 = 0.5f * 0.254829592f, GELU_A2 = 0.5f * -0.284496736f, GELU_A3 = 0.5f * 1.421413741f,
+                GELU_A4 = 0.5f * -1.453152027f, GELU_A5 = 0.5f * 1.061405429f;
+__device__ __forceinline__ float gelu_half_poly(float t) {      // 0.5 (a1 t + a2 t^2 + ... + a5 t^5)
+  return t * (GELU_A1 + t * (GELU_A2 + t * (GELU_A3 + t * (GELU_A4 + t * GELU_A5))));
+}
+__device__ __forceinline__ float relu_max(float x) {             // max(x, 0) as ONE v_max_f32 (fmaxf puts a canonicalising max in front)
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
 __device__ __forceinline__ float gelu_erf(float x) {
-  // exact (erf) GELU, nn.GELU default (libs/modeling/blocks.py:531): 0.5 x (1 + erf(x / sqrt 2)).
-  // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 rounding level) on one v_exp_f32 and one
-  // v_rcp_f32 instead of ocml's erff (~40 instructions; it was 10-13 % of the FFN fc GEMM).  1 + erf is formed
-  // without cancellation on the negative side: 1 + erf(-z) = poly(t) e^{-z^2}.
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float pe = poly * __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
-  const float one_plus_erf = x >= 0.f ? 2.0f - pe : pe;
-  return 0.5f * x * one_plus_erf;
+  const float zs = fabsf(x) * GELU_CZ;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(zs, GELU_CT, 1.0f));
+  const float ex = __builtin_amdgcn_exp2f(-zs * zs);
+  return __builtin_fmaf(-fabsf(x), gelu_half_poly(t) * ex, relu_max(x));
 }
 
 }  // namespace dcf

@@ -2474,6 +2474,7 @@ int dcf_op_ffn(const float* X, const float* ln_w, const float* ln_b, const float
     dcf::FfnChainArgs a{};
     a.X = X; a.ldx = E; a.W1s = p1; a.b1 = fc_b; a.ln_s = fc_s; a.stats = stats; a.stats_slots = E / 64; a.W2s = p2; a.b2 = b2; a.ls = ls;
     a.R = X; a.ldr = E; a.rowmask = mask; a.C = C; a.ldc = E; a.stats_out = stats_out; a.stats_w = 64; a.M = M;
+    a.variant = chain == 1 ? 0 : chain - 1;        // chain 2: the four-wave kernel, 3: the eight-wave kernel
     rc = dcf::launch_ffn_chain(a, st);
   } else if (rc == 0) {
     DCF_HIP(hipMallocAsync((void**)&hid, (size_t)M * H * sizeof(float), st));

@@ -26,9 +26,11 @@ struct FfnChainArgs {
   int stats_w;
   unsigned* status;            // sticky numerics word (GemmArgs::status)
   int M;
+  int variant;                 // 0: the default kernel, 1: four waves (k_ffn_chain), 2: eight waves, producer / consumer pairs (k_ffn_pair)
 };
 
-// E = 256 only; rows in tiles of 128 (one workgroup of four waves per CU, 136 KiB of LDS)
+// E = 256 only; rows in tiles of 128 (one workgroup per CU: eight waves as four producer / consumer pairs, 154 KiB of LDS,
+// persistent over its row tiles; or the four-wave kernel, 136 KiB)
 int launch_ffn_chain(const FfnChainArgs& a, hipStream_t stream);
 // stats [rows][C / stats_w] float2 <- (sum, sum of squares) of every row of X in the slot layout of GemmArgs::stats_out
 int launch_row_stats(const float* X, int64_t ldx, float* stats, int rows, int C, int stats_w, hipStream_t stream);

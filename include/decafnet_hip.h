@@ -300,7 +300,8 @@ int dcf_op_linear_ln_carry(const float* A, const float* W1, const float* b1, con
  *   C = X + ls * ((GELU(LN(X) W1^T + b1) W2^T + b2) * mask),   W1 (4E, E), W2 (E, 4E), hidden width 4E
  * ln_w / ln_b NULL = no LayerNorm in front; ls NULL = 1; mask NULL = all rows valid; stats_out (optional, (M, E / 64, 2)):
  * (sum, sum of squares) of every row written to C.  f16x3 operand split.  chain = 0: two GEMMs with the hidden activations in
- * memory; chain = 1 (E = 256 only): one kernel, the hidden activations stay in registers (csrc/ffn_chain.hip). */
+ * memory; chain = 1 (E = 256 only): one kernel, the hidden activations stay in registers (csrc/ffn_chain.hip: the default kernel;
+ * chain = 2: its four-wave form, chain = 3: its eight-wave producer / consumer form -- bit-identical results). */
 int dcf_op_ffn(const float* X, const float* ln_w, const float* ln_b, const float* W1, const float* b1, const float* W2, const float* b2,
                const float* ls, const uint8_t* mask, float* C, float* stats_out, int32_t M, int32_t E, int32_t chain, void* stream);
 

@@ -240,10 +240,13 @@ def test_head_chain_vs_fp64(L, B, T, C, NO, scale):
 # (M, LayerNorm in front, LayerScale, row mask, row statistics out, row mean): a partial last tile, fewer rows than one tile,
 # one tile per CU and several rounds of tiles
 @pytest.mark.parametrize('M,with_ln,with_ls,with_mask,with_stats,shift', [
-    (128, 0, 0, 0, 0, 0.0), (200, 1, 1, 1, 0, 0.0), (33000, 1, 1, 1, 1, 0.0), (70000, 0, 1, 0, 1, 2.0), (40, 1, 0, 1, 0, -1.5)])
+    (128, 0, 0, 0, 0, 0.0), (200, 1, 1, 1, 0, 0.0), (33000, 1, 1, 1, 1, 0.0), (70000, 0, 1, 0, 1, 2.0), (40, 1, 0, 1, 0, -1.5),
+    (131072 + 300, 1, 1, 1, 1, 0.5)])
 def test_ffn_chain_vs_fp64(L, M, with_ln, with_ls, with_mask, with_stats, shift):
     """FFN in one kernel (csrc/ffn_chain.hip: both products transposed, the hidden activations in registers) against fp64
-    and against the GEMM pair it replaces (blocks.py:535-538, 589-590)"""
+    and against the GEMM pair it replaces (blocks.py:535-538, 589-590).  chain 1 = the default kernel, 2 = the four-wave kernel,
+    3 = the eight-wave kernel (producer / consumer wave pairs, persistent over its row tiles: the last case gives a workgroup
+    more than four tiles and a ragged last one): the two kernels must agree bit for bit."""
     pkg, lib = L
     E = 256
     g = torch.Generator().manual_seed(M + with_ln)
@@ -268,7 +271,7 @@ def test_ffn_chain_vs_fp64(L, M, with_ln, with_ls, with_mask, with_stats, shift)
     ref = x + y
     d = {k: v.cuda() for k, v in dict(X=X, lw=lw, lb=lb, W1=W1, b1=b1, W2=W2, b2=b2, ls=ls, mask=mask.to(torch.uint8)).items()}
     out = {}
-    for chain in (1, 0):
+    for chain in (1, 2, 3, 0):
         if chain == 0 and with_stats and M < 8192:
             continue
         C = torch.full((M + 1, E), float('nan'), device='cuda')          # one guard row behind the last one
@@ -284,6 +287,10 @@ def test_ffn_chain_vs_fp64(L, M, with_ln, with_ls, with_mask, with_stats, shift)
             Sc = S.cpu().double().sum(1)
             torch.testing.assert_close(Sc[:, 0], ref.sum(1), rtol=1e-4, atol=2e-3)
             torch.testing.assert_close(Sc[:, 1], (ref * ref).sum(1), rtol=1e-4, atol=2e-3)
+        out[('S', chain)] = S.cpu() if with_stats else None
+    assert torch.equal(out[2], out[3]) and torch.equal(out[1], out[3]), 'the four-wave and the eight-wave kernel differ'
+    if with_stats:
+        assert torch.equal(out[('S', 2)], out[('S', 3)])
     if 0 in out:
         tol = 1e-5 if with_ln else 2e-6      # without the LayerNorm fold: same products, same order, a few ulps at most
         torch.testing.assert_close(out[1], out[0], rtol=tol, atol=tol)

@@ -31,7 +31,7 @@ def main():
         mask = (torch.rand(M, generator=g) > 0.1).to(torch.uint8).cuda()
         C = torch.empty(M, E, device='cuda')
         for with_ln in (1, 0):
-            for chain in (0, 1):
+            for chain in (0, 2, 3):      # GEMM pair, four-wave kernel, eight-wave (producer / consumer) kernel
                 ts = []
                 for it in range(6):
                     torch.cuda.synchronize()
