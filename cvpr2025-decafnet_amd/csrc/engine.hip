@@ -735,6 +735,7 @@ struct Arena {
 struct Buffers {
   float *P1, *P2, *tn, *partial, *correl, *gate;
   uint8_t *mask_all, *nbr_all, *kvmask, *maskv;
+  uint8_t* tile_flags;                        // [B][(T0 + 63) / 64] 64-clip row tiles a query's gate keeps (GateArgs::tile_flags)
   uint8_t *mask_pre, *nbr_pre;                // vid_net.stride > 1: masks / neighbour flags of the input-resolution levels T0, T0/2, .. T0/stride
   float* col5;                                // vid_net.stride > 1: [B*T0/2][5E] rows of a k5 / stride-2 embedding convolution
   float *X, *R[7], *H2, *HID, *F, *HA, *HB, *HC, *HD, *logits1, *tcnA, *tcnB, *kvn, *Kt, *Vt;
@@ -756,6 +757,7 @@ static void carve(Arena& a, const dcf_config& c, int T0, int B, int nq, int S, i
   b.partial = a.take<float>((size_t)SCORE_SLICES * (nq + nvid) * T0);
   b.correl = a.take<float>((size_t)nq * T0);
   b.gate = a.take<float>(rows0);
+  b.tile_flags = a.take<uint8_t>((size_t)B * ((T0 + 63) / 64));
   b.mask_all = a.take<uint8_t>(rowsAll);
   b.nbr_all = a.take<uint8_t>(rowsAll);
   b.mask_pre = a.take<uint8_t>(strided ? 2 * rows0 : 0);
@@ -1582,6 +1584,13 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
   bool scores_on_gemm = !gate_override && fuse_scores_on() && m->vid_w2 && m->gemm_terms != 0 && m->wsplit.count(m->vid_w2) &&
                         m->wsplit_ldw[m->vid_w2] == m->vid_ldw && E % 128 == 0 && T0 % 4 == 0;
   for (int v = 0; v < nvid; ++v) scores_on_gemm = scores_on_gemm && vs.nq[v] <= GEMM_SCORE_MAXQ;
+  {
+    // ... and the text vectors of a video's queries have to fit beside the GEMM's tile in the default 64 KiB of LDS (the tile and its
+    // statistics block take ~22 KiB): 4 queries x D = 2048 do, D = 4096 does not -- the scoring kernels serve those
+    int maxq = 0;
+    for (int v = 0; v < nvid; ++v) maxq = std::max(maxq, vs.nq[v]);
+    scores_on_gemm = scores_on_gemm && (size_t)maxq * D * sizeof(float) <= 40960;
+  }
   int q_of[DCF_MAX_VIDEOS];                          // first query row of video v in tn / correl
   for (int v = 0, q_off = 0; v < nvid; q_off += vs.nq[v], ++v) q_of[v] = q_off;
   if (!gate_override) {                              // the scores of every video's queries
@@ -1594,6 +1603,16 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
     if (scores_on_gemm) TRY(launch_text_cls_norm(sa, st));
     else TRY(launch_sidekick(sa, st));
   }
+  // Gate first, expert product second (model.py:531-543): `vid * all_weight` is zero outside the top-k blocks, so the rows of
+  // W1 . vid under a closed gate are never used -- with every query of a video in THIS chunk (nq <= max_batch) the gate of all of them
+  // is known before the expert GEMMs start, and a row tile that none of the video's queries keeps is skipped (GemmArgs::tile_skip).
+  // One query per video: the gate keeps int(0.3 n) of n blocks of `sn` clips, ~half of the 64-row tiles touch none of them;
+  // q queries: ~0.5^q of the tiles (independent gates).  Several chunks of queries / the externally gated forward: every tile.
+  const int nflags = (T0 + 63) / 64;
+  static const bool no_gate_skip = getenv("DCF_NO_GATE_SKIP") != nullptr;        // developer switch: every row tile of the expert product
+  const bool gate_first = !gate_override && nq <= Bmax && m->vid_w1 && m->gemm_terms != 0 && !no_gate_skip && debug_option("gate_skip", 1) != 0;
+  unsigned long long vmap0 = 0;
+  for (int i = 0; i < nq && i < 16; ++i) vmap0 |= (unsigned long long)video_of[i] << (4 * i);
   {
     // the deep and shallow halves of vid_map of every video have the same shape: three of them share a grid (blockIdx.z
     // selects the operand set), so five videos are four full launches instead of five two-thirds-full ones
@@ -1606,23 +1625,46 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
       ng = 0;
       return rc;
     };
-    for (int v = 0; v < nvid; ++v) {
-      if (m->vid_w1) { g[ng++] = gemm(vs.vid[v], T0, m->vid_w1, nullptr, b.P1 + (size_t)v * T0 * E, E, T0, E, D); if (ng == 3) TRY(flush()); }
-      if (m->vid_w2) {
-        g[ng] = gemm(vs.shallow[v], T0, m->vid_w2, nullptr, b.P2 + (size_t)v * T0 * E, E, T0, E, D);
-        if (scores_on_gemm) {
-          g[ng].score_tn = b.tn + (size_t)q_of[v] * D; g[ng].score_out = b.correl + (size_t)q_of[v] * T0;
-          g[ng].score_nq = vs.nq[v]; g[ng].score_norm = c.norm;
-        }
-        if (++ng == 3) TRY(flush());
+    auto shallow_half = [&](int v) -> int {
+      g[ng] = gemm(vs.shallow[v], T0, m->vid_w2, nullptr, b.P2 + (size_t)v * T0 * E, E, T0, E, D);
+      if (scores_on_gemm) {
+        g[ng].score_tn = b.tn + (size_t)q_of[v] * D; g[ng].score_out = b.correl + (size_t)q_of[v] * T0;
+        g[ng].score_nq = vs.nq[v]; g[ng].score_norm = c.norm;
       }
-    }
-    TRY(flush());
-    if (nvid > 1) {                               // the videos' masks side by side: one launch (it was one copy node per video)
-      MaskPtrs mp{};
-      for (int v = 0; v < nvid; ++v) mp.p[v] = vs.mask[v];
-      hipLaunchKernelGGL(k_gather_masks, dim3((unsigned)((T0 + 255) / 256), (unsigned)nvid), dim3(256), 0, st, mp, b.maskv, T0);
-      DCF_HIP(hipGetLastError());
+      if (++ng == 3) return flush();
+      return 0;
+    };
+    auto expert_half = [&](int v, bool skip) -> int {
+      g[ng] = gemm(vs.vid[v], T0, m->vid_w1, nullptr, b.P1 + (size_t)v * T0 * E, E, T0, E, D);
+      if (skip) { g[ng].tile_skip = b.tile_flags + (size_t)q_of[v] * nflags; g[ng].skip_nq = vs.nq[v]; g[ng].skip_stride = nflags; }
+      if (++ng == 3) return flush();
+      return 0;
+    };
+    auto gather_masks = [&]() -> int {
+      if (nvid > 1) {                               // the videos' masks side by side: one launch (it was one copy node per video)
+        MaskPtrs mp{};
+        for (int v = 0; v < nvid; ++v) mp.p[v] = vs.mask[v];
+        hipLaunchKernelGGL(k_gather_masks, dim3((unsigned)((T0 + 255) / 256), (unsigned)nvid), dim3(256), 0, st, mp, b.maskv, T0);
+        DCF_HIP(hipGetLastError());
+      }
+      return 0;
+    };
+    if (gate_first) {
+      if (m->vid_w2) for (int v = 0; v < nvid; ++v) TRY(shallow_half(v));
+      TRY(flush());
+      TRY(gather_masks());
+      GateArgs ga{b.correl, nvid > 1 ? b.maskv : vid_mask, b.gate, sv > 1 ? b.mask_pre : b.mask_all, T0, nq, 0, c.sn, c.msf, (double)c.sratio, vmap0,
+                  b.tile_flags, nflags};
+      TRY(launch_gate(ga, st));
+      for (int v = 0; v < nvid; ++v) TRY(expert_half(v, true));
+      TRY(flush());
+    } else {
+      for (int v = 0; v < nvid; ++v) {
+        if (m->vid_w1) TRY(expert_half(v, false));
+        if (m->vid_w2) TRY(shallow_half(v));
+      }
+      TRY(flush());
+      TRY(gather_masks());
     }
   }
   if (nvid > 1) vid_mask = b.maskv;
@@ -1643,8 +1685,8 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
       hipLaunchKernelGGL(k_apply_gate, dim3((rows0 + 255) / 256), dim3(256), 0, st, gate_override + (int64_t)q0 * T0, vid_mask,
                          b.gate, mask_in, T0, rows0, c.msf);
       DCF_HIP(hipGetLastError());
-    } else {
-      GateArgs ga{b.correl, vid_mask, b.gate, mask_in, T0, B, q0, c.sn, c.msf, (double)c.sratio, vmap};
+    } else if (!gate_first) {                      // (gate_first: selected in front of the expert products, above)
+      GateArgs ga{b.correl, vid_mask, b.gate, mask_in, T0, B, q0, c.sn, c.msf, (double)c.sratio, vmap, nullptr, 0};
       TRY(launch_gate(ga, st));
     }
     int pre_off = 0;                              // first row of the last input-resolution level (= pyramid level 0) in mask_pre
@@ -2228,7 +2270,7 @@ int dcf_graph_active(const dcf_model* m) { return m ? m->last_launch : 0; }
 
 int dcf_debug_set_option(const char* name, int32_t value) {
   DCF_CHECK(name && *name, "dcf_debug_set_option: empty name");
-  static const char* known[] = {"dec_chain_min_rows", "enc_chain_min_rows", "enc_attn_min_rows", "fuse_scores", "tcn_frag"};
+  static const char* known[] = {"dec_chain_min_rows", "enc_chain_min_rows", "enc_attn_min_rows", "fuse_scores", "tcn_frag", "gate_skip"};
   bool ok = false;
   for (const char* k : known) ok = ok || strcmp(k, name) == 0;
   DCF_CHECK(ok, "dcf_debug_set_option: unknown option '%s'", name);

@@ -83,6 +83,13 @@ struct GemmArgs {
   const float* score_tn;
   float* score_out;
   int score_nq, score_norm;
+  // A_CHANMAJOR, split tile kernels only: row tiles the caller does not need (the expert half of vid_map under the top-k gate,
+  // model.py:531-543: `vid * all_weight` is zero outside the selected blocks).  tile_skip[q * skip_stride + t / 64] != 0 says that
+  // query q of this video keeps at least one of the clips 64 (t / 64) .. + 63 (written by k_gate, GateArgs::tile_flags); a
+  // workgroup whose row tile is kept by NONE of the skip_nq queries returns before its first load and leaves its tile of C
+  // unwritten -- the consumer must not read rows whose gate is 0 (k_vidmap_combine does not).  nullptr = every tile.
+  const uint8_t* tile_skip;
+  int skip_nq, skip_stride;
   // f16x3 mode: sticky device word, bit 0 is set when an accumulator leaves the finite range (an operand overflowed the
   // fp16 range, or the inputs already held inf / NaN); nullptr = not reported
   unsigned* status;

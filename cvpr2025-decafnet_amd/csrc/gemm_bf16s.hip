@@ -178,6 +178,15 @@ __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4 || (NST > 2
   int m0, n0;
   if (!tile_origin<BM, BN>(p, m0, n0)) return;
   const int M = p.M, K = p.K;
+  if constexpr (AMODE == A_CHANMAJOR && BM % 64 == 0 && !SCORE) {
+    if (p.tile_skip) {                                 // uniform: row tiles no query of this video keeps (GemmArgs::tile_skip)
+      const int f0 = m0 >> 6, f1 = min((m0 + BM + 63) >> 6, (M + 63) >> 6);
+      unsigned any = 0;
+      for (int q = 0; q < p.skip_nq; ++q)
+        for (int f = f0; f < f1; ++f) any |= p.tile_skip[(int64_t)q * p.skip_stride + f];
+      if (!any) return;
+    }
+  }
   const int KT = K / SBK;
   const float sa = a_scale_of(p);
   if constexpr (STATS) { if (p.stats_in) stats_load<BM, NT>(p, wg_stats, m0, tid); }     // uniform
@@ -760,6 +769,9 @@ static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterm
       }
       if (want_score) {
         const size_t lds_sc = lds + (size_t)score_q * p.K * sizeof(float);
+        // (no hipFuncAttributeMaxDynamicSharedMemorySize on these instantiations: the caller keeps the text vectors within the
+        // default 64 KiB -- engine.hip scores_on_gemm -- and sends wider features through k_sidekick_*)
+        DCF_CHECK(lds_sc <= 65536, "launch_gemm_split: %d text vectors of %d channels beside the tile need %zu bytes of LDS (> 64 KiB)", score_q, p.K, lds_sc);
         constexpr int NST_ = DEEP ? 3 : 2;
         if (nterms == 6) hipLaunchKernelGGL((gemm_bf16s_kernel<WM, WN, TM, TN, A_CHANMAJOR, 6, false, 2, false, false, true>), grid, dim3(WM * WN * 64), lds_sc, stream, b);
         else hipLaunchKernelGGL((gemm_bf16s_kernel<WM, WN, TM, TN, A_CHANMAJOR, T_F16, false, NST_, false, false, true>), grid, dim3(WM * WN * 64), lds_sc, stream, b);

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_vidmap_combine(const float* __restrict_
   const float g = gate[r];
   const float s = w3 ? correl[r] : 0.f;     // scat: the clip's raw sidekick score is one more input channel
   Row<NCH> a, b;
-  if (P1) a.load(P1 + (int64_t)t * E, E, lane); else a.zero();
+  if (P1 && g != 0.f) a.load(P1 + (int64_t)t * E, E, lane); else a.zero();     // (rows under a closed gate may not exist: GemmArgs::tile_skip)
   if (P2) b.load(P2 + (int64_t)t * E, E, lane); else b.zero();
 #pragma unroll
   for (int j = 0; j < NCH; ++j) {

@@ -42,6 +42,8 @@ struct GateArgs {
   int T, B, q0, sn, msf;
   double sratio;
   unsigned long long vmap;  // video index of batch element b in nibble b (0 for one video)
+  uint8_t* tile_flags;      // optional [B][nflags]: flag t / 64 of batch element b = its gate keeps a clip of 64 (t / 64) .. + 63
+  int nflags;               // (T + 63) / 64
 };
 int launch_gate(const GateArgs& a, hipStream_t st);
 

@@ -253,6 +253,22 @@ __global__ __launch_bounds__(1024) void k_gate(GateArgs p) {
     const bool m = vid_mask[t] != 0;
     p.mask_out[(size_t)b * p.T + t] = p.msf ? m : (m && g != 0.f);
   }
+  // which 64-clip row tiles this query keeps at all (GemmArgs::tile_skip): a wave's 64 lanes are the clips of one tile
+  if (p.tile_flags) {
+    for (int t0 = (tid & ~63); t0 < p.nflags * 64; t0 += 1024) {
+      const int t = t0 + (tid & 63);
+      float g = 0.f;
+      if (t < len) {
+        int src;
+        if (len == n) src = t;
+        else if (len == 2 * n) src = t >> 1;
+        else src = min((int)floorf((float)t * scale), n - 1);
+        g = sel[src] ? 1.f : 0.f;
+      }
+      const unsigned long long keep = __ballot(g != 0.f);
+      if ((tid & 63) == 0) p.tile_flags[(size_t)b * p.nflags + (t0 >> 6)] = keep ? 1 : 0;
+    }
+  }
 }
 
 int launch_gate(const GateArgs& a, hipStream_t st) {
