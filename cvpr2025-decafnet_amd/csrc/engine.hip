@@ -1656,8 +1656,23 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
       GateArgs ga{b.correl, nvid > 1 ? b.maskv : vid_mask, b.gate, sv > 1 ? b.mask_pre : b.mask_all, T0, nq, 0, c.sn, c.msf, (double)c.sratio, vmap0,
                   b.tile_flags, nflags};
       TRY(launch_gate(ga, st));
-      for (int v = 0; v < nvid; ++v) TRY(expert_half(v, true));
-      TRY(flush());
+      // the expert halves of ALL videos in one grid where the operands allow it: the ~half of the row tiles that survive the gates
+      // then fill the chip once (three launches of three videos each took as long as without the gate: a 64 x 256 tile is bound
+      // by the latency of its 32 K steps, not by how many tiles run beside it)
+      auto wit = m->wsplit.find(m->vid_w1);
+      const bool one_grid = nvid > 1 && nvid <= GEMM_ZMAX && E % 256 == 0 && T0 % 4 == 0 && wit != m->wsplit.end() && m->wsplit_ldw[m->vid_w1] == m->vid_ldw;
+      if (one_grid) {
+        GemmArgs base = gemm(vs.vid[0], T0, m->vid_w1, nullptr, b.P1, E, T0, E, D);
+        base.ldw = m->vid_ldw; base.a_scale = 1.f; base.Ws = wit->second; base.status = m->status; base.skip_stride = nflags;
+        const float* zA[GEMM_ZMAX]; float* zC[GEMM_ZMAX]; const uint8_t* zs[GEMM_ZMAX]; int zq[GEMM_ZMAX];
+        for (int v = 0; v < nvid; ++v) { zA[v] = vs.vid[v]; zC[v] = b.P1 + (size_t)v * T0 * E; zs[v] = b.tile_flags + (size_t)q_of[v] * nflags; zq[v] = vs.nq[v]; }
+        // the profile prices this launch at the clips the gate keeps at least -- int(sratio n) of n blocks -- not at the full product:
+        // the tiles it skips are work the reference does (on zeros) and this kernel does not
+        TRY(launch_gemm_split_z(base, nvid, zA, zC, zs, zq, m->wsplit_terms[m->vid_w1], st, std::min(1.0, std::max(0.0, (double)c.sratio))));
+      } else {
+        for (int v = 0; v < nvid; ++v) TRY(expert_half(v, true));
+        TRY(flush());
+      }
     } else {
       for (int v = 0; v < nvid; ++v) {
         if (m->vid_w1) TRY(expert_half(v, false));

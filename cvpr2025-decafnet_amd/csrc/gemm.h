@@ -98,6 +98,7 @@ struct GemmArgs {
   float a_scale;
 };
 
+constexpr int GEMM_ZMAX = 16;          // operand sets of one channel-major GEMM in one grid (launch_gemm_split_z)
 constexpr int GEMM_SCORE_MAXQ = 4;     // queries whose sidekick scores one channel-major GEMM carries (GemmArgs::score_out)
 
 // Launch up to 3 independent GEMMs of identical (M, N, K, mode) in one grid (blockIdx.z).
@@ -107,6 +108,11 @@ int launch_gemm(const GemmArgs* g, int count, GemmAMode mode, hipStream_t stream
 // planes, 3 products) or 6 (bf16x6: three bf16 planes, 6 products).  The weight image must have been made for the same mode.
 constexpr int GEMM_F16X3 = 16, GEMM_BF16X6 = 6;
 int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, hipStream_t stream);
+// one channel-major GEMM (base: W / Ws, shape, lda, ldc, skip_stride) over nz (A, C) pairs in one grid, each with its own row-tile
+// selection skip[z] / skip_nq[z] (GemmArgs::tile_skip; skip or skip[z] null = every tile); 64 x 256 tiles, N % 256 == 0, nz <= 16
+// work_fraction: what the per-launch profile counts as this launch's algorithmic work (a lower bound of the share of row tiles that run)
+int launch_gemm_split_z(const GemmArgs& base, int nz, const float* const* A, float* const* C, const uint8_t* const* skip, const int* skip_nq,
+                        int nterms, hipStream_t stream, double work_fraction = 1.0);
 // overflow: optional device word, bit 0 set if a weight does not fit the scaled fp16 range (f16x3 only)
 int launch_split_planes(const float* W, unsigned short* out, int N, int K, int64_t ldw, hipStream_t st, int nterms = GEMM_BF16X6,
                         unsigned* overflow = nullptr);

@@ -239,7 +239,7 @@ static int launch_cfg(const GemmBatch& b, int count, GemmAMode mode, hipStream_t
 
 int launch_gemm(const GemmArgs* g, int count, GemmAMode mode, hipStream_t stream) {
   DCF_CHECK(count >= 1 && count <= 3, "launch_gemm: count %d out of range", count);
-  GemmBatch b;
+  GemmBatch b{};
   for (int i = 0; i < 3; ++i) {
     b.g[i] = g[i < count ? i : 0];
     if (b.g[i].ldw == 0) b.g[i].ldw = b.g[i].K;

@@ -171,7 +171,13 @@ __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4 || (NST > 2
   constexpr int WG_OFF = (NPL * BM * ROWB > WM * WN * EPI_WAVE_FLOATS * 4 ? NPL * BM * ROWB : WM * WN * EPI_WAVE_FLOATS * 4);
   float* wg_stats = reinterpret_cast<float*>(smem_b + WG_OFF);
 
-  const GemmArgs p = LN ? batch.g[0] : (blockIdx.z == 0 ? batch.g[0] : (blockIdx.z == 1 ? batch.g[1] : batch.g[2]));
+  GemmArgs p = (LN || batch.zcount > 0) ? batch.g[0] : (blockIdx.z == 0 ? batch.g[0] : (blockIdx.z == 1 ? batch.g[1] : batch.g[2]));
+  if constexpr (AMODE == A_CHANMAJOR && !SCORE && !LN) {
+    if (batch.zcount > 0) {                             // uniform: operand set blockIdx.z of the one GEMM (GemmBatch::zcount)
+      const int z = blockIdx.z;
+      p.A = gemm_zsel(batch.zA, z); p.C = gemm_zsel(batch.zC, z); p.tile_skip = gemm_zsel(batch.zskip, z); p.skip_nq = gemm_zsel(batch.zskip_nq, z);
+    }
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
@@ -660,7 +666,7 @@ __global__ __launch_bounds__(KS * 64) void gemm_bf16s_kslice_kernel(GemmBatch ba
 }
 
 template <int WM, int WN, int TM, int TN>
-static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterms, hipStream_t stream) {
+static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterms, hipStream_t stream, double work_fraction = 1.0) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const GemmArgs& p = b.g[0];
   DCF_CHECK(!(p.flags & G_ADALN) || TN % 2 == 0, "launch_gemm_split: G_ADALN needs a tile whose waves span 64 columns (got %dx%d)", BM, BN);
@@ -670,7 +676,7 @@ static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterm
   const char* fam = nterms == 6 ? "gemm_bf16x6" : "gemm_f16x3";
   if (shapes) snprintf(name, sizeof(name), "%s<%dx%d,%s>[%dx%dx%dx%d]", fam, BM, BN, mode == A_ROWS ? "rows" : mode == A_ROWS_TAP3 ? "tap3" : "chanmajor", count, p.M, p.N, p.K);
   else snprintf(name, sizeof(name), "%s<%dx%d,%s>", fam, BM, BN, mode == A_ROWS ? "rows" : mode == A_ROWS_TAP3 ? "tap3" : "chanmajor");
-  const double mnk = (double)count * p.M * (double)p.N * p.K;
+  const double mnk = work_fraction * (double)count * p.M * (double)p.N * p.K;     // (work_fraction: the share of the row tiles a gated launch runs at least)
   ProfScope prof(name, stream, 2.0 * mnk,
                  4.0 * count * ((double)p.M * p.K / (mode == A_ROWS_TAP3 ? 3 : 1) + 1.5 * (double)p.N * p.K + (double)p.M * p.N * ((p.flags & G_RES) ? 2 : 1)));
   const int npl = nterms == 6 ? 3 : 2;
@@ -704,7 +710,7 @@ static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterm
 #define LS(MODE_, NT_) LSK(MODE_, NT_, false)
 #define LSN(MODE_, NT_) LSK(MODE_, NT_, true)
   bool want_stats = false, want_aln = false;
-  for (int i = 0; i < count; ++i) {
+  for (int i = 0; i < count && i < 3; ++i) {
     want_stats = want_stats || b.g[i].stats_out || b.g[i].stats_in;
     want_aln = want_aln || b.g[i].a_stats;
   }
@@ -760,7 +766,7 @@ static int launch_cfg_s(const GemmBatch& b, int count, GemmAMode mode, int nterm
     if constexpr (WM == 1 && WN == 4 && TM == 2) {
       bool want_score = false;
       int score_q = 0;
-      for (int i = 0; i < count; ++i) {
+      for (int i = 0; i < count && i < 3; ++i) {
         if (!b.g[i].score_out) continue;
         want_score = true;
         DCF_CHECK(b.g[i].score_tn && b.g[i].score_nq >= 1 && b.g[i].score_nq <= GEMM_SCORE_MAXQ && b.g[i].M % 4 == 0 &&
@@ -800,7 +806,7 @@ static int launch_kslice(const GemmBatch& b, int count, int nterms, hipStream_t 
   const char* fam = nterms == 6 ? "gemm_bf16x6" : "gemm_f16x3";
   if (shapes) snprintf(name, sizeof(name), "%s<%dx64,kslice>[%dx%dx%dx%d]", fam, small ? 32 : 64, count, p.M, p.N, p.K);
   else snprintf(name, sizeof(name), "%s<64x64,kslice>", fam);
-  const double mnk = (double)count * p.M * (double)p.N * p.K;
+  const double mnk = work_fraction * (double)count * p.M * (double)p.N * p.K;     // (work_fraction: the share of the row tiles a gated launch runs at least)
   ProfScope prof(name, stream, 2.0 * mnk, 4.0 * count * ((double)p.M * p.K + 1.5 * (double)p.N * p.K + (double)p.M * p.N * ((p.flags & G_RES) ? 2 : 1)));
   if (small) {   // (eight K slices for K = 1024 on these tiles measured the same as four: 2.34 vs 2.35 ms per step)
     if (nterms == 6) hipLaunchKernelGGL((gemm_bf16s_kslice_kernel<6, 1>), grid, dim3(256), 0, stream, b);
@@ -855,7 +861,7 @@ bool gemm_can_fuse_ln(int M, int N, int K, GemmAMode mode) {
 int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, hipStream_t stream) {
   DCF_CHECK(count >= 1 && count <= 3, "launch_gemm_split: count %d out of range", count);
   DCF_CHECK(nterms == T_F16 || nterms == 6, "launch_gemm_split: nterms must be 16 (f16x3) or 6 (bf16x6)");
-  GemmBatch b;
+  GemmBatch b{};
   for (int i = 0; i < 3; ++i) b.g[i] = g[i < count ? i : 0];
   if (mode == A_ROWS_TAP3)                                  // k3 convolutions walk K slab-major (see gemm_bf16s_kernel)
     for (int i = 0; i < 3; ++i) b.g[i].flags |= G_TAPSLAB;
@@ -939,6 +945,26 @@ int launch_gemm_split(const GemmArgs* g, int count, GemmAMode mode, int nterms, 
   if (N % 128 == 0 && wgs(64, 128) >= WANT) return launch_cfg_s<1, 4, 2, 1>(b, count, mode, nterms, stream);   // 64x128
   if (N % 64 == 0) return launch_cfg_s<2, 2, 1, 1>(b, count, mode, nterms, stream);                             // 64x64
   return launch_cfg_s<4, 1, 1, 1>(b, count, mode, nterms, stream);
+}
+
+// The same channel-major GEMM (f16x3 / bf16x6 operand split) over nz (A, C) pairs in ONE grid of 64 x 256 tiles, each pair with its own
+// row-tile selection (GemmArgs::tile_skip; skip[z] may be null): see GemmBatch::zcount.
+int launch_gemm_split_z(const GemmArgs& base, int nz, const float* const* A, float* const* C, const uint8_t* const* skip, const int* skip_nq,
+                        int nterms, hipStream_t stream, double work_fraction) {
+  DCF_CHECK(nz >= 1 && nz <= GEMM_ZMAX, "launch_gemm_split_z: %d operand sets (1 .. %d)", nz, GEMM_ZMAX);
+  DCF_CHECK(nterms == T_F16 || nterms == 6, "launch_gemm_split_z: nterms must be 16 (f16x3) or 6 (bf16x6)");
+  DCF_CHECK(base.Ws && base.M > 0 && base.M % 4 == 0 && base.N % 256 == 0 && base.K > 0 && base.K % SBK == 0 && base.lda % 4 == 0 && !base.flags &&
+                !base.score_out && !base.ln_w && !base.stats_out && !base.stats_in,
+            "launch_gemm_split_z: a plain channel-major GEMM with N %% 256 == 0 only");
+  GemmBatch b{};
+  for (int i = 0; i < 3; ++i) b.g[i] = base;
+  b.zcount = nz;
+  for (int z = 0; z < nz; ++z) {
+    DCF_CHECK(A[z] && C[z], "launch_gemm_split_z: null operand");
+    b.zA[z] = A[z]; b.zC[z] = C[z]; b.zskip[z] = skip ? skip[z] : nullptr; b.zskip_nq[z] = skip && skip[z] ? skip_nq[z] : 0;
+  }
+  b.g[0].A = A[0]; b.g[0].C = C[0];
+  return launch_cfg_s<1, 4, 2, 2>(b, nz, A_CHANMAJOR, nterms, stream, work_fraction);
 }
 
 }  // namespace dcf

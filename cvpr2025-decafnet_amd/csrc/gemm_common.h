@@ -5,9 +5,24 @@
 
 namespace dcf {
 
+// Up to three GEMMs of one shape share a grid (blockIdx.z selects g[z]).  zcount > 0 (channel-major tile kernel without scores only,
+// launch_gemm_split_z): blockIdx.z < zcount selects operand set z of g[0] -- the same GEMM over zcount (A, C) pairs, e.g. the expert
+// half of vid_map of every video of a forward in ONE launch, each with its own row-tile selection (GemmArgs::tile_skip).
 struct GemmBatch {
   GemmArgs g[3];
+  int zcount;
+  const float* zA[GEMM_ZMAX];
+  float* zC[GEMM_ZMAX];
+  const uint8_t* zskip[GEMM_ZMAX];
+  int zskip_nq[GEMM_ZMAX];
 };
+template <class T>
+__device__ __forceinline__ T gemm_zsel(const T (&a)[GEMM_ZMAX], int z) {      // (a cascade of scalar selects: a kernel-argument array indexed by
+  T r = a[0];                                                                //  blockIdx would be copied to scratch)
+#pragma unroll
+  for (int i = 1; i < GEMM_ZMAX; ++i) r = z == i ? a[i] : r;
+  return r;
+}
 
 // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (private L2 each), so blocks b and
 // b + 8 share an L2.  The column tiles of one row tile all read the same A rows: number the tiles so that they
