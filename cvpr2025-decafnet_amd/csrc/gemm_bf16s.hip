@@ -806,7 +806,7 @@ static int launch_kslice(const GemmBatch& b, int count, int nterms, hipStream_t 
   const char* fam = nterms == 6 ? "gemm_bf16x6" : "gemm_f16x3";
   if (shapes) snprintf(name, sizeof(name), "%s<%dx64,kslice>[%dx%dx%dx%d]", fam, small ? 32 : 64, count, p.M, p.N, p.K);
   else snprintf(name, sizeof(name), "%s<64x64,kslice>", fam);
-  const double mnk = work_fraction * (double)count * p.M * (double)p.N * p.K;     // (work_fraction: the share of the row tiles a gated launch runs at least)
+  const double mnk = (double)count * p.M * (double)p.N * p.K;
   ProfScope prof(name, stream, 2.0 * mnk, 4.0 * count * ((double)p.M * p.K + 1.5 * (double)p.N * p.K + (double)p.M * p.N * ((p.flags & G_RES) ? 2 : 1)));
   if (small) {   // (eight K slices for K = 1024 on these tiles measured the same as four: 2.34 vs 2.35 ms per step)
     if (nterms == 6) hipLaunchKernelGGL((gemm_bf16s_kslice_kernel<6, 1>), grid, dim3(256), 0, stream, b);
