@@ -11,7 +11,8 @@ Modules the reference imports at module level but never touches on the grounding
 replaced by inert stubs.
 
 Fixture families:  G1 ops.npz / ops64.npz, G2 gate.npz, G3 e2e_*.npz, G4 postproc.npz,
-G5 nms_kat.npz, G6 data_io.npz (feature files, annotations, text-CLS table through the reference's loaders).
+G5 nms_kat.npz, G6 data_io.npz (feature files, annotations, text-CLS table through the reference's loaders),
+G3 at bench scale: e2e_scale_c3.npz / e2e_scale_c4.npz (T = 16 384 / 65 536, outputs only; `make_golden.py scale`).
 """
 import importlib
 import importlib.util
@@ -429,6 +430,44 @@ def gen_e2e():
         save(f'e2e_{name}.npz', out)
 
 
+# Outputs-only fixtures at the scale the large-grid kernels run at: weights and inputs regenerate from the seeds
+# (synth.make_state_dict / make_inputs), the file holds the reference's logits / offsets / masks of every level and its encoded text.
+E2E_SCALE = {
+    # BASELINE configs[2]: the probe configuration of tests/test_gpu_e2e.py::test_probe_config_vs_oracle[16384]
+    'c3': dict(opt=dict(D=1024, E=256, TE=256, text_in=128, n_levels=8, win=9, n_heads=4, sn=60, sratio=0.3, msf=True, norm=True,
+                        max_seq_len=2048, text_layers=2, text_max_len=48), T=16384, vid_len=16001, nq=1, lq=32, wseed=7, iseed=8),
+    # BASELINE configs[3] unsharded: test_config4_unsharded_T65536_vs_oracle (position encoding resampled 8x, video_net.py:147-150)
+    'c4': dict(opt=dict(D=1024, E=256, TE=256, text_in=128, n_levels=8, win=9, n_heads=4, sn=60, sratio=0.3, msf=True, norm=True,
+                        max_seq_len=8192, text_layers=2, text_max_len=48), T=65536, vid_len=65000, nq=1, lq=32, wseed=11, iseed=12),
+}
+
+
+@torch.no_grad()
+def gen_e2e_scale():
+    from libs.modeling.model import PtTransformerEarlyFusionIterative
+    for name, c in E2E_SCALE.items():
+        if ONLY and name not in ONLY:
+            continue
+        opt = make_opt(**c['opt'])
+        model = PtTransformerEarlyFusionIterative(opt.clone(), second_fusion=False).eval()
+        shapes = {k: list(v.shape) for k, v in model.state_dict().items()}
+        sd = synth.make_state_dict(shapes, c['wseed'])
+        model.load_state_dict(sd)
+        inp = synth.make_inputs(c['opt']['D'], c['T'], c['vid_len'], c['nq'], c['opt']['text_in'], c['lq'], c['iseed'])
+        texts, tmasks = zip(*[model.encode_text(tok[None], torch.ones(1, 1, tok.size(-1), dtype=torch.bool)) for tok in inp['tokens']])
+        logits, offsets, masks = model(inp['vid'], inp['shallow_vid'], inp['vid_masks'], tuple(texts), inp['text_cls'], tuple(tmasks), eval=True)
+        out = dict(opt_kwargs=c['opt'], meta=dict(T=c['T'], vid_len=c['vid_len'], nq=c['nq'], lq=c['lq'], wseed=c['wseed'], iseed=c['iseed']),
+                   weight_checksum=torch.stack([sum(v.double().sum() for v in sd.values()), sum(v.double().abs().sum() for v in sd.values())]),
+                   input_checksum=torch.stack([inp['vid'].double().sum(), inp['shallow_vid'].double().abs().sum()]))
+        for q in range(c['nq']):
+            out[f'q{q}/text'] = texts[q]
+            for l in range(len(logits[q])):
+                out[f'q{q}/l{l}/logits'] = logits[q][l]
+                out[f'q{q}/l{l}/offsets'] = offsets[q][l]
+                out[f'q{q}/l{l}/mask'] = np.packbits(masks[q][l].numpy().astype(np.uint8))      # (a prefix of ones: one bit per clip)
+        save(f'e2e_scale_{name}.npz', out)
+
+
 @torch.no_grad()
 def gen_text_identity():
     """TextIdentity (text_net.py:22-89) in its three shapes -- embedding + attention-pooled token, position encoding with
@@ -813,6 +852,8 @@ if __name__ == '__main__':
         gen_e2e_variants()
     if 'text_identity' in which or 'e2e' in which:
         gen_text_identity()
+    if 'scale' in which:
+        gen_e2e_scale()
     if 'train' in which:
         gen_train()
     if 'postproc' in which:

@@ -331,6 +331,50 @@ def test_secondary_compositions(name):
             assert torch.equal(out[2][q][l], g.t(f'q{q}/l{l}/mask'))
 
 
+def scale_fixture(name):
+    """(kw, meta, reference outputs) of tests/golden/e2e_scale_<name>.npz: logits / offsets / masks of every level as the reference
+    returned them (masks stored one bit per clip)"""
+    g = Golden(f'e2e_scale_{name}.npz')
+    meta, kw = g.js('meta'), g.js('opt_kwargs')
+    L = kw['n_levels']
+    want = ([], [], [])
+    for q in range(meta['nq']):
+        lg = [g.t(f'q{q}/l{l}/logits') for l in range(L)]
+        want[0].append(lg)
+        want[1].append([g.t(f'q{q}/l{l}/offsets') for l in range(L)])
+        want[2].append([torch.from_numpy(np.unpackbits(g.t(f'q{q}/l{l}/mask').numpy())[:lg[l].numel()].astype(bool)).view(1, 1, -1)
+                        for l in range(L)])
+    return g, kw, meta, want
+
+
+@pytest.mark.parametrize('name', ['c3', 'c4'])
+def test_oracle_at_bench_scale(name):
+    """the oracle against the REFERENCE's outputs where the large-grid kernels run: BASELINE configs[2] (T = 16 384, vid_len 16 001) and
+    configs[3] unsharded (T = 65 536, position encoding resampled 8x, 1 084 scoring blocks); model.py:480-565, video_net.py:141-151"""
+    g, kw, meta, want = scale_fixture(name)
+    pkg = load_pkg()
+    opt = pkg.config.make_opt(**kw)
+    model_shapes = {k: list(v.shape) for k, v in pkg.modeling.create_model(opt).state_dict().items()}
+    sd = pkg.synth.make_state_dict(model_shapes, meta['wseed'])
+    chk = torch.stack([sum(v.double().sum() for v in sd.values()), sum(v.double().abs().sum() for v in sd.values())])
+    torch.testing.assert_close(chk, g.t('weight_checksum'), rtol=1e-12, atol=0)            # the same weights as the generator's
+    inp = pkg.synth.make_inputs(kw['D'], meta['T'], meta['vid_len'], meta['nq'], kw['text_in'], meta['lq'], meta['iseed'])
+    torch.testing.assert_close(torch.stack([inp['vid'].double().sum(), inp['shallow_vid'].double().abs().sum()]), g.t('input_checksum'), rtol=1e-12, atol=0)
+    texts, tmasks = zip(*[R.encode_text(sd, opt.model, t[None], torch.ones(1, 1, t.size(-1), dtype=torch.bool)) for t in inp['tokens']])
+    for q in range(meta['nq']):
+        close(texts[q], g.t(f'q{q}/text'), atol=1e-5, rtol=1e-5)
+    with torch.no_grad():
+        out = R.forward_eval(sd, opt.model, inp['vid'], inp['shallow_vid'], inp['vid_masks'], list(texts), inp['text_cls'], list(tmasks))
+    worst = 0.0
+    for q in range(meta['nq']):
+        for l in range(kw['n_levels']):
+            assert torch.equal(out[2][q][l].view(-1), want[2][q][l].view(-1))
+            worst = max(worst, float((out[0][q][l] - want[0][q][l]).abs().max()), float((out[1][q][l] - want[1][q][l]).abs().max()))
+            close(out[0][q][l], want[0][q][l], atol=2e-5, rtol=2e-5)
+            close(out[1][q][l], want[1][q][l], atol=2e-5, rtol=2e-5)
+    print(f'oracle vs reference at {name}: max |delta| = {worst:.2e}')
+
+
 def test_text_identity():
     """TextIdentity + AttNPool1D restatement (text_net.py:22-89, blocks.py:396-411) vs the reference, alone and inside a model"""
     g = Golden('text_identity.npz')
