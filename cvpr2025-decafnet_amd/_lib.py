@@ -61,6 +61,7 @@ SIGNATURES = {
     'dcf_graph_active': (i32, [vp]),
     'dcf_debug_set_option': (i32, [ctypes.c_char_p, i32]),
     'dcf_model_set_graph_mode': (i32, [vp, i32]),
+    'dcf_model_set_ln_carry': (i32, [vp, i32]),
     'dcf_profile_enable': (i32, [i32]),
     'dcf_profile_report': (i64, [ctypes.c_char_p, i64]),
     'dcf_collect_segments': (i32, [c_f32p, c_f32p, c_u8p, i32, i64, i32, f32, i32, f32, c_f32p, c_f32p, c_i32p, vp]),

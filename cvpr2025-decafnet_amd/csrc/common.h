@@ -223,6 +223,15 @@ constexpr float GELU_A1 = 0.5f * 0.254829592f, GELU_A2 = 0.5f * -0.284496736f, G
 __device__ __forceinline__ float gelu_half_poly(float t) {      // 0.5 (a1 t + a2 t^2 + ... + a5 t^5)
   return t * (GELU_A1 + t * (GELU_A2 + t * (GELU_A3 + t * (GELU_A4 + t * GELU_A5))));
 }
+// One-pass LayerNorm statistics (sum, sum of squares carried between kernels: var = E[x^2] - mean^2) lose ~1e-7 mean^2 / var of the
+// variance to cancellation -- fp32 level while a row's mean does not dwarf its spread, which holds for every activation the
+// synthetic and the reference-generated fixtures produce (|mean| / sigma <= 3), but is an assumption about a real checkpoint.  It is
+// guarded, not assumed: a consumer that meets a row with mean^2 > LN_ILL_RATIO (var + eps) -- |mean| > 8 sigma, relative error of rstd
+// beyond ~1e-5 -- raises bit 1 of the sticky numerics word (dcf_numerics_status: 16); the host then switches the model to the
+// standalone two-pass LayerNorm launches (dcf_model_set_ln_carry) and repeats the forward.  All-zero (masked) rows never trip it.
+constexpr float LN_ILL_RATIO = 64.f;
+__device__ __forceinline__ bool ln_ill(float mean, float var) { return mean * mean > LN_ILL_RATIO * (var + 1e-5f); }
+
 __device__ __forceinline__ float relu_max(float x) {             // max(x, 0) as ONE v_max_f32 (fmaxf puts a canonicalising max in front)
   float r;
   asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));

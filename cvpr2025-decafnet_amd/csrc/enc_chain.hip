@@ -226,6 +226,7 @@ __global__ __launch_bounds__(256, 1) void k_enc_qkv(EncQkvArgs p) {
       const float var = fmaxf(__builtin_fmaf(-mean, mean, xor32_sum(s2) * (1.0f / EE)), 0.f);
       fmean = mean;
       frstd = 1.0f / sqrtf(var + 1e-5f);
+      if (inseq && ln_ill(mean, var) && p.status) atomicOr(p.status, 2u);         // (common.h LN_ILL_RATIO)
     }
     // output tile t2 of pair `pr`, group g: the folded LayerNorm rstd (acc - mean s[n]) + c[n] (GemmArgs::stats_in), store
     auto epilogue = [&](int pr, int t2, int g) __attribute__((always_inline)) {

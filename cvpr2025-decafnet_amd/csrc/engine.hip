@@ -218,6 +218,7 @@ struct dcf_model {
   std::unordered_map<const float*, int> wsplit_terms;               // mode the image of a weight was made for (16 / 6)
   int gemm_terms = 16;                       // 16: f16x3 split MFMA GEMM (default); 6: bf16x6; 0: native fp32 MFMA
   bool force_x6 = false;                     // a weight did not fit the scaled fp16 range: the model runs bf16x6
+  bool no_ln_carry = false;                  // dcf_model_set_ln_carry(m, 0): every LayerNorm as its own two-pass launch
   unsigned* status = nullptr;                // device words: [0] sticky numerics flag of the f16x3 GEMMs, [1] weight range flag
   bool finalized = false;
   const float* pe = nullptr;
@@ -885,10 +886,12 @@ static int run_ffn(dcf_model* m, const float* X, const float* fc_w, const float*
 }
 
 // can the LayerNorm between a producer GEMM (rows x n_prod, K = k_prod) and the ffn.fc that consumes it ride as row statistics?
-static bool g_no_carry() {
+static bool g_no_carry_env() {
   static const bool off = getenv("DCF_NO_LN_CARRY") != nullptr;      // developer switch: standalone LayerNorm launches instead
   return off;
 }
+// ... or the model was told so (dcf_model_set_ln_carry: a row's mean dwarfed its spread, common.h LN_ILL_RATIO)
+#define g_no_carry() (g_no_carry_env() || m->no_ln_carry)
 // (each GEMM is asked about with the arithmetic of ITS weight image: one of the two may have fallen back to bf16x6)
 static bool can_carry_ln(dcf_model* m, const float* prod_w, const float* fc_wf, int rows, int n_prod, int k_prod, int E) {
   if (g_no_carry() || !fc_wf || !prod_w || m->gemm_terms == 0 || !m->wsplit.count(fc_wf) || !m->wsplit.count(prod_w)) return false;
@@ -932,7 +935,8 @@ static int enc_chain_min_rows() {
 static bool can_chain_enc(dcf_model* m, const EncW& w, int rows, int stride, int64_t ldx) {
   static const bool off = getenv("DCF_NO_ENC_CHAIN") != nullptr;    // developer switch: the separate launches
   const dcf_config& c = m->cfg;
-  return !off && m->gemm_terms == GEMM_F16X3 && w.qkv_chain[0] && w.qkv_chain[1] && w.qkv_chain[2] && stride == 1 &&
+  // (m->no_ln_carry: the kernel folds q / k / v_norm with one-pass statistics of the convolution outputs)
+  return !off && !m->no_ln_carry && m->gemm_terms == GEMM_F16X3 && w.qkv_chain[0] && w.qkv_chain[1] && w.qkv_chain[2] && stride == 1 &&
          enc_chain_supports(c.E, c.vid_heads, c.win > 0 ? c.win : 99) && rows >= enc_chain_min_rows() && ldx % 4 == 0;
 }
 
@@ -1966,7 +1970,7 @@ static int text_encode(dcf_model* m, const float* tokens, const uint8_t* token_m
 extern "C" {
 
 const char* dcf_last_error(void) { return dcf::g_err.c_str(); }
-int dcf_abi_version(void) { return 8; }
+int dcf_abi_version(void) { return 9; }
 
 int dcf_model_create(const dcf_config* cfg, dcf_model** out) {
   DCF_CHECK(cfg && out, "dcf_model_create: null argument");
@@ -2138,9 +2142,18 @@ int dcf_numerics_status(dcf_model* m, int32_t reset, void* stream) {
     DCF_HIP(hipMemcpyAsync(&flag, m->status, sizeof(flag), hipMemcpyDeviceToHost, st));
     if (reset) DCF_HIP(hipMemsetAsync(m->status, 0, sizeof(unsigned), st));
     DCF_HIP(hipStreamSynchronize(st));
-    if (flag) out |= 1;
+    if (flag & ~2u) out |= 1;
+    if (flag & 2u) out |= 16;                  // one-pass LayerNorm statistics met an ill-conditioned row (common.h LN_ILL_RATIO)
   }
   return out;
+}
+
+int dcf_model_set_ln_carry(dcf_model* m, int32_t on) {
+  DCF_CHECK(m, "dcf_model_set_ln_carry: null model");
+  const bool off = on == 0;
+  if (off != m->no_ln_carry) dcf::drop_graph(m);
+  m->no_ln_carry = off;
+  return 0;
 }
 
 int dcf_numerics_status_async(dcf_model* m, int32_t* host_dst, void* stream) {
@@ -2532,7 +2545,24 @@ int dcf_op_ffn(const float* X, const float* ln_w, const float* ln_b, const float
     a.X = X; a.ldx = E; a.W1s = p1; a.b1 = fc_b; a.ln_s = fc_s; a.stats = stats; a.stats_slots = E / 64; a.W2s = p2; a.b2 = b2; a.ls = ls;
     a.R = X; a.ldr = E; a.rowmask = mask; a.C = C; a.ldc = E; a.stats_out = stats_out; a.stats_w = 64; a.M = M;
     a.variant = chain == 1 ? 0 : chain - 1;        // chain 2: the four-wave kernel, 3: the eight-wave kernel
+    unsigned* word = nullptr;                      // the sticky numerics word of this call (bit 1: common.h LN_ILL_RATIO)
+    DCF_HIP(hipMallocAsync((void**)&word, sizeof(unsigned), st));
+    DCF_HIP(hipMemsetAsync(word, 0, sizeof(unsigned), st));
+    a.status = word;
     rc = dcf::launch_ffn_chain(a, st);
+    unsigned flag = 0u;
+    if (rc == 0) { DCF_HIP(hipMemcpyAsync(&flag, word, sizeof(flag), hipMemcpyDeviceToHost, st)); DCF_HIP(hipStreamSynchronize(st)); }
+    DCF_HIP(hipFreeAsync(word, st));
+    if (rc == 0 && ln_w && (flag & 2u)) {
+      // a row's mean dwarfs its spread: the folded one-pass statistics are not trustworthy for it -- what the engine does after
+      // dcf_model_set_ln_carry(m, 0): the two-pass LayerNorm as its own launch, the same kernel on its output
+      DCF_HIP(hipMallocAsync((void**)&xn, (size_t)M * E * sizeof(float), st));
+      dcf::LnArgs ln{}; ln.X = X; ln.ldx = E; ln.Y = xn; ln.ldy = E; ln.w = ln_w; ln.b = ln_b; ln.rows = M; ln.C = E;
+      rc = dcf::launch_ln(ln, st);
+      if (rc == 0) rc = dcf::launch_split_planes(W1, p1, H, E, E, st, nterms);
+      a.X = xn; a.b1 = b1; a.ln_s = nullptr; a.stats = nullptr; a.status = nullptr;
+      if (rc == 0) rc = dcf::launch_ffn_chain(a, st);
+    }
   } else if (rc == 0) {
     DCF_HIP(hipMallocAsync((void**)&hid, (size_t)M * H * sizeof(float), st));
     dcf::GemmArgs gf = dcf::gemm(fc_in, E, fc_w, fc_b, hid, H, M, H, E);

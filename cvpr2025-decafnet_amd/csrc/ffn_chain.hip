@@ -138,7 +138,9 @@ __global__ __launch_bounds__(256, 1) void k_ffn_chain(FfnChainArgs p) {
     for (int k = 0; k < p.stats_slots; ++k) { s1 += sp[2 * k]; s2 += sp[2 * k + 1]; }
     const float inv = 1.0f / (float)FE;
     mean = s1 * inv;
-    rstd = 1.0f / sqrtf(fmaxf(__builtin_fmaf(-mean, mean, s2 * inv), 0.f) + 1e-5f);
+    const float var = fmaxf(__builtin_fmaf(-mean, mean, s2 * inv), 0.f);
+    rstd = 1.0f / sqrtf(var + 1e-5f);
+    if (row < p.M && ln_ill(mean, var) && p.status) atomicOr(p.status, 2u);       // (common.h LN_ILL_RATIO)
   }
   // folded LayerNorm: 16 (rstd (acc U - mean s) + c) = acc r1 + (16 s) r2 + 16 c
   const float r1 = FOLD ? rstd * U16 : U16, r2 = -rstd * mean;
@@ -491,7 +493,9 @@ __global__ __launch_bounds__(512, 2) void k_ffn_pair(FfnChainArgs p, int tiles) 
         for (int k = 0; k < p.stats_slots; ++k) { s1 += sp[2 * k]; s2 += sp[2 * k + 1]; }
         const float inv = 1.0f / (float)FE;
         const float mean = s1 * inv;
-        const float rstd = 1.0f / sqrtf(fmaxf(__builtin_fmaf(-mean, mean, s2 * inv), 0.f) + 1e-5f);
+        const float var = fmaxf(__builtin_fmaf(-mean, mean, s2 * inv), 0.f);
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        if (ln_ill(mean, var) && p.status) atomicOr(p.status, 2u);                // (common.h LN_ILL_RATIO; a clamped row repeats row M - 1)
         r1_o = rstd * U16;
         r2_o = -rstd * mean;
       }

@@ -211,7 +211,9 @@ __global__ __launch_bounds__(WM * WN * 64, ((TM * TN >= 5 || TM >= 4 || (NST > 2
       float s1 = 0.f, s2 = 0.f;
       for (int k = 0; k < p.a_stats_slots; ++k) { s1 += sp[2 * k]; s2 += sp[2 * k + 1]; }
       const float mean = s1 * inv;
-      const float rstd = 1.0f / sqrtf(fmaxf(__builtin_fmaf(-mean, mean, s2 * inv), 0.f) + 1e-5f);
+      const float var = fmaxf(__builtin_fmaf(-mean, mean, s2 * inv), 0.f);
+      const float rstd = 1.0f / sqrtf(var + 1e-5f);
+      if (ln_ill(mean, var) && p.status) atomicOr(p.status, 2u);            // (common.h LN_ILL_RATIO)
       aln_row[2 * t] = rstd;
       aln_row[2 * t + 1] = -mean * rstd;
     }

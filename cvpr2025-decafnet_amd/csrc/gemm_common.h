@@ -293,6 +293,7 @@ __device__ __forceinline__ void stats_load(const GemmArgs& p, float* wg, int m0,
     const float var = fmaxf(__builtin_fmaf(-mean, mean, s2 * inv), 0.f);
     wg[2 * t] = mean;
     wg[2 * t + 1] = 1.0f / sqrtf(var + 1e-5f);
+    if (row < p.M && ln_ill(mean, var) && p.status) atomicOr(p.status, 2u);      // (common.h LN_ILL_RATIO)
   }
 }
 

@@ -327,6 +327,12 @@ class GroundingEvaluator:
     def _check_numerics(models):
         """the f16x3 GEMM mode flags operands beyond the fp16 range (|a| >= 4094) instead of passing inf / NaN on"""
         for m in models:
-            if hasattr(m, 'numerics_status') and m.numerics_status(reset=True) & 1:
+            st = m.numerics_status(reset=True) if hasattr(m, 'numerics_status') else 0
+            if st & 1:
                 raise RuntimeError("an activation left the fp16 operand range of the f16x3 GEMM mode: results are not valid; "
                                    "set opt.model.gemm_mode = 'bf16x6'")
+            if st & 16:
+                for mm in models:
+                    mm.set_ln_carry(False)
+                raise RuntimeError("a LayerNorm carried between kernels as one-pass row statistics met a row whose mean dwarfs its spread: "
+                                   "results are not valid; the model now runs two-pass LayerNorm launches (set_ln_carry(False)) -- run again")

@@ -356,6 +356,11 @@ class _Engine:
             _lib.check(self.lib.dcf_model_set_graph_mode(self.handle, code), 'dcf_model_set_graph_mode')
             self._graph_mode = code
 
+    def set_ln_carry(self, on):
+        if getattr(self, '_ln_carry', True) != bool(on):
+            _lib.check(self.lib.dcf_model_set_ln_carry(self.handle, int(bool(on))), 'dcf_model_set_ln_carry')
+            self._ln_carry = bool(on)
+
     def bind(self, model):
         """(Re)bind the module's parameters if their storage or contents changed.  The walk over the module tree
         (state_dict) costs about as much host time as a whole T = 16384 forward takes on the GPU, so the tensor list is
@@ -365,6 +370,7 @@ class _Engine:
         # replaced Parameter OBJECTS (module.weight = nn.Parameter(...), load_state_dict(assign=True), re-parametrisation)
         # keep neither the storage nor the version counter of the cached ones: the identity of every parameter slot is
         # part of the check (a walk over _parameters dicts, no state_dict construction: ~0.1 ms for 400 tensors)
+        self.set_ln_carry(getattr(model, 'ln_carry', True))
         ids = model._parameter_ids()
         if self.cached is None or ids != self.cached_ids:
             self.cached = model._named_engine_tensors()
@@ -487,6 +493,7 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         # output buffers are reused between calls of the same shape, which lets the engine replay one captured HIP
         # graph instead of ~135 kernel launches -- results of call k are overwritten by call k+1.
         self.reuse_output_buffers = False
+        self.ln_carry = True                        # LayerNorms carried between kernels as row statistics where the kernels allow (set_ln_carry)
         self._out_cache = {}
         # 'auto' (replay a HIP graph for large batched forwards, launch small ones eagerly: dcf_model_set_graph_mode),
         # 'always' or 'never'
@@ -579,13 +586,31 @@ class PtTransformerEarlyFusionIterative(nn.Module):
 
     def numerics_status(self, reset=False):
         """dcf_numerics_status of the engine (blocking): bit 0 = a GEMM of the f16x3 mode produced a non-finite value since
-        the last reset (an activation beyond |a| < 4094): re-run with opt.model.gemm_mode = 'bf16x6'."""
+        the last reset (an activation beyond |a| < 4094): re-run with opt.model.gemm_mode = 'bf16x6'; 16 = a LayerNorm carried as
+        one-pass row statistics met an ill-conditioned row: set_ln_carry(False) and repeat."""
         if self._engine is None:
             return 0
         rc = self._engine.lib.dcf_numerics_status(self._engine.handle, int(bool(reset)), _lib.current_stream())
         if rc < 0:
             _lib.check(rc, 'dcf_numerics_status')
         return rc
+
+    def set_ln_carry(self, on):
+        """dcf_model_set_ln_carry: False = every LayerNorm of the model runs as its own two-pass launch instead of riding between
+        kernels as one-pass row statistics (what numerics_status() & 16 asks for)"""
+        self.ln_carry = bool(on)
+        if self._engine is not None:
+            self._engine.set_ln_carry(on)
+
+    def _ln_carry_tripped(self):
+        """numerics_status() & 16: a carried LayerNorm met a row whose mean dwarfs its spread (mean^2 > 64 var).  The model switches
+        to the two-pass LayerNorm launches by itself; the forwards since the last check have to be repeated."""
+        self.set_ln_carry(False)
+        self.numerics_status(reset=True)
+        raise RuntimeError("a LayerNorm carried between kernels as one-pass row statistics met a row whose mean dwarfs its spread "
+                           "(|mean| > 8 sigma) in an earlier forward of this model: its variance lost accuracy to cancellation.  The "
+                           "model now runs every LayerNorm as its own two-pass launch (set_ln_carry(False)); repeat the forward(s) "
+                           "since the last check.  The flag has been reset.")
 
     def graph_active(self):
         """dcf_graph_active: how the last forward was issued (0 eager launches, 1 HIP-graph replay, 2 capture + launch)"""
@@ -648,6 +673,8 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         if not ev.query():
             return
         eng.status_probe[2] = False
+        if int(host[0]) & 2:
+            self._ln_carry_tripped()
         if int(host[0]) & 1:
             self.numerics_status(reset=True)
             raise RuntimeError("an activation left the fp16 operand range of the f16x3 GEMM mode (|a| >= 4094) in an earlier "
@@ -924,6 +951,7 @@ class PtTransformer(PtTransformerEarlyFusionIterative):
         self.gemm_mode = GEMM_MODES[mo.get('gemm_mode', 'f16x3')]
         self._engine = None
         self.reuse_output_buffers = False
+        self.ln_carry = True                        # LayerNorms carried between kernels as row statistics where the kernels allow (set_ln_carry)
         self._out_cache = {}
         self.graph_mode = 'auto'
 
@@ -962,6 +990,7 @@ class PtTransformerEarlyFusion(PtTransformerEarlyFusionIterative):
         self.gemm_mode = GEMM_MODES[mo.get('gemm_mode', 'f16x3')]
         self._engine = None
         self.reuse_output_buffers = False
+        self.ln_carry = True                        # LayerNorms carried between kernels as row statistics where the kernels allow (set_ln_carry)
         self._out_cache = {}
         self.graph_mode = 'auto'
 

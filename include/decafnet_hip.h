@@ -91,13 +91,21 @@ int dcf_model_bind(dcf_model* m, const char* name, const float* data, const int6
  *   1 = some GEMM accumulator left the finite range since the last reset (an activation beyond the fp16 operand range
  *       |a| < 4094 of the f16x3 mode, or inf/NaN in the inputs): outputs since then are not trustworthy -- re-run with
  *       gemm_mode = 6;   2 = a weight did not fit (|w| >= 255.9) and the model fell back to bf16x6 at finalize;
- *   4 = the model runs bf16x6;  8 = the model runs the native fp32 MFMA path.   reset != 0 clears bit 1's source. */
+ *   4 = the model runs bf16x6;  8 = the model runs the native fp32 MFMA path;
+ *  16 = a LayerNorm that rides between two kernels as one-pass row statistics (sum, sum of squares) met a row whose mean dwarfs its
+ *       spread (mean^2 > 64 (var + eps)): the variance of such a row loses more than ~1e-5 to cancellation -- call
+ *       dcf_model_set_ln_carry(m, 0) and repeat the forward (ABI version 9).   reset != 0 clears the sources of 1 and 16. */
 int dcf_numerics_status(dcf_model* m, int32_t reset, void* stream);
 /* The same status word without blocking: enqueues a 4-byte device -> host copy of the sticky flag (bit 0 above) into
  * `host_dst` (pinned memory) on `stream`; the caller reads it once an event recorded after the call has completed.
  * Independently of either call, a forward that ends with the flag raised overwrites its logits with NaN, so that a plain
- * `model(...)` caller (the reference's Evaluator, libs/worker_v2.py:1007) cannot mistake them for valid scores. */
+ * `model(...)` caller (the reference's Evaluator, libs/worker_v2.py:1007) cannot mistake them for valid scores.
+ * (The word copied here is the raw device word: bit 0 = status 1, bit 1 = status 16.) */
 int dcf_numerics_status_async(dcf_model* m, int32_t* host_dst, void* stream);
+/* on = 0: every LayerNorm of the model runs as its own two-pass launch (blocks.py:125-131: mean, then the mean of squared deviations)
+ * instead of riding between kernels as one-pass row statistics; on = 1 (default): carried where the kernels allow.  Drops captured
+ * graphs.  What dcf_numerics_status bit 16 asks for.  ABI version 9. */
+int dcf_model_set_ln_carry(dcf_model* m, int32_t on);
 
 /* Absolute position encoding buffer `vid_net.pe` (non-persistent in the reference,
  * libs/modeling/video_net.py:75-78): token-major (T, E) fp32 already resampled for length T
@@ -301,7 +309,9 @@ int dcf_op_linear_ln_carry(const float* A, const float* W1, const float* b1, con
  * ln_w / ln_b NULL = no LayerNorm in front; ls NULL = 1; mask NULL = all rows valid; stats_out (optional, (M, E / 64, 2)):
  * (sum, sum of squares) of every row written to C.  f16x3 operand split.  chain = 0: two GEMMs with the hidden activations in
  * memory; chain = 1 (E = 256 only): one kernel, the hidden activations stay in registers (csrc/ffn_chain.hip: the default kernel;
- * chain = 2: its four-wave form, chain = 3: its eight-wave producer / consumer form -- bit-identical results). */
+ * chain = 2: its four-wave form, chain = 3: its eight-wave producer / consumer form -- bit-identical results).  With a LayerNorm
+ * in front the one-kernel form carries it as one-pass row statistics; if a row turns out ill-conditioned for that (dcf_numerics_status
+ * bit 16) the call repeats itself with the LayerNorm as its own two-pass launch, as the engine does after dcf_model_set_ln_carry(m, 0). */
 int dcf_op_ffn(const float* X, const float* ln_w, const float* ln_b, const float* W1, const float* b1, const float* W2, const float* b2,
                const float* ls, const uint8_t* mask, float* C, float* stats_out, int32_t M, int32_t E, int32_t chain, void* stream);
 

@@ -298,6 +298,70 @@ def test_ffn_chain_vs_fp64(L, M, with_ln, with_ls, with_mask, with_stats, shift)
         pkg._lib.check(lib.dcf_op_ffn(P(d['X']), None, None, P(d['W1']), P(d['b1']), P(d['W2']), P(d['b2']), None, None, P(C), None, 8, 128, 1, st()))
 
 
+@pytest.mark.parametrize('ratio', [30.0, 300.0])
+def test_ffn_chain_guards_the_one_pass_layernorm(L, ratio):
+    """rows whose mean dwarfs their spread (|mean| / sigma = 30, 300): the LayerNorm in front of the FFN kernel rides as one-pass row
+    statistics (var = E[x^2] - mean^2: relative error ~1e-7 mean^2 / var), the kernel flags such rows (common.h LN_ILL_RATIO, numerics
+    bit 16) and the call repeats with the two-pass LayerNorm launch -- the FFN's contribution C - X must hold the fp64 reference at the
+    usual tolerance (unguarded: 5e-5 .. 5e-3 off).  blocks.py:125-131 is two-pass."""
+    pkg, lib = L
+    E, M = 256, 20000
+    g = torch.Generator().manual_seed(int(ratio))
+    X = torch.randn(M, E, generator=g) + ratio * (torch.rand(M, 1, generator=g) * 0.2 + 0.9) * torch.where(torch.rand(M, 1, generator=g) > 0.5, 1.0, -1.0)
+    lw, lb = torch.rand(E, generator=g) + 0.5, torch.randn(E, generator=g) * 0.5
+    W1 = torch.randn(4 * E, E, generator=g) / math.sqrt(E)
+    b1 = torch.randn(4 * E, generator=g) * 0.3
+    W2 = torch.randn(E, 4 * E, generator=g) / math.sqrt(4 * E)
+    b2 = torch.randn(E, generator=g) * 0.3
+    x = X.double()
+    mu = x.mean(1, keepdim=True)
+    xin = (x - mu) / torch.sqrt(((x - mu) ** 2).mean(1, keepdim=True) + 1e-5) * lw.double() + lb.double()
+    y = F.gelu(xin @ W1.double().t() + b1.double()) @ W2.double().t() + b2.double()
+    d = {k: v.cuda() for k, v in dict(X=X, lw=lw, lb=lb, W1=W1, b1=b1, W2=W2, b2=b2).items()}
+    for chain in (1, 2, 3):
+        C = torch.empty(M, E, device='cuda')
+        pkg._lib.check(lib.dcf_op_ffn(P(d['X']), P(d['lw']), P(d['lb']), P(d['W1']), P(d['b1']), P(d['W2']), P(d['b2']), None, None,
+                                      P(C), None, M, E, chain, st()))
+        # what fp32 itself allows at |x| ~ ratio, sigma = 1: the row mean (a sum of 256 values ~ratio) and x - mean are good to a few
+        # ulp(ratio) whatever the algorithm -- the reference's fp32 LayerNorm as well -- and C = X + y is rounded at |X| ~ ratio
+        got_y = C.cpu().double() - x
+        ulp = 2.0 ** (math.floor(math.log2(ratio * 1.2)) - 23)
+        torch.testing.assert_close(got_y, y, rtol=2e-5, atol=2e-5 + 8 * ulp)
+
+
+def test_layernorm_carry_trips_the_guard_and_the_model_falls_back(L):
+    """the same guard on a model: an encoder layer whose input rows have |mean| >> sigma raises numerics bit 16; set_ln_carry(False)
+    sends every LayerNorm through its own two-pass launch and the flag stays clear"""
+    import ctypes
+    pkg, lib = L
+    kw = dict(D=64, E=256, TE=64, text_in=32, n_levels=2, win=5, n_heads=4, sn=8, sratio=0.3, msf=True, norm=True,
+              max_seq_len=128, text_layers=1, text_max_len=24)
+    opt = pkg.config.make_opt(**kw)
+    model = pkg.modeling.create_model(opt)
+    sd = pkg.synth.make_state_dict({k: list(v.shape) for k, v in model.state_dict().items()}, 3)
+    # a DC-heavy residual stream: the last embedding LayerNorm's bias lifts every channel of every clip by 40 (ReLU keeps it), so the
+    # rows that reach ln_ffn of the first encoder layer -- carried as row statistics -- have |mean| ~ 40 at a spread below 1
+    sd['vid_net.embd_norms.1.bias'] = sd['vid_net.embd_norms.1.bias'] + 40.0
+    model.load_state_dict(sd)
+    model = model.cuda().eval().requires_grad_(False)
+    T = 20480
+    inp = pkg.synth.make_inputs(64, T, T, 1, 32, 6, 4)
+    tm = [model.encode_text(t[None].cuda(), torch.ones(1, 1, t.size(-1), dtype=torch.bool, device='cuda')) for t in inp['tokens']]
+    args = (inp['vid'].cuda(), inp['shallow_vid'].cuda(), inp['vid_masks'].cuda(), tuple(t for t, _ in tm), inp['text_cls'].cuda(), tuple(m for _, m in tm))
+    model(*args, eval=True)
+    torch.cuda.synchronize()
+    assert model.ln_carry
+    with pytest.raises(RuntimeError, match='mean dwarfs its spread'):        # the next call into the model sees the flag of the first one
+        model(*args, eval=True)
+    assert not model.ln_carry, 'the model must have switched to the two-pass LayerNorm launches by itself'
+    out = model(*args, eval=True)
+    assert model.numerics_status(reset=True) & 16 == 0
+    from oracle import decafnet_ref as R
+    want = R.forward_eval(sd, opt.model, inp['vid'], inp['shallow_vid'], inp['vid_masks'], [t.cpu() for t, _ in tm], inp['text_cls'], [m.cpu() for _, m in tm])
+    for l in range(2):
+        torch.testing.assert_close(out[0][0][l].cpu(), want[0][0][l], rtol=2e-4, atol=2e-4)
+
+
 @pytest.mark.parametrize('nterms,tol', [(6, 2e-5), (16, 2e-5)])
 @pytest.mark.parametrize('M,N,K', [(256, 256, 512), (1000, 128, 64), (4096, 256, 1024), (16384, 256, 96), (20, 128, 32)])
 def test_linear_channel_major_split(L, M, N, K, nterms, tol):
