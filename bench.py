@@ -168,10 +168,11 @@ def run_sharded(args, pkg, dist, rank, world, dev):
                           for tok in inp['tokens']])
     d = pkg.dist
     L, win = kw['n_levels'], kw['win']
-    halo = d.receptive_field(L, win, kw['fusion_layers'])
+    arch = d.arch_of(model)                           # layer counts of THIS model: the halos are functions of them
+    halo = d.receptive_field(L, win, **arch)
     # queries first, clips second (dist.shard_plan_2d): with NQ = 1 this is the pure T-shard of BASELINE configs[3]
     # ... and the clip axis itself with the pyramid cut at a level k where that computes fewer rows (dist.hybrid_plan; --no-hybrid: windows only)
-    harch = None if args.no_hybrid else dict(fusion_layers=kw['fusion_layers'], n_embd_convs=2, n_stem=0, head_layers=2)
+    harch = None if args.no_hybrid else arch
     grid = d.shard_plan_2d(T, world, nq, L, win, halo, hybrid_arch=harch)
     hyb = grid.get('hybrid')
     groups = d.make_grid_groups(grid['t_shards'], grid['q_groups']) if dist is not None else None

@@ -18,6 +18,8 @@
 #include <algorithm>
 #include <cstring>
 #include <string>
+#include <atomic>
+#include <mutex>
 #include <unordered_map>
 #include <vector>
 
@@ -52,7 +54,15 @@ static std::unordered_map<std::string, int>& debug_options() {
   static std::unordered_map<std::string, int> o;
   return o;
 }
+static std::mutex& debug_options_mutex() {
+  static std::mutex mu;
+  return mu;
+}
+// bumped by every dcf_debug_set_option: a model whose captured graphs were recorded under another epoch drops them (the options
+// choose kernels, a replay would keep running the old choice)
+static std::atomic<int> g_option_epoch{0};
 static int debug_option(const char* name, int dflt) {
+  std::lock_guard<std::mutex> lock(debug_options_mutex());
   auto& o = debug_options();
   auto it = o.find(name);
   return it == o.end() ? dflt : it->second;
@@ -219,6 +229,7 @@ struct dcf_model {
   int gemm_terms = 16;                       // 16: f16x3 split MFMA GEMM (default); 6: bf16x6; 0: native fp32 MFMA
   bool force_x6 = false;                     // a weight did not fit the scaled fp16 range: the model runs bf16x6
   bool no_ln_carry = false;                  // dcf_model_set_ln_carry(m, 0): every LayerNorm as its own two-pass launch
+  int option_epoch = 0;                      // g_option_epoch the captured graphs were recorded under
   unsigned* status = nullptr;                // device words: [0] sticky numerics flag of the f16x3 GEMMs, [1] weight range flag
   bool finalized = false;
   const float* pe = nullptr;
@@ -2081,6 +2092,8 @@ static int forward_maybe_graph(dcf_model* m, const VideoSet& vs, int T0, int nq,
                                const float* const* text, const uint8_t* const* text_mask, const int32_t* text_len,
                                const float* gate, float* lo, float* oo, uint8_t* mo, hipStream_t st) {
   static const bool no_graph = getenv("DCF_NO_GRAPH") != nullptr;
+  if (m->hyb) m->hyb->valid = false;              // whatever way this forward is issued (a graph replay does not pass through forward())
+  if (m->option_epoch != g_option_epoch.load()) { drop_graph(m); m->option_epoch = g_option_epoch.load(); }
   // Auto: replay a graph only for forwards of >= 64 K level-0 rows.  Measured on MI355X (profiles/r03_notes.md): the batched
   // forward runs at the same speed either way (25.36 vs 25.35 ms per 24-video step) and the graph shields it from host
   // jitter; ONE video per call (~100 launches of 5 - 40 us) is 5 % faster launched eagerly (1.75 vs 1.84 ms: a graph node
@@ -2302,8 +2315,12 @@ int dcf_debug_set_option(const char* name, int32_t value) {
   bool ok = false;
   for (const char* k : known) ok = ok || strcmp(k, name) == 0;
   DCF_CHECK(ok, "dcf_debug_set_option: unknown option '%s'", name);
-  if (value < 0) dcf::debug_options().erase(name);           // back to the built-in value
-  else dcf::debug_options()[name] = value;
+  {
+    std::lock_guard<std::mutex> lock(dcf::debug_options_mutex());
+    if (value < 0) dcf::debug_options().erase(name);           // back to the built-in value
+    else dcf::debug_options()[name] = value;
+  }
+  dcf::g_option_epoch.fetch_add(1);                         // every model drops its captured graphs at its next forward
   return 0;
 }
 

@@ -110,7 +110,7 @@ def shard_plan_2d(T: int, world: int, nq: int, n_levels: int, win: int, halo: in
     T = 65 536), NQ = 1 is the pure T-shard (1.625x).  Returns the dict of the plan with the smallest number of rows per rank
     (ties: fewer clip chunks):
       t_shards, q_groups, plan (``shard_plan`` of the clip axis), queries (per group: (q_lo, q_hi)), rows_factor.
-    ``hybrid_arch`` (dict of ``hybrid_halos``' layer counts, or {}): the clip axis may also be cut with the pyramid split at a level k
+    ``hybrid_arch`` (dict of ``hybrid_halos``' layer counts, all four of them: ``arch_of(model)``): the clip axis may also be cut with the pyramid split at a level k
     (``hybrid_plan``: no recomputed pyramid top, 1.12x instead of 1.56x at T = 65 536 on 8 clip chunks); the candidate then carries
     ``hybrid`` = that plan, its ``plan`` entries are (lo, hi, n_lo, n_hi) -- the NARROW window, what a caller slices its features to --
     and ``sharded_forward_2d`` runs ``hybrid_forward`` inside a clip-chunk group.
@@ -154,6 +154,9 @@ class HipBackend:
 
     def __init__(self, model):
         self.model = model
+
+    def arch(self):
+        return arch_of(self.model)
 
     def scores(self, shallow_own, text_cls):
         from . import _lib
@@ -344,12 +347,20 @@ def sharded_forward(backend, vid_w, shallow_w, mask_full, plan, rank, T, n_level
 # ---------------------------------------------------------------------------------------------
 # T-sharding WITHOUT recomputing the top of the pyramid: the pyramid cut at level k
 # ---------------------------------------------------------------------------------------------
-def hybrid_halos(n_levels: int, win: int, k: int, fusion_layers: int = 2, n_embd_convs: int = 2, n_stem: int = 0, head_layers: int = 2):
+def arch_of(model) -> dict:
+    """the layer counts the halos are functions of, read off the model the plan is for (modeling.PtTransformerEarlyFusionIterative):
+    what ``shard_plan_2d(hybrid_arch=...)``, ``hybrid_plan(**arch)`` and ``receptive_field`` take"""
+    n_embd_convs, n_stem, _ = model.vid_net.arch
+    return dict(fusion_layers=len(model.fusion.layers), n_embd_convs=int(n_embd_convs), n_stem=int(n_stem), head_layers=int(model.head_layers))
+
+
+def hybrid_halos(n_levels: int, win: int, k: int, *, fusion_layers: int, n_embd_convs: int, n_stem: int, head_layers: int):
     """(hA, hB): one-sided halo of the NARROW window in clips (levels 0..k: early fusion, embedding, the encoder up to level k, cls_head on
     the level-k grid, the refinement TCN's 2^L - 1 clips, the pooling chain down to level k, cls_head2 / reg_head) and of the COARSE window in
     level-k rows (it must cover the narrow window -- the TCN stacks the logits of every level at the narrow window's clips -- plus the
     encoder reach of levels k+1..L-1 on the level-k grid, the heads' three rows of the top level and the pooling chain), each rounded up to
-    the window alignment of its pyramid (blocks.py:216: every level a multiple of win // 2)."""
+    the window alignment of its pyramid (blocks.py:216: every level a multiple of win // 2).  The layer counts have no defaults: halos
+    computed for another architecture are too small and the sharded outputs silently wrong (``arch_of(model)``)."""
     L, hw = n_levels, win // 2
     hw1 = max(hw, 1)
     LC = L - k
@@ -387,7 +398,7 @@ def hybrid_plan(T: int, world: int, n_levels: int, win: int, k: int = None, **ar
             fits = fits and (c_hi - c_lo) <= (n_hi - n_lo)           # the coarse levels run in the narrow pyramid's scratch (dcf_hybrid_phase1)
             ranks.append(dict(lo=lo, hi=hi, n_lo=n_lo, n_hi=n_hi, c_lo=c_lo, c_hi=c_hi))
         even = sum((T // world) >> l for l in range(L))
-        return dict(k=kk, ranks=ranks, rows_factor=worst / even, fits=fits)
+        return dict(k=kk, ranks=ranks, rows_factor=worst / even, fits=fits, arch=dict(arch))
 
     if k is not None:
         p = build(k)
@@ -412,6 +423,8 @@ def hybrid_forward(backend, vid_w, shallow_w, mask_full, plan, rank, T, n_levels
     """
     k, me = plan['k'], plan['ranks'][rank]
     ranks = plan['ranks']
+    if hasattr(backend, 'arch'):                       # the halos of the plan are functions of the layer counts: they must be this model's
+        assert backend.arch() == plan['arch'], f"the plan was made for {plan['arch']}, the model has {backend.arch()}"
     lo, hi, n_lo, n_hi, c_lo, c_hi = (me[x] for x in ('lo', 'hi', 'n_lo', 'n_hi', 'c_lo', 'c_hi'))
     nq = text_cls.shape[0]
     L = n_levels

@@ -16,6 +16,7 @@ sys.path.insert(0, ROOT)
 
 KW = dict(D=32, E=32, TE=32, text_in=16, n_levels=4, win=5, n_heads=2, sn=8, sratio=0.3, msf=True, norm=True,
           max_seq_len=64, text_layers=1, text_max_len=24)
+ARCH = dict(fusion_layers=2, n_embd_convs=2, n_stem=0, head_layers=2)     # the layer counts of the models below (dist.arch_of): the plans have no defaults
 T, VID_LEN, NQ = 512, 470, 2
 
 
@@ -128,7 +129,7 @@ def _worker_hybrid(rank, world, port, outdir, k):
         torch.set_num_threads(2)
         pkg, opt, sd, inp, texts, tmasks = _setup()
         d = pkg.dist
-        plan = d.hybrid_plan(T, world, KW['n_levels'], KW['win'], k)
+        plan = d.hybrid_plan(T, world, KW['n_levels'], KW['win'], k, **ARCH)
         me = plan['ranks'][rank]
         backend = OracleHybridBackend(sd, opt.model)
         with torch.no_grad():
@@ -179,7 +180,7 @@ def _worker_2d(rank, world, port, outdir, nq, hybrid=False):
         pkg, opt, sd, inp, texts, tmasks = _setup()
         d = pkg.dist
         halo = d.receptive_field(KW['n_levels'], KW['win'])
-        grid = d.shard_plan_2d(T, world, nq, KW['n_levels'], KW['win'], halo, hybrid_arch={} if hybrid else None)
+        grid = d.shard_plan_2d(T, world, nq, KW['n_levels'], KW['win'], halo, hybrid_arch=ARCH if hybrid else None)
         assert (grid['hybrid'] is not None) == (hybrid and grid['t_shards'] > 1)
         groups = d.make_grid_groups(grid['t_shards'], grid['q_groups'])
         t = rank % grid['t_shards']
@@ -208,12 +209,12 @@ def test_shard_plan_2d_prefers_queries():
     assert d.shard_plan_2d(65536, 8, 4, 8, 9, rf)['rows_factor'] <= 1.15      # VERDICT r02 item 5's bar, met from NQ = 4 on
     # with the pyramid cut allowed inside a clip-chunk group the NQ = 1 corner meets the bar too, and the plan's
     # windows are the narrow ones
-    g1 = d.shard_plan_2d(65536, 8, 1, 8, 9, rf, hybrid_arch={})
+    g1 = d.shard_plan_2d(65536, 8, 1, 8, 9, rf, hybrid_arch=ARCH)
     assert g1['t_shards'] == 8 and g1['hybrid'] is not None and g1['hybrid']['k'] == 3 and g1['rows_factor'] <= 1.15
     assert all(p[3] - p[2] <= 8192 + 2 * 384 for p in g1['plan']) and g1['plan'][3][3] - g1['plan'][3][2] == 8960
-    g2 = d.shard_plan_2d(65536, 8, 2, 8, 9, rf, hybrid_arch={})
+    g2 = d.shard_plan_2d(65536, 8, 2, 8, 9, rf, hybrid_arch=ARCH)
     assert (g2['t_shards'], g2['q_groups']) == (4, 2) and g2['hybrid'] is not None and g2['rows_factor'] <= 1.07
-    assert d.shard_plan_2d(65536, 8, 8, 8, 9, rf, hybrid_arch={})['hybrid'] is None      # whole videos per rank: nothing to cut
+    assert d.shard_plan_2d(65536, 8, 8, 8, 9, rf, hybrid_arch=ARCH)['hybrid'] is None      # whole videos per rank: nothing to cut
 
 
 @pytest.mark.timeout(900)
@@ -302,12 +303,12 @@ def test_sharded_forward_matches_unsharded_world2():
 def test_hybrid_plan_rows():
     """the pyramid cut at level k: rows a rank computes over an even share (BASELINE config 4 sizes, one query), window alignments"""
     d = load_pkg().dist
-    p = d.hybrid_plan(65536, 8, 8, 9)
+    p = d.hybrid_plan(65536, 8, 8, 9, **ARCH)
     assert p['k'] == 3 and p['rows_factor'] <= 1.15, p['rows_factor']            # VERDICT r03 item 7's bar (the pure T-shard: 1.56)
-    assert d.hybrid_plan(65536, 4, 8, 9)['rows_factor'] <= 1.07
+    assert d.hybrid_plan(65536, 4, 8, 9, **ARCH)['rows_factor'] <= 1.07
     for world in (2, 4, 8):
         for k in (1, 2, 3, 4, 5):
-            q = d.hybrid_plan(65536, world, 8, 9, k)
+            q = d.hybrid_plan(65536, world, 8, 9, k, **ARCH)
             prev = 0
             for r in q['ranks']:
                 assert r['lo'] == prev and r['hi'] > r['lo']

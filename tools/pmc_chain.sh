@@ -3,7 +3,9 @@
 # counter group over the single-stream bench (program directly after --, counters alone with --kernel-trace) -> gpurun_out/pmc_chain.json
 # (per kernel: every counter summed over the kernel's dispatches / its dispatch count).  GPU box only.
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-/root/repo}
+[ -f "$R/bench.py" ] || { echo "no bench.py under $R"; exit 1; }
+mkdir -p "$R/gpurun_out"
 GROUPS_=("GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD"
          "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_RD"
          "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA" "MeanOccupancyPerCU LDSBankConflict")

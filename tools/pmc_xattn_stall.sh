@@ -3,7 +3,9 @@
 # tools/xattn_bench.py config2 (program directly after --, counters alone with --kernel-trace) -> gpurun_out/pmc_xattn_stall.json.
 # A group the profiler refuses is skipped (its names are listed under "refused").  GPU box only.
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-/root/repo}
+[ -f "$R/bench.py" ] || { echo "no bench.py under $R"; exit 1; }
+mkdir -p "$R/gpurun_out"
 rocprofv3 -L > $R/gpurun_out/pmc_counters_available.txt 2>&1 || true
 GROUPS_=("GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_VALU"
          "SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_LDS" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU"

@@ -51,7 +51,7 @@ def main():
     vw, sw, mw, gw = vid[0][:, w_lo:w_hi].contiguous(), sh[0][:, w_lo:w_hi].contiguous(), mask[0][w_lo:w_hi].contiguous(), gate[:, w_lo:w_hi].contiguous()
     t_win = timeit(lambda: be.forward_window(vw, sw, mw, texts, tmasks, gw, T, w_lo))
     # pyramid cut at level k: the exchanged tensors taken from one pass of every rank's phases
-    hp = d.hybrid_plan(T, world, L, win)
+    hp = d.hybrid_plan(T, world, L, win, **d.arch_of(model))
     k = hp['k']
     bes = [be] + [d.HipBackend(model.replica()) for _ in range(world - 1)]
     sl = lambda r: (vid[0][:, r['n_lo']:r['n_hi']].contiguous(), sh[0][:, r['n_lo']:r['n_hi']].contiguous(),   # noqa: E731

@@ -6,7 +6,9 @@
 # One forward of eight videos at a time on ONE stream (--videos 1 --batch 8): kernels never overlap, so the per-kernel
 # durations of the CSV are the undisturbed ones and reproduce the JSON's roofline (unlike the 3-stream default run).
 tag=${1:-r03}
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-/root/repo}
+[ -f "$R/bench.py" ] || { echo "no bench.py under $R"; exit 1; }
+mkdir -p "$R/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/solo_$tag
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/solo_$tag -- python3 $R/bench.py --videos 1 --batch 8 --steps 10 --warmup 3 --min-timed-s 0 --no-cpu-baseline --no-post > $R/gpurun_out/${tag}_bench_n1_solo.json 2> /tmp/solo_$tag.err || { tail -20 /tmp/solo_$tag.err; exit 1; }
