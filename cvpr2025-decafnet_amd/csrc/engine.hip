@@ -1448,6 +1448,10 @@ __global__ void k_hybrid_stack(const float* __restrict__ l1n, const LevelTable* 
   }
 }
 
+static int tcn_stack_env() {
+  static const int v = getenv("DCF_TCN_STACK") ? atoi(getenv("DCF_TCN_STACK")) : -1;     // developer switch: leading TCN layers per launch
+  return v;
+}
 static RefineArgs refine_args(dcf_model* m) {
   RefineArgs ra{};
   ra.w_in = m->tcn_in_w; ra.b_in = m->tcn_in_b;
@@ -1455,6 +1459,7 @@ static RefineArgs refine_args(dcf_model* m) {
   ra.host_b_pw = m->tcn_bp.data(); ra.host_ln_w = m->tcn_lnw.data(); ra.host_ln_b = m->tcn_lnb.data();
   ra.w_out = m->tcn_out_w; ra.b_out = m->tcn_out_b;
   ra.host_frag = (!m->tcn_frag.empty() && debug_option("tcn_frag", 1) != 0) ? m->tcn_frag.data() : nullptr;
+  ra.stack_layers = debug_option("tcn_stack", tcn_stack_env());          // (dcf_debug_set_option: 0 = layer by layer)
   ra.f16 = m->gemm_terms == GEMM_F16X3; ra.status = m->status;
   return ra;
 }
@@ -1885,6 +1890,8 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
       ra.host_b_pw = m->tcn_bp.data(); ra.host_ln_w = m->tcn_lnw.data(); ra.host_ln_b = m->tcn_lnb.data();
       ra.w_out = m->tcn_out_w; ra.b_out = m->tcn_out_b;
       ra.host_frag = (!m->tcn_frag.empty() && debug_option("tcn_frag", 1) != 0) ? m->tcn_frag.data() : nullptr;
+      ra.stack_layers = debug_option("tcn_stack", tcn_stack_env());          // (dcf_debug_set_option: 0 = layer by layer)
+  ra.stack_layers = debug_option("tcn_stack", tcn_stack_env());          // (dcf_debug_set_option: 0 = layer by layer)
       ra.bufA = b.tcnA; ra.bufB = b.tcnB; ra.F = b.F; ra.ldf = E + TCN_HID; ra.E = E;
       ra.B = B; ra.T0 = Tp; ra.n_levels = L; ra.n_layers = L;
       ra.f16 = m->gemm_terms == GEMM_F16X3; ra.status = m->status;
@@ -2311,7 +2318,7 @@ int dcf_graph_active(const dcf_model* m) { return m ? m->last_launch : 0; }
 
 int dcf_debug_set_option(const char* name, int32_t value) {
   DCF_CHECK(name && *name, "dcf_debug_set_option: empty name");
-  static const char* known[] = {"dec_chain_min_rows", "enc_chain_min_rows", "enc_attn_min_rows", "fuse_scores", "tcn_frag", "gate_skip"};
+  static const char* known[] = {"dec_chain_min_rows", "enc_chain_min_rows", "enc_attn_min_rows", "fuse_scores", "tcn_frag", "gate_skip", "tcn_stack"};
   bool ok = false;
   for (const char* k : known) ok = ok || strcmp(k, name) == 0;
   DCF_CHECK(ok, "dcf_debug_set_option: unknown option '%s'", name);
@@ -2891,6 +2898,7 @@ int dcf_op_tcn(dcf_model* m, const char* prefix, const float* x, const uint8_t* 
     ra.host_b_pw = m->tcn_bp.data(); ra.host_ln_w = m->tcn_lnw.data(); ra.host_ln_b = m->tcn_lnb.data();
     ra.w_out = m->tcn_out_w; ra.b_out = m->tcn_out_b;
     ra.host_frag = (!m->tcn_frag.empty() && dcf::debug_option("tcn_frag", 1) != 0) ? m->tcn_frag.data() : nullptr;
+    ra.stack_layers = dcf::debug_option("tcn_stack", tcn_stack_env());          // (dcf_debug_set_option: 0 = layer by layer)
     ra.bufA = buf; ra.bufB = buf + (size_t)B * T * TCN_HID; ra.F = Y; ra.ldf = TCN_HID; ra.E = 0;
     ra.B = B; ra.T0 = T; ra.n_levels = n_in; ra.n_layers = n_layers;
     ra.f16 = m->gemm_terms == GEMM_F16X3; ra.status = m->status;

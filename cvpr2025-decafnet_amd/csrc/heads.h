@@ -55,6 +55,8 @@ struct RefineArgs {
   int f16;                            // 1: the layers run on the matrix cores in the f16x3 arithmetic of the dense convolutions
                                       // (weights range-checked with launch_f16_weight_range), 0: fp32 on the vector ALUs
   unsigned* status;                   // f16: sticky numerics word (bit 0 raised on a non-finite intermediate), may be null
+  int stack_layers;                   // f16 with fragment images: how many leading TCN layers run as ONE launch over LDS windows (k_tcn_stack):
+                                      // -1 = default (5: dilations 1 .. 16), 0 / 1 = none, at most 5 and never the last layer
 };
 int launch_refine(const RefineArgs& a, const LevelTable& host_lt, hipStream_t st);
 // masked max-pool (k3, s2) of the 32 refined channels (columns [E, E + 32) of F) from the rows of one level to the next

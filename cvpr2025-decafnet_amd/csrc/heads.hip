@@ -741,6 +741,180 @@ __global__ __launch_bounds__(256) void k_tcn_layer_mfma(const float* __restrict_
   if (bad && status) atomicOr(status, 1u);
 }
 
+// ------------------------------------------------------------------------------------------
+// The first NL layers of the TCN (dilations 1, 2, .. 2^(NL-1)) in ONE launch.  A layer by itself is latency-bound (a dependent
+// load -> split -> MFMA -> LayerNorm chain per wave over rows of 128 bytes: 24 us per layer at 131 072 rows, 6.5 us at 16 384) and
+// reads and writes every row; here a workgroup keeps a window of TS_ROWS consecutive rows of ONE sequence in LDS (two buffers,
+// row pitch 36 floats: the 16-lane groups of a `ds_read_b128` then fall on 64 distinct banks), runs the layers on it back to
+// back -- a barrier between two layers, the arithmetic of k_tcn_layer_mfma operation for operation -- and writes the rows whose
+// whole receptive field (2^NL - 1 rows to either side) lay inside the window.  Rows outside the sequence are zero in every
+// layer (the convolutions' zero padding), rows of the window's rim come out wrong and are never written.
+// ------------------------------------------------------------------------------------------
+constexpr int TS_ROWS = 256, TS_PITCH = 36, TS_MAXL = 5;
+struct TcnStackArgs {
+  const float* X;                      // [B*T0][32] the stack's input rows
+  float* Y;                            // [B*T0][32] rows after layer NL - 1
+  const h16x8* frag[TS_MAXL];          // the layers' fragment images (launch_tcn_frag_image)
+  const float* bd[TS_MAXL]; const float* bp[TS_MAXL]; const float* lnw[TS_MAXL]; const float* lnb[TS_MAXL];
+  const uint8_t* mask;                 // [B*T0]
+  int B, T0;
+  unsigned* status;
+};
+
+template <int NL>
+__global__ __launch_bounds__(256) void k_tcn_stack(TcnStackArgs p) {
+  static_assert(NL >= 2 && NL <= TS_MAXL, "2 .. 5 layers");
+  constexpr int HALO = (1 << NL) - 1, VALID = TS_ROWS - 2 * HALO;
+  extern __shared__ __attribute__((aligned(16))) float ts_lds[];               // [2][TS_ROWS][TS_PITCH]
+  const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, h = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int per_seq = (p.T0 + VALID - 1) / VALID;
+  const int b = blockIdx.x / per_seq, tile = blockIdx.x - b * per_seq;
+  const int t_lo = tile * VALID - HALO;                                        // sequence position of window row 0
+  const int64_t seq0 = (int64_t)b * p.T0;
+  // ---- the window: TS_ROWS x 32 floats, contiguous in memory (row pitch 32 floats): 16-byte pieces in thread order
+#pragma unroll
+  for (int k = 0; k < TS_ROWS * 8 / 256; ++k) {
+    const int idx = k * 256 + tid, row = idx >> 3, c4 = idx & 7;
+    const int t = t_lo + row;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (t >= 0 && t < p.T0) v = *reinterpret_cast<const f32x4*>(p.X + (seq0 + t) * TCN_HID + 4 * c4);
+    *reinterpret_cast<f32x4*>(ts_lds + row * TS_PITCH + 4 * c4) = v;
+  }
+  // the two 32-row blocks of this wave: window rows (2 wv + kb) 32 + n
+  bool inseq[2];
+  float mk[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const int t = t_lo + (2 * wv + kb) * 32 + n;
+    inseq[kb] = t >= 0 && t < p.T0;
+    mk[kb] = (inseq[kb] && p.mask[seq0 + (inseq[kb] ? t : 0)]) ? 1.f : 0.f;
+  }
+  __syncthreads();
+  bool bad = false;
+  int cur = 0;
+  // (a rolled loop: unrolled, the compiler requests every layer's fragments up front -- 512 registers and scratch; the layer's pointers
+  // by a cascade of selects: a kernel-argument array indexed by a variable is copied to scratch)
+  auto pick = [&](auto const (&arr)[TS_MAXL], int l) __attribute__((always_inline)) {
+    auto r = arr[0];
+#pragma unroll
+    for (int k = 1; k < TS_MAXL; ++k) r = l == k ? arr[k] : r;
+    return r;
+  };
+#pragma unroll 1
+  for (int l = 0; l < NL; ++l) {
+    const int dil = 1 << l;
+    const float* in = ts_lds + cur * TS_ROWS * TS_PITCH;
+    float* out = ts_lds + (cur ^ 1) * TS_ROWS * TS_PITCH;
+    h16x8 wd_h[6], wd_l[6], wp_h[2], wp_l[2];
+    const h16x8* frag = pick(p.frag, l);
+#pragma unroll
+    for (int kc = 0; kc < 6; ++kc) { wd_h[kc] = frag[(kc * 2) * 64 + lane]; wd_l[kc] = frag[(kc * 2 + 1) * 64 + lane]; }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { wp_h[c] = frag[((6 + c) * 2) * 64 + lane]; wp_l[c] = frag[((6 + c) * 2 + 1) * 64 + lane]; }
+    f32x4 bd4[4], bp4[4], lw4[4], lb4[4];
+    chan4(pick(p.bd, l), h, bd4); chan4(pick(p.bp, l), h, bp4); chan4(pick(p.lnw, l), h, lw4); chan4(pick(p.lnb, l), h, lb4);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int i = (2 * wv + kb) * 32 + n;
+      // ---- relu(dilated k3): the three taps of the row (rows beyond the window read as zero: such a row's result is not used)
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      f32x4 xin[3][2][2];
+#pragma unroll
+      for (int tap = 0; tap < 3; ++tap) {
+        const int ii = i + (tap - 1) * dil;
+        const bool ok = ii >= 0 && ii < TS_ROWS;
+        const float* src = in + (ok ? ii : 0) * TS_PITCH + 8 * h;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + 16 * cc + 4 * u);
+            xin[tap][cc][u] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+      }
+      f32x4 res[4];                                      // residual = the row itself, in accumulator channel order
+#pragma unroll
+      for (int q = 0; q < 4; ++q) res[q] = *reinterpret_cast<const f32x4*>(in + i * TS_PITCH + 8 * q + 4 * h);
+#pragma unroll
+      for (int kc = 0; kc < 6; ++kc) {
+        const f32x4 a = xin[kc >> 1][kc & 1][0], bq = xin[kc >> 1][kc & 1][1];
+        const float x[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
+        h16x8 xh, xl;
+        split8(x, TCN_SA, xh, xl);
+        acc = mma3(wd_h[kc], wd_l[kc], xh, xl, acc);
+      }
+      float hid[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float v = acc[e] * TCN_UNSCALE + bd4[e >> 2][e & 3];
+        bad |= inseq[kb] && !(__builtin_fabsf(v) <= 3.4028234664e38f);
+        hid[e] = fmaxf(v, 0.f);
+      }
+      // ---- 1x1 conv, residual, mask
+      f32x16 acc2;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float x[8] = {hid[8 * c], hid[8 * c + 1], hid[8 * c + 2], hid[8 * c + 3], hid[8 * c + 4], hid[8 * c + 5], hid[8 * c + 6], hid[8 * c + 7]};
+        h16x8 xh, xl;
+        split8(x, TCN_SA, xh, xl);
+        acc2 = mma3(wp_h[c], wp_l[c], xh, xl, acc2);
+      }
+      float o[16], sum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float v = acc2[e] * TCN_UNSCALE + bp4[e >> 2][e & 3];
+        bad |= inseq[kb] && !(__builtin_fabsf(v) <= 3.4028234664e38f);
+        o[e] = (res[e >> 2][e & 3] + v) * mk[kb];
+        sum += o[e];
+      }
+      // ---- LayerNorm over the 32 channels of the row (lanes n and n + 32)
+      const float mean = xor32_sum(sum) * (1.0f / TCN_HID);
+      float sq = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { const float d = o[e] - mean; sq += d * d; }
+      const float rs = 1.0f / sqrtf(xor32_sum(sq) * (1.0f / TCN_HID) + 1e-5f);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = inseq[kb] ? (o[4 * q + j] - mean) * rs * lw4[q][j] + lb4[q][j] : 0.f;   // (outside the sequence: the next layer's zero padding)
+        *reinterpret_cast<f32x4*>(out + i * TS_PITCH + 8 * q + 4 * h) = y;
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // ---- the rows whose receptive field lay inside the window
+  const float* fin = ts_lds + cur * TS_ROWS * TS_PITCH;
+#pragma unroll
+  for (int k = 0; k < TS_ROWS * 8 / 256; ++k) {
+    const int idx = k * 256 + tid, row = idx >> 3, c4 = idx & 7;
+    const int t = t_lo + row;
+    if (row >= HALO && row < HALO + VALID && t < p.T0)
+      *reinterpret_cast<f32x4*>(p.Y + (seq0 + t) * TCN_HID + 4 * c4) = *reinterpret_cast<const f32x4*>(fin + row * TS_PITCH + 4 * c4);
+  }
+  if (bad && p.status) atomicOr(p.status, 1u);
+}
+
+template <int NL>
+static void launch_tcn_stack_n(const TcnStackArgs& a, hipStream_t st) {
+  constexpr int VALID = TS_ROWS - 2 * ((1 << NL) - 1);
+  const unsigned grid = (unsigned)(a.B * ((a.T0 + VALID - 1) / VALID));
+  const size_t lds = (size_t)2 * TS_ROWS * TS_PITCH * sizeof(float);
+  static bool attr_set[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tcn_stack<NL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL((k_tcn_stack<NL>), dim3(grid), dim3(256), lds, st, a);
+}
+
 // |w| * 2^8 must stay inside fp16 for the kernel above: raises *flag otherwise (checked once per model, like the GEMM weights)
 __global__ void k_f16_weight_range(const float* __restrict__ w, int n, unsigned* __restrict__ flag) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -882,7 +1056,30 @@ int launch_refine(const RefineArgs& a, const LevelTable& lt, hipStream_t st) {
   const dim3 gm((((tiles + tpw - 1) / tpw) + 3) / 4);
   bool out_done = false;
   auto fimg = [&](int i) { return a.host_frag && a.host_frag[i] ? reinterpret_cast<const h16x8*>(a.host_frag[i]) : (const h16x8*)nullptr; };
-  for (int i = 0; i < a.n_layers; ++i) {
+  // the first layers (dilations 1 .. 16: a halo of 31 rows) as one launch over LDS windows; the rest -- dilations from 32 on, whose
+  // halos would outgrow the window -- layer by layer
+  int first = 0;
+  {
+    int nl = a.stack_layers < 0 ? 5 : a.stack_layers;
+    if (nl > TS_MAXL) nl = TS_MAXL;
+    if (nl > a.n_layers - 1) nl = a.n_layers - 1;        // (the last layer carries conv_out)
+    bool have = a.f16 && nl >= 2 && a.T0 >= 1;
+    for (int i = 0; i < nl && have; ++i) have = fimg(i) != nullptr;
+    if (have) {
+      TcnStackArgs sa{};
+      sa.X = cur; sa.Y = nxt; sa.mask = a.mask_all; sa.B = a.B; sa.T0 = a.T0; sa.status = a.status;
+      for (int i = 0; i < nl; ++i) { sa.frag[i] = fimg(i); sa.bd[i] = a.host_b_dil[i]; sa.bp[i] = a.host_b_pw[i]; sa.lnw[i] = a.host_ln_w[i]; sa.lnb[i] = a.host_ln_b[i]; }
+      switch (nl) {
+        case 2: launch_tcn_stack_n<2>(sa, st); break;
+        case 3: launch_tcn_stack_n<3>(sa, st); break;
+        case 4: launch_tcn_stack_n<4>(sa, st); break;
+        default: launch_tcn_stack_n<5>(sa, st); break;
+      }
+      float* t = cur; cur = nxt; nxt = t;
+      first = nl;
+    }
+  }
+  for (int i = first; i < a.n_layers; ++i) {
     DCF_CHECK(a.host_w_dil && a.host_w_dil[i], "refine: missing TCN layer %d", i);
     if (a.f16) {
       if (i + 1 < a.n_layers) {

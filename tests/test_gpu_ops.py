@@ -788,6 +788,27 @@ def test_tcn_golden(L):
     finally:
         pkg._lib.check(lib.dcf_debug_set_option(b'tcn_frag', -1))
     assert torch.equal(outs[0], outs[1])
+    # the leading layers as ONE launch over LDS windows (k_tcn_stack; the fixture has 4 layers: 3 are stacked, the last carries conv_out)
+    # against the layer-by-layer launches: the same arithmetic, the same bits -- on the fixture and on longer, ragged sequences
+    # (several windows per sequence, a sequence end inside a window, masked rows)
+    try:
+        pkg._lib.check(lib.dcf_debug_set_option(b'tcn_stack', 0))
+        Y0 = torch.empty(bs * T, 32, device='cuda')
+        pkg._lib.check(lib.dcf_op_tcn(h, b'r', P(tok(x)), P(mask.reshape(-1).contiguous().cuda()), bs, T, n_in, 4, P(Y0), st()), 'dcf_op_tcn')
+        assert torch.equal(Y0, outs[0])
+        g = torch.Generator().manual_seed(4)
+        for bs2, T2 in ((3, 1000), (2, 4096), (1, 37)):
+            x2 = torch.randn(bs2 * T2, n_in, generator=g).cuda()
+            m2 = (torch.rand(bs2 * T2, generator=g) > 0.15).to(torch.uint8).cuda()
+            got = []
+            for nl in (0, 2, 3):
+                pkg._lib.check(lib.dcf_debug_set_option(b'tcn_stack', nl))
+                Y2 = torch.empty(bs2 * T2, 32, device='cuda')
+                pkg._lib.check(lib.dcf_op_tcn(h, b'r', P(x2), P(m2), bs2, T2, n_in, 4, P(Y2), st()), 'dcf_op_tcn')
+                got.append(Y2.clone())
+            assert torch.equal(got[0], got[1]) and torch.equal(got[0], got[2]), (bs2, T2)
+    finally:
+        pkg._lib.check(lib.dcf_debug_set_option(b'tcn_stack', -1))
     lib.dcf_model_destroy(h)
 
 
