@@ -33,7 +33,8 @@ template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ int dpp_zero_i(int v) {
   return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
 }
-__device__ __forceinline__ int block_exscan(int v, int* s_wave /* [NW+1] */, int& total) {
+template <int NWV = NW>
+__device__ __forceinline__ int block_exscan(int v, int* s_wave /* [NWV+1] */, int& total) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   int inc = v;
   inc += dpp_zero_i<0x111>(inc);                     // row_shr:1
@@ -47,7 +48,7 @@ __device__ __forceinline__ int block_exscan(int v, int* s_wave /* [NW+1] */, int
   __syncthreads();
   int before = 0, tot = 0;
 #pragma unroll
-  for (int i = 0; i < NW; ++i) { const int t = s_wave[i]; tot += t; before += i < w ? t : 0; }
+  for (int i = 0; i < NWV; ++i) { const int t = s_wave[i]; tot += t; before += i < w ? t : 0; }
   total = tot;
   return before + inc - v;
 }
@@ -661,15 +662,34 @@ __device__ __forceinline__ MaxPos better(MaxPos a, MaxPos b) {
   return a;
 }
 
+// the wave's best (value, position) in every lane: the DPP steps of wave_max (common.h) on the pair
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ MaxPos dpp_mp(MaxPos a) {
+  return MaxPos{dpp_self<CTRL, ROW_MASK>(a.v), __builtin_amdgcn_update_dpp(a.pos, a.pos, CTRL, ROW_MASK, 0xf, false)};
+}
+__device__ __forceinline__ MaxPos wave_best(MaxPos b) {
+  b = better(b, dpp_mp<DPP_XOR1>(b));
+  b = better(b, dpp_mp<DPP_XOR2>(b));
+  b = better(b, dpp_mp<DPP_HALF_MIRROR>(b));
+  b = better(b, dpp_mp<DPP_MIRROR>(b));
+  b = better(b, dpp_mp<DPP_BCAST15, 0xA>(b));
+  b = better(b, dpp_mp<DPP_BCAST31, 0xC>(b));
+  return MaxPos{__int_as_float(__builtin_amdgcn_readlane(__float_as_int(b.v), 63)), __builtin_amdgcn_readlane(b.pos, 63)};
+}
+
+#ifndef DCF_SOFTNMS_THREADS
+#define DCF_SOFTNMS_THREADS 256
+#endif
+constexpr int SNT = DCF_SOFTNMS_THREADS, SNW = SNT / 64;      // soft NMS: a pick is four barriers and a handful of LDS round trips -- four waves synchronise faster than sixteen
 template <bool BIG>
-__global__ __launch_bounds__(NT) void k_softnms(SoftNmsArgs p, unsigned char* scratch, size_t scratch_per_q) {
+__global__ __launch_bounds__(SNT) void k_softnms(SoftNmsArgs p, unsigned char* scratch, size_t scratch_per_q) {
   __shared__ float s_x1[BIG ? 1 : NMS_CAP], s_x2[BIG ? 1 : NMS_CAP], s_sc[BIG ? 1 : NMS_CAP], s_ar[BIG ? 1 : NMS_CAP];
   __shared__ int s_ind[BIG ? 1 : NMS_CAP];
   __shared__ int s_slot[BIG ? 1 : NMS_CAP];
-  __shared__ int s_wave[NW + 1];
-  __shared__ float s_v[NW];
-  __shared__ int s_p[NW];
-  __shared__ int s_maxpos;
+  __shared__ int s_wave[SNW + 1];
+  __shared__ float s_v[SNW];
+  __shared__ int s_p[SNW];
+  __shared__ int s_dead, s_cnt;
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int n = p.counts ? min(p.counts[q], p.n_max) : p.n_max;
   const float* segs = p.segs + (size_t)q * p.stride * 2;
@@ -687,7 +707,7 @@ __global__ __launch_bounds__(NT) void k_softnms(SoftNmsArgs p, unsigned char* sc
   } else {
     x1 = s_x1; x2 = s_x2; sc = s_sc; ar = s_ar; ind = s_ind; slot = s_slot;
   }
-  for (int i = tid; i < n; i += NT) {
+  for (int i = tid; i < n; i += SNT) {
     const float l = segs[2 * i], r = segs[2 * i + 1];
     x1[i] = l; x2[i] = r; sc[i] = scores[i]; ar[i] = (r - l) + 1e-6f; ind[i] = i;
   }
@@ -695,38 +715,62 @@ __global__ __launch_bounds__(NT) void k_softnms(SoftNmsArgs p, unsigned char* sc
   int nsegs = n;
   const int iters = p.max_iters > 0 ? p.max_iters : n;
   int i = 0;
+  // Four barriers per pick (it was five, with a twelve-step ds_bpermute butterfly, a one-thread section and the exp in four waves of five):
+  //   [A] the waves' best (score, position) -- a DPP reduction per wave -- are in LDS; EVERY thread reduces the SNW partials, so all know
+  //       the pick `mp`; every thread reads the picked segment (slot mp) and the one it changes places with (slot i);
+  //   [B] thread 0 writes the swap and the detection, the others look at the segments behind i -- the thread that meets position mp works on
+  //       the values of slot i it read before [B] (the slot's content after the swap) -- and list those the pick overlaps;
+  //   [B2] the listed segments are decayed; s_dead is raised if a score fell below min_score;
+  //   [C] the scores are in place for the next pick; s_dead decides (uniformly) whether the pruning pass runs.
   for (; i < nsegs && i < iters; ++i) {
     // ---- argmax over [i, nsegs)
     MaxPos best{0.f, -1};
-    for (int pos = i + tid; pos < nsegs; pos += NT) best = better(best, MaxPos{sc[pos], pos});
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      MaxPos o{__shfl_xor(best.v, off, 64), __shfl_xor(best.pos, off, 64)};
-      best = better(best, o);
-    }
+    for (int pos = i + tid; pos < nsegs; pos += SNT) best = better(best, MaxPos{sc[pos], pos});
+    best = wave_best(best);
     if (lane == 0) { s_v[w] = best.v; s_p[w] = best.pos; }
-    __syncthreads();
+    __syncthreads();                                                                      // [A]
+    MaxPos bb{s_v[0], s_p[0]};
+#pragma unroll
+    for (int k = 1; k < SNW; ++k) bb = better(bb, MaxPos{s_v[k], s_p[k]});
+    const int mp = bb.pos;
+    // the pick (slot mp) and the segment that moves into its slot (slot i): nms_cpu.cpp:115-133
+    const float ix1 = x1[mp], ix2 = x2[mp], isc = sc[mp], ia = ar[mp];
+    const int iind = ind[mp];
+    const float ox1 = x1[i], ox2 = x2[i], osc = sc[i], oar = ar[i];
+    const int oind = ind[i];
+    if (tid == 0) { s_dead = 0; s_cnt = 0; }
+    __syncthreads();                                                                      // [B]
     if (tid == 0) {
-      MaxPos b{s_v[0], s_p[0]};
-      for (int k = 1; k < NW; ++k) b = better(b, MaxPos{s_v[k], s_p[k]});
-      const int mp = b.pos;
-      // swap i <-> mp and emit the detection (nms_cpu.cpp:115-133)
-      const float ix1 = x1[mp], ix2 = x2[mp], isc = sc[mp], iar = ar[mp];
-      const int iind = ind[mp];
       dets[i * 3 + 0] = ix1; dets[i * 3 + 1] = ix2; dets[i * 3 + 2] = isc;
-      x1[mp] = x1[i]; x2[mp] = x2[i]; sc[mp] = sc[i]; ar[mp] = ar[i]; ind[mp] = ind[i];
-      x1[i] = ix1; x2[i] = ix2; sc[i] = isc; ar[i] = iar; ind[i] = iind;
-      s_maxpos = mp;
+      x1[i] = ix1; x2[i] = ix2; sc[i] = isc; ar[i] = ia; ind[i] = iind;
+      if (mp != i) { x1[mp] = ox1; x2[mp] = ox2; ar[mp] = oar; ind[mp] = oind; }         // (its score: by the thread that decays position mp)
     }
-    __syncthreads();
-    const float ix1 = x1[i], ix2 = x2[i], ia = ar[i];
-    // ---- decay every later segment (nms_cpu.cpp:137-155)
+    // ---- decay every later segment (nms_cpu.cpp:137-155).  Without overlap the weight is exactly 1 -- exp(-0) for the Gaussian, below
+    // any positive threshold for the other two -- and score * 1 is the score: only the segments the pick touches need the division and
+    // the double-precision exp.  They are few (tens of 2 000) but scattered, so four of five waves would run the exp for a lane or
+    // two: their positions go to a list (`slot`, free outside the pruning pass) and ceil(count / 64) waves work it off behind [B2].
     int dead_cnt = 0;
-    for (int pos = i + 1 + tid; pos < nsegs; pos += NT) {
-      const float xx1 = fmaxf(ix1, x1[pos]);
-      const float xx2 = fminf(ix2, x2[pos]);
+    for (int pos = i + 1 + tid; pos < nsegs; pos += SNT) {
+      const bool moved = pos == mp;                      // this slot now holds what slot i held
+      const float px1 = moved ? ox1 : x1[pos], px2 = moved ? ox2 : x2[pos], psc = moved ? osc : sc[pos];
+      const float inter = fmaxf(0.f, fminf(ix2, px2) - fmaxf(ix1, px1));
+      if (inter > 0.f || (p.method != 2 && !(p.iou_thresh > 0.f))) {
+        slot[atomicAdd(&s_cnt, 1)] = pos;
+      } else {
+        if (moved) sc[pos] = psc;
+        dead_cnt += psc < p.min_score;
+      }
+    }
+    __syncthreads();                                                                      // [B2]
+    const int n_touch = s_cnt;
+    for (int k = tid; k < n_touch; k += SNT) {
+      const int pos = slot[k];
+      const bool moved = pos == mp;
+      const float px1 = moved ? ox1 : x1[pos], px2 = moved ? ox2 : x2[pos], par = moved ? oar : ar[pos], psc = moved ? osc : sc[pos];
+      const float xx1 = fmaxf(ix1, px1);
+      const float xx2 = fminf(ix2, px2);
       const float inter = fmaxf(0.f, xx2 - xx1);
-      const float ovr = inter / (ia + ar[pos] - inter);
+      const float ovr = inter / (ia + par - inter);
       float weight = 1.f;
       if (p.method == 0) { if (ovr >= p.iou_thresh) weight = 0.f; }
       else if (p.method == 1) { if (ovr >= p.iou_thresh) weight = 1.f - ovr; }
@@ -734,13 +778,15 @@ __global__ __launch_bounds__(NT) void k_softnms(SoftNmsArgs p, unsigned char* sc
         // glibc expf is correctly rounded in (almost) all cases; so is exp in double rounded to float
         weight = (float)exp((double)(-(ovr * ovr) / p.sigma));
       }
-      const float s = sc[pos] * weight;
-      sc[pos] = s;
-      dead_cnt += s < p.min_score;
+      const float s_ = psc * weight;
+      sc[pos] = s_;
+      dead_cnt += s_ < p.min_score;
     }
+    if (dead_cnt) s_dead = 1;
+    __syncthreads();                                                                      // [C]
+    if (!s_dead) continue;                               // uniform
     int n_dead;
-    block_exscan(dead_cnt, s_wave, n_dead);
-    if (n_dead == 0) continue;                        // uniform
+    block_exscan<SNW>(dead_cnt, s_wave, n_dead);
     // ---- emulate the sequential "swap with the last segment" pruning (nms_cpu.cpp:157-165):
     // survivors keep their slots; the k-th dead slot (left to right) inside the new range is
     // filled by the k-th surviving segment counted from the right end of the old range.
@@ -749,7 +795,7 @@ __global__ __launch_bounds__(NT) void k_softnms(SoftNmsArgs p, unsigned char* sc
     const int new_n = first + n_alive;
     // each thread owns a contiguous run of positions so that prefix counts are ordered
     const int span = nsegs - first;
-    const int per = (span + NT - 1) / NT;
+    const int per = (span + SNT - 1) / SNT;
     const int lo = first + tid * per, hi = min(lo + per, nsegs);
     int c_dead_left = 0, c_alive_right = 0;
     for (int pos = lo; pos < hi; ++pos) {
@@ -757,8 +803,8 @@ __global__ __launch_bounds__(NT) void k_softnms(SoftNmsArgs p, unsigned char* sc
       if (pos < new_n) c_dead_left += dead; else c_alive_right += !dead;
     }
     int tot_d, tot_a;
-    int pd = block_exscan(c_dead_left, s_wave, tot_d);
-    int pa = block_exscan(c_alive_right, s_wave, tot_a);
+    int pd = block_exscan<SNW>(c_dead_left, s_wave, tot_d);
+    int pa = block_exscan<SNW>(c_alive_right, s_wave, tot_a);
     for (int pos = lo; pos < hi; ++pos) {
       if (pos < new_n && sc[pos] < p.min_score) slot[pd++] = pos;
     }
@@ -775,7 +821,7 @@ __global__ __launch_bounds__(NT) void k_softnms(SoftNmsArgs p, unsigned char* sc
     nsegs = new_n;
   }
   const int n_out = (p.max_iters > 0) ? min(i, nsegs) : nsegs;
-  for (int k = tid; k < n_out; k += NT) out[k] = (long long)ind[k];
+  for (int k = tid; k < n_out; k += SNT) out[k] = (long long)ind[k];
   if (tid == 0) p.out_counts[q] = n_out;
 }
 
@@ -786,14 +832,14 @@ int launch_softnms(const SoftNmsArgs& a, int nq, hipStream_t st) {
   DCF_CHECK(a.stride >= a.n_max, "softnms: stride < n_max");
   ProfScope prof("softnms_1d", st, 0.0, 0.0);
   if (a.n_max <= NMS_CAP) {
-    hipLaunchKernelGGL(k_softnms<false>, dim3(nq), dim3(NT), 0, st, a, (unsigned char*)nullptr, (size_t)0);
+    hipLaunchKernelGGL(k_softnms<false>, dim3(nq), dim3(SNT), 0, st, a, (unsigned char*)nullptr, (size_t)0);
     DCF_HIP(hipGetLastError());
     return 0;
   }
   const size_t per_q = (softnms_big_scratch(a.n_max) + 255) & ~(size_t)255;
   unsigned char* scratch = nullptr;
   DCF_HIP(hipMallocAsync((void**)&scratch, per_q * nq, st));
-  hipLaunchKernelGGL(k_softnms<true>, dim3(nq), dim3(NT), 0, st, a, scratch, per_q);
+  hipLaunchKernelGGL(k_softnms<true>, dim3(nq), dim3(SNT), 0, st, a, scratch, per_q);
   const hipError_t e = hipGetLastError();
   DCF_HIP(hipFreeAsync(scratch, st));
   DCF_HIP(e);
