@@ -435,9 +435,9 @@ __global__ __launch_bounds__(256, 1) void k_ffn_chain(FfnChainArgs p) {
 // itself any more; what remains is the per-chunk synchronisation of this LDS-ring design.
 //
 // LDS: the same two 64 KiB stages (W1 chunk t | W2 chunk t - 2), ONE 4 KiB exchange buffer per pair and a word per pair that the
-// consumer sets to the iteration number once it has the buffer's content in registers; the producer writes the next content at
-// the END of its iteration, after checking that word (it practically never waits: the consumer reads the buffer first thing
-// after the barrier, some 3 000 cycles earlier).  Bias vectors behind that: 154 KiB in all.
+// consumer sets to the iteration number once it has the buffer's content in registers; the producer checks that word before it writes
+// the next content -- the first K step's half in the middle of its iteration, the second at the end (it practically never waits:
+// the consumer reads the buffer first thing after the barrier, some 1 500 cycles earlier).  Bias vectors behind that: 154 KiB in all.
 constexpr int XCH = 4096;                      // bytes of an exchange buffer: bh[0] | bh[1] | bl[0] | bl[1], 64 lanes x 16 bytes each
 constexpr int PAIR_FLAGS = 2 * STAGE + 4 * XCH;
 constexpr int PAIR_BIAS = PAIR_FLAGS + 64;
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(512, 2) void k_ffn_pair(FfnChainArgs p, int tiles) 
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = w & 3;                                             // the pair = the 32-row slice of the tile
-  const bool producer = w < 4;
+  const bool producer = w < 4;                                     // (the consumers as the older waves of their SIMDs: 423 against 392 us)
   const unsigned lane16 = (unsigned)lane * 16u;
   const int my_tiles = (tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int total_iters = my_tiles * TILE_ITERS + 2;               // the consumer runs two iterations behind the producer
@@ -586,6 +586,15 @@ __global__ __launch_bounds__(512, 2) void k_ffn_pair(FfnChainArgs p, int tiles) 
 #ifndef DCF_PAIR_NO_DMA
         if (s < 8 && ch_next >= 0) issue_piece(g + 1, ch_next, s);
 #endif
+        if constexpr (DB) {
+          if (s == 8) {
+            // the first K step's operand (hidden units of slots 0 .. 7) is complete: out it goes, half an iteration before the barrier.
+            // The consumer has had this buffer's previous content in registers since the start of the iteration (flags[j] == g).
+            while (flags[j] < g) __builtin_amdgcn_s_sleep(1);
+            *reinterpret_cast<u32x4*>(xch + 0 * 1024 + lane16) = nh[0];
+            *reinterpret_cast<u32x4*>(xch + 2 * 1024 + lane16) = nl[0];
+          }
+        }
         // the GELU of hidden unit 16 (s >> 3) + 8 h + (s & 7) of chunk i - 1
         float v, tt, ex;
         auto step_a = [&]() __attribute__((always_inline)) {             // 16 x pre-activation, t, e^{-z^2}
@@ -638,12 +647,8 @@ __global__ __launch_bounds__(512, 2) void k_ffn_pair(FfnChainArgs p, int tiles) 
 #undef DCF_PINV1M
 #undef DCF_PINV2M
       STAMP(DX ? 4 : 0);                                               // the slot loop (4: the iteration that reloads the rows)
-      if constexpr (DB) {
-        // the consumer has had this buffer's previous content in registers since the start of the iteration (flags[j] == g)
-        while (flags[j] < g) __builtin_amdgcn_s_sleep(1);
-        *reinterpret_cast<u32x4*>(xch + 0 * 1024 + lane16) = nh[0];
+      if constexpr (DB) {                                              // (the first K step's half went out behind slot 8)
         *reinterpret_cast<u32x4*>(xch + 1 * 1024 + lane16) = nh[1];
-        *reinterpret_cast<u32x4*>(xch + 2 * 1024 + lane16) = nl[0];
         *reinterpret_cast<u32x4*>(xch + 3 * 1024 + lane16) = nl[1];
       }
       STAMP(1);                                                        // handshake + exchange write
@@ -673,7 +678,7 @@ __global__ __launch_bounds__(512, 2) void k_ffn_pair(FfnChainArgs p, int tiles) 
     }
     for (int e = 0; e < 2; ++e) __builtin_amdgcn_s_barrier();          // the consumer's last product and its epilogue
 #ifdef DCF_FFN_STAMP
-    if (blockIdx.x == 0 && tid == 0)
+    if (blockIdx.x == 0 && lane == 0 && j == 0)
       for (int e = 0; e < 8; ++e) dcf_pair_stamps[e] = acc_[e];
 #endif
   } else {
@@ -849,7 +854,7 @@ __global__ __launch_bounds__(512, 2) void k_ffn_pair(FfnChainArgs p, int tiles) 
       if (++i == TILE_ITERS) { i = 0; ++tile_k; }
     }
 #ifdef DCF_FFN_STAMP
-    if (blockIdx.x == 0 && tid == 256)
+    if (blockIdx.x == 0 && lane == 0 && j == 0)
       for (int e = 0; e < 8; ++e) dcf_pair_stamps[8 + e] = acc_[e];
 #endif
   }

@@ -14,8 +14,8 @@ import sys
 
 
 def is_gemm(name):
-    # k_ffn_chain / k_head_chain: fc + proj (resp. a head's two trunk convolutions) as one kernel, profiled as gemm_f16x3<ffn_chain> / <head_chain>
-    return re.search(r'gemm_bf16s_(kslice_)?kernel<|gemm_f32_kernel<|k_ffn_chain<|k_head_chain<|k_dec_chain<|k_enc_qkv|k_enc_attn', name) is not None
+    # k_ffn_chain / k_ffn_pair / k_head_chain: fc + proj (resp. a head's two trunk convolutions) as one kernel, profiled as gemm_f16x3<ffn_chain> / <head_chain>
+    return re.search(r'gemm_bf16s_(kslice_)?kernel<|gemm_f32_kernel<|k_ffn_chain<|k_ffn_pair<|k_head_chain<|k_dec_chain<|k_enc_qkv|k_enc_attn', name) is not None
 
 
 def main():
