@@ -443,6 +443,10 @@ constexpr int PAIR_FLAGS = 2 * STAGE + 4 * XCH;
 constexpr int PAIR_BIAS = PAIR_FLAGS + 64;
 constexpr int PAIR_LDS_BYTES = PAIR_BIAS + (2 * FH + 2 * FE) * (int)sizeof(float);
 constexpr int TILE_ITERS = NCHUNK + 1;         // 33: producer iterations per row tile (32 first products + one GELU-and-reload)
+#ifndef DCF_PAIR_CSHARE
+#define DCF_PAIR_CSHARE 4
+#endif
+constexpr int PAIR_CSHARE = DCF_PAIR_CSHARE;   // W2 pieces of a stage (of a wave's eight) the consumer requests itself while it multiplies
 
 template <bool FOLD>
 __global__ __launch_bounds__(512, 2) void k_ffn_pair(FfnChainArgs p, int tiles) {
@@ -476,6 +480,14 @@ __global__ __launch_bounds__(512, 2) void k_ffn_pair(FfnChainArgs p, int tiles) 
     };
 #pragma unroll
     for (int i = 0; i < 8; ++i) issue_piece(0, 0, i);
+    // ... and, while its consumer multiplies, the last 8 - PAIR_CSHARE of that wave's eight W2 pieces: a request stalls the wave that
+    // issues it for 60 - 100 cycles; the consumer -- the younger wave of the SIMD, it gets the matrix pipe when this one does not want
+    // it -- is the one the barrier waits for (3 780 against 3 280 cycles with eight requests each), this wave has the slack
+    const unsigned short* w2_base = p.W2s + (size_t)(2 * j) * (FH / 32) * BLK;
+    auto issue_piece2 = [&](int g_next, int ch, int i) __attribute__((always_inline)) {
+      const unsigned short* src = w2_base + (size_t)ch * BLK + (size_t)(i >> 2) * (FH / 32) * BLK + (((i >> 1) & 1) * 3 + (i & 1)) * PIECE;
+      glds16(src, lane16, 32768u + (unsigned)(2 * j) * 4096u + (unsigned)(g_next & 1) * STAGE + (unsigned)i * 1024u);
+    };
 
     f16x8 xh[16], xl[16];
     // folded LayerNorm: 16 (rstd (acc U - mean s) + c) = acc r1 + (16 s) r2 + 16 c, r1 = rstd U16, r2 = - rstd mean (per row = per lane)
@@ -536,6 +548,10 @@ __global__ __launch_bounds__(512, 2) void k_ffn_pair(FfnChainArgs p, int tiles) 
                     __attribute__((always_inline)) {
       constexpr bool DA = decltype(do_a)::value, DB = decltype(do_b)::value, DX = decltype(do_x)::value;
       const unsigned char* buf = lds + (g & 1) * STAGE;
+      // what the consumer does in THIS iteration (a product: it then requests only PAIR_CSHARE of its W2 pieces) and the W2 chunk it
+      // needs in the next one (it stands at i + 1 of this tile then, or at 0 of the next tile / of the drain)
+      const bool c_prod = i >= 2 || (i == 0 && g >= TILE_ITERS);
+      const int ch2_next = (i + 1 >= 2 && i + 1 < TILE_ITERS) ? i - 1 : (i + 1 == TILE_ITERS ? NCHUNK - 1 : -1);
       f32x4 raw[32];
       float r1_n = U16, r2_n = 0.f;
       if constexpr (DX) {
@@ -585,6 +601,7 @@ __global__ __launch_bounds__(512, 2) void k_ffn_pair(FfnChainArgs p, int tiles) 
         if constexpr (DB) { if ((s & 3) == 0 && s + 4 < 16) quad((s >> 2) + 1, ((s >> 2) + 1) & 1); }
 #ifndef DCF_PAIR_NO_DMA
         if (s < 8 && ch_next >= 0) issue_piece(g + 1, ch_next, s);
+        if (s >= 8 && s < 16 - PAIR_CSHARE && c_prod && ch2_next >= 0) issue_piece2(g + 1, ch2_next, PAIR_CSHARE + s - 8);
 #endif
         if constexpr (DB) {
           if (s == 8) {
@@ -742,7 +759,7 @@ __global__ __launch_bounds__(512, 2) void k_ffn_pair(FfnChainArgs p, int tiles) 
         for (int b = 0; b < 8; ++b) {
           const int set = b & 1, m = b & 3, kk = b >> 2;
 #ifndef DCF_PAIR_NO_DMA
-          if (ch_next >= 0) issue_piece(g + 1, ch_next, b);
+          if (b < PAIR_CSHARE && ch_next >= 0) issue_piece(g + 1, ch_next, b);       // (the rest: its producer, see there)
 #endif
           if (b + 1 < 8) {
             const int mn = (b + 1) & 3, kn = (b + 1) >> 2;
