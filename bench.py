@@ -59,6 +59,9 @@ def parse():
                     help='BASELINE configs[3]: one video of this many clips, clip-chunk sharded over the ranks (0 = replicas)')
     ap.add_argument('--min-timed-s', type=float, default=2.0,
                     help='repeat the timed block of --steps steps (each block barrier + synchronise bracketed) until this much time is covered')
+    ap.add_argument('--attn-mode', default='f16x3', choices=['f16x3', 'f16'],
+                    help="attention products on the matrix cores: f16x3 (fp32 accurate, default) or f16 (one fp16 product: BASELINE configs[4]'s "
+                         "'bf16 MFMA attention'; opt-in, the line's `parity` is its delta against the fp32 oracle)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--debug-gloo-one-gpu', action='store_true',
                     help='flow check of the multi-rank path on a one-GPU box: gloo rendezvous, every rank on cuda:0 (timings meaningless)')
@@ -324,6 +327,7 @@ def main():
     kw = probe_kwargs(T)
     opt = pkg.config.make_opt(**kw)
     opt.model['max_batch'] = args.max_batch
+    opt.model['attn_mode'] = args.attn_mode
     model = pkg.modeling.create_model(opt)
     shapes = {k: list(v.shape) for k, v in model.state_dict().items()}
     sd = pkg.synth.make_state_dict(shapes, 2025)
@@ -449,6 +453,7 @@ def main():
                    'max_batch': args.max_batch, 'videos_per_step': n_videos, 'forwards_in_flight': n_lanes, 'videos_per_forward': max(1, args.batch), 'parallelism': f'replicas x{world}',
                    'launch': ' / '.join(launch_note[m_] for m_ in launch_modes) + ' (dcf_graph_active after the setup calls; DCF_NO_GRAPH=1 = eager)',
                    'csrc_sha16': csrc_hash(),
+                   'attn_mode': args.attn_mode + (' (fp32-accurate operand split)' if args.attn_mode == 'f16x3' else ' (ONE fp16 product per multiply-add in QK^T / PV: opt-in, not fp32 accurate; see parity)'),
                    # what torch.distributed saw: a SCALE run proves from this that RCCL ran with N ranks
                    'dist': ({'world_size': dist.get_world_size(), 'backend': dist.get_backend(),
                              'note': "backend 'nccl' is RCCL on ROCm; replicas only: the barrier and the MAX-reduce of the timing are its collectives"}

@@ -24,7 +24,7 @@ class DcfConfig(ctypes.Structure):
                                    'n_stem', 'n_levels', 'win', 'head_layers', 'sn')] + \
                [('sratio', f32)] + [(n, i32) for n in ('msf', 'norm', 'use_abs_pe', 'max_batch', 'gemm_mode', 'model_kind', 'second_fusion',
                                                       'text_in', 'text_layers', 'text_heads', 'text_abs_pe', 'text_bkgd',
-                                                      'scat', 'sfonly', 'text_kind', 'xattn_affine', 'vid_stride', 'pool_only')]
+                                                      'scat', 'sfonly', 'text_kind', 'xattn_affine', 'vid_stride', 'pool_only', 'attn_mode')]
 
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header

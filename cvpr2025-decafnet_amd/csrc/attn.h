@@ -16,6 +16,7 @@ struct XAttnArgs {
   // opt.model.gemm_mode is, so an operand beyond the fp16 range (|x| > 65504) or a non-finite one is reported here instead of
   // turning into inf / NaN context rows silently; nullptr = not reported
   unsigned* status;
+  int single;              // dcf_config::attn_mode 1: one fp16 product per multiply-add (hi planes only) instead of the f16x3 triple
 };
 
 struct LocalAttnArgs {

@@ -149,6 +149,7 @@ __global__ __launch_bounds__(256) void k_xattn_mfma(XAttnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const float scale = 1.0f / sqrtf(sqrtf((float)D));
+  const bool single = p.single != 0;                  // uniform: the hi planes alone (dcf_config::attn_mode 1)
 
   bool nonfinite = false;                // an operand this thread split into fp16 planes was out of range / not finite
   auto track = [&](const f32x4& x) __attribute__((always_inline)) {
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256) void k_xattn_mfma(XAttnArgs p) {
         const xh4 kh = *reinterpret_cast<const xh4*>(Kh + (16 * kt + r) * KP + 16 * c + 4 * g);
         const xh4 kl = *reinterpret_cast<const xh4*>(Kl + (16 * kt + r) * KP + 16 * c + 4 * g);
 #pragma unroll
-        for (int t = 0; t < QT; ++t) s[t][kt] = mma3(kh, kl, qh[t][c], ql[t][c], s[t][kt]);
+        for (int t = 0; t < QT; ++t) s[t][kt] = single ? __builtin_amdgcn_mfma_f32_16x16x16f16(kh, qh[t][c], s[t][kt], 0, 0, 0) : mma3(kh, kl, qh[t][c], ql[t][c], s[t][kt]);
       }
     }
     // ---- trailing keys: full fp32 dot product per row, replicated over the 4 lane groups
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256) void k_xattn_mfma(XAttnArgs p) {
         const xh4 vh = *reinterpret_cast<const xh4*>(Vh + (16 * ct + r) * VP + 16 * kt + 4 * g);
         const xh4 vl = *reinterpret_cast<const xh4*>(Vl + (16 * ct + r) * VP + 16 * kt + 4 * g);
 #pragma unroll
-        for (int t = 0; t < QT; ++t) o[t] = mma3(vh, vl, ph[t][kt], pl[t][kt], o[t]);
+        for (int t = 0; t < QT; ++t) o[t] = single ? __builtin_amdgcn_mfma_f32_16x16x16f16(vh, ph[t][kt], o[t], 0, 0, 0) : mma3(vh, vl, ph[t][kt], pl[t][kt], o[t]);
       }
 #pragma unroll
       for (int j = 0; j < REM; ++j) {

@@ -34,6 +34,7 @@ struct DecChainArgs {
   int affine;                   // fusion.xattn_mode == 'affine' (blocks.py:623-626)
   int lk2;                      // 32-key tiles of the text: 1 (Lk <= 32) or 2 (Lk <= 64)
   unsigned* status;             // sticky numerics word (GemmArgs::status)
+  int attn_single;              // dcf_config::attn_mode 1: S^T = K Q^T and O^T = V^T P^T as one fp16 product each (hi planes)
 };
 
 // true if the kernel covers this decoder shape

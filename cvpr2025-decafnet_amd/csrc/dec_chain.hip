@@ -349,10 +349,12 @@ __global__ __launch_bounds__(256, 1) void k_dec_chain(DecChainArgs p) {
         // beside the second product
         issue_piece(2 * hd + 2, 2 * ks);
         issue_piece(2 * hd + 2, 2 * ks + 1);
+        if (!p.attn_single) {                          // (uniform; dcf_config::attn_mode 1 keeps the hi x hi product alone)
 #pragma unroll
-        for (int kt = 0; kt < LK2; ++kt) S[kt] = mma(kf[set][kt][0], sl_[ks], S[kt]);
+          for (int kt = 0; kt < LK2; ++kt) S[kt] = mma(kf[set][kt][0], sl_[ks], S[kt]);
 #pragma unroll
-        for (int kt = 0; kt < LK2; ++kt) S[kt] = mma(kf[set][kt][1], sh_[ks], S[kt]);
+          for (int kt = 0; kt < LK2; ++kt) S[kt] = mma(kf[set][kt][1], sh_[ks], S[kt]);
+        }
 #pragma unroll
         for (int kt = 0; kt < LK2; ++kt) S[kt] = mma(kf[set][kt][0], sh_[ks], S[kt]);
         __builtin_amdgcn_sched_barrier(0);
@@ -408,10 +410,12 @@ __global__ __launch_bounds__(256, 1) void k_dec_chain(DecChainArgs p) {
         // (the rest of the next stage's pieces)
 #pragma unroll
         for (int i = 0; i < 8 / (2 * LK2); ++i) issue_piece(2 * hd + 2, 8 + st_ * (8 / (2 * LK2)) + i);
+        if (!p.attn_single) {
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) O[ct] = mma(vf[set][ct][0], pl[kt][q], O[ct]);
+          for (int ct = 0; ct < 2; ++ct) O[ct] = mma(vf[set][ct][0], pl[kt][q], O[ct]);
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) O[ct] = mma(vf[set][ct][1], ph[kt][q], O[ct]);
+          for (int ct = 0; ct < 2; ++ct) O[ct] = mma(vf[set][ct][1], ph[kt][q], O[ct]);
+        }
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) O[ct] = mma(vf[set][ct][0], ph[kt][q], O[ct]);
         __builtin_amdgcn_sched_barrier(0);

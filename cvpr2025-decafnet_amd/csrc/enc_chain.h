@@ -45,6 +45,7 @@ struct EncAttnArgs {
   int stats_w;
   int B, T, win;                // window size (odd, <= 9)
   unsigned* status;
+  int attn_single;              // dcf_config::attn_mode 1: the window attention's two products as one fp16 product each (hi planes)
 };
 int launch_enc_attn(const EncAttnArgs& a, hipStream_t stream);
 

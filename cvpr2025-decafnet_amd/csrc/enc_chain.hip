@@ -409,10 +409,12 @@ __global__ __launch_bounds__(256, 1) void k_enc_attn(EncAttnArgs p) {
     for (int e = 0; e < 16; ++e) { S[e] = 0.f; SH[e] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      S = mma(kl[ks], qh[ks], S);
-      SH = mma(hl[ks], qh[ks], SH);
-      S = mma(kh[ks], ql[ks], S);
-      SH = mma(hh[ks], ql[ks], SH);
+      if (!p.attn_single) {                            // (uniform; dcf_config::attn_mode 1 keeps the hi x hi product alone)
+        S = mma(kl[ks], qh[ks], S);
+        SH = mma(hl[ks], qh[ks], SH);
+        S = mma(kh[ks], ql[ks], S);
+        SH = mma(hh[ks], ql[ks], SH);
+      }
       S = mma(kh[ks], qh[ks], S);
       SH = mma(hh[ks], qh[ks], SH);
     }
@@ -470,10 +472,12 @@ __global__ __launch_bounds__(256, 1) void k_enc_attn(EncAttnArgs p) {
       for (int e = 0; e < 16; ++e) O[ct][e] = 0.f;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
+      if (!p.attn_single) {
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) O[ct] = mma(vl[ct][q], ph[q], O[ct]);
+        for (int ct = 0; ct < 2; ++ct) O[ct] = mma(vl[ct][q], ph[q], O[ct]);
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) O[ct] = mma(vh[ct][q], pl[q], O[ct]);
+        for (int ct = 0; ct < 2; ++ct) O[ct] = mma(vh[ct][q], pl[q], O[ct]);
+      }
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) O[ct] = mma(vh[ct][q], ph[q], O[ct]);
     }

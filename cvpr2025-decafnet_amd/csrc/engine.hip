@@ -1001,7 +1001,7 @@ static int run_encoder(dcf_model* m, const EncW& w, Buffers& b, const float* Xin
     EncAttnArgs aa{};
     aa.Q = b.R[4]; aa.K = b.R[5]; aa.V = b.R[6]; aa.mask = mask_out; aa.Wp = w.wp_chain; aa.bp = w.bp; aa.ls = w.ls_attn;
     if (stride == 2) { aa.R = b.R[3]; aa.ldr = E; } else { aa.R = Xin; aa.ldr = ldx; }
-    aa.Y = b.R[1]; aa.ldy = E; aa.stats_out = carry ? b.stats : nullptr; aa.stats_w = STATS_W; aa.B = B; aa.T = To; aa.win = c.win; aa.status = m->status;
+    aa.Y = b.R[1]; aa.ldy = E; aa.stats_out = carry ? b.stats : nullptr; aa.stats_w = STATS_W; aa.B = B; aa.T = To; aa.win = c.win; aa.status = m->status; aa.attn_single = c.attn_mode == 1;
     {
       ProfScope prof("gemm_f16x3<enc_attn>", st, 2.0 * rows * E * E + 4.0 * rows * E * c.win, (double)rows * E * 4.0 * 5.0);
       TRY(launch_enc_attn(aa, st));
@@ -1247,7 +1247,7 @@ static int run_fusion(dcf_model* m, Buffers& b, float* X, int64_t ldx, int B, in
       da.X = X; da.ldx = ldx; da.mask = mask; da.ln_q_w = w.ln_q_w; da.ln_q_b = w.ln_q_b; da.dw = w.dw; da.qn_w = w.qn_w; da.qn_b = w.qn_b;
       da.Wq = w.wq_chain; da.bq = w.bq; da.KV = b.kvimg; da.kmask = b.kmadd; da.Wp = w.wp_chain; da.bp = w.bp_il;
       da.Q3 = b.R[2]; da.ldq = E; da.stats_out = carry ? b.stats : nullptr; da.stats_w = STATS_W;
-      da.B = B; da.T = T; da.affine = c.xattn_affine; da.lk2 = lk2; da.status = m->status;
+      da.B = B; da.T = T; da.affine = c.xattn_affine; da.lk2 = lk2; da.status = m->status; da.attn_single = c.attn_mode == 1;
       {
         ProfScope prof("gemm_f16x3<dec_chain>", st, 2.0 * rows * E * 3.0 * E + 4.0 * rows * E * Lk, (double)rows * E * 4.0 * 2.0);
         TRY(launch_dec_chain(da, st));
@@ -1265,11 +1265,11 @@ static int run_fusion(dcf_model* m, Buffers& b, float* X, int64_t ldx, int B, in
     TRY(run_gemm(m, &gq, 1, A_ROWS, st));
     if (lt) {
       for (int l = 0; l < lt->n_levels; ++l) {
-        XAttnArgs xa{b.R[2] + (int64_t)lt->start[l] * E, b.Kt, b.Vt, b.kvmask, b.R[0] + (int64_t)lt->start[l] * E, B, lt->T[l], Lk, E, c.fusion_heads, m->status};
+        XAttnArgs xa{b.R[2] + (int64_t)lt->start[l] * E, b.Kt, b.Vt, b.kvmask, b.R[0] + (int64_t)lt->start[l] * E, B, lt->T[l], Lk, E, c.fusion_heads, m->status, c.attn_mode == 1};
         TRY(launch_xattn(xa, st));
       }
     } else {
-      XAttnArgs xa{b.R[2], b.Kt, b.Vt, b.kvmask, b.R[0], B, T, Lk, E, c.fusion_heads, m->status};
+      XAttnArgs xa{b.R[2], b.Kt, b.Vt, b.kvmask, b.R[0], B, T, Lk, E, c.fusion_heads, m->status, c.attn_mode == 1};
       TRY(launch_xattn(xa, st));
     }
     if (m->gemm_terms != 0 && w.wp_il && m->wsplit.count(w.wp_il) && gemm_can_fuse_adaln(rows, 2 * E, E)) {
@@ -1993,6 +1993,7 @@ int dcf_abi_version(void) { return 9; }
 int dcf_model_create(const dcf_config* cfg, dcf_model** out) {
   DCF_CHECK(cfg && out, "dcf_model_create: null argument");
   DCF_CHECK(cfg->E > 0 && cfg->E % 32 == 0 && cfg->E <= 992, "E=%d must be a positive multiple of 32 (<= 992)", cfg->E);
+  DCF_CHECK(cfg->attn_mode == 0 || cfg->attn_mode == 1, "attn_mode=%d: 0 (f16x3) or 1 (one fp16 product)", cfg->attn_mode);
   DCF_CHECK(cfg->D > 0 && cfg->D % 32 == 0, "D=%d must be a positive multiple of 32", cfg->D);
   DCF_CHECK(cfg->TE > 0 && cfg->TE % 32 == 0, "TE=%d must be a positive multiple of 32", cfg->TE);
   DCF_CHECK(cfg->n_levels >= 1 && cfg->n_levels <= DCF_MAX_LEVELS, "n_levels=%d out of range", cfg->n_levels);

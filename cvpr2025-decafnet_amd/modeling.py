@@ -439,6 +439,10 @@ def _encode_text(model, tokens, token_masks):
 
 
 GEMM_MODES = {'f16x3': 16, 'bf16x6': 6, 'fp32': 1}
+# arithmetic of the attention products on the matrix cores (extension key opt.model.attn_mode): 'f16x3' (default, fp32 accurate) or
+# 'f16': one fp16 product per multiply-add (opt-in, ~1e-4 on the logits; BASELINE configs[4]'s "bf16 MFMA attention" with fp16's
+# three extra bits)
+ATTN_MODES = {'f16x3': 0, 'f16': 1}
 
 
 class PtTransformerEarlyFusionIterative(nn.Module):
@@ -488,6 +492,7 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         # dense-conv arithmetic (extension key opt.model.gemm_mode), all fp32 accurate: 'f16x3' (default: two fp16 planes
         # per operand on the fp16 matrix cores), 'bf16x6' (three bf16 planes) or 'fp32' (native fp32 MFMA)
         self.gemm_mode = GEMM_MODES[mo.get('gemm_mode', 'f16x3')]
+        self.attn_mode = ATTN_MODES[mo.get('attn_mode', 'f16x3')]
         self._engine = None
         # Serving option (off by default: the reference returns fresh tensors every call).  When True the three flat
         # output buffers are reused between calls of the same shape, which lets the engine replay one captured HIP
@@ -643,6 +648,7 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         c.model_kind, c.second_fusion = self.MODEL_KIND, int(bool(self.second_fusion))
         c.xattn_affine = int(len(self.fusion.layers) > 0 and self.fusion.layers[0].xattn_mode == 'affine')
         c.vid_stride, c.pool_only = vn.stride, int(vn.pool_only)
+        c.attn_mode = getattr(self, 'attn_mode', 0)
         _text_config(c, self.text_net)
         return c
 
@@ -949,6 +955,7 @@ class PtTransformer(PtTransformerEarlyFusionIterative):
         self.head_layers = ch.get('n_layers', 2)
         self.max_batch = int(mo.get('max_batch', 0) or 0)
         self.gemm_mode = GEMM_MODES[mo.get('gemm_mode', 'f16x3')]
+        self.attn_mode = ATTN_MODES[mo.get('attn_mode', 'f16x3')]
         self._engine = None
         self.reuse_output_buffers = False
         self.ln_carry = True                        # LayerNorms carried between kernels as row statistics where the kernels allow (set_ln_carry)
@@ -988,6 +995,7 @@ class PtTransformerEarlyFusion(PtTransformerEarlyFusionIterative):
         self.head_layers = ch.get('n_layers', 2)
         self.max_batch = int(mo.get('max_batch', 0) or 0)
         self.gemm_mode = GEMM_MODES[mo.get('gemm_mode', 'f16x3')]
+        self.attn_mode = ATTN_MODES[mo.get('attn_mode', 'f16x3')]
         self._engine = None
         self.reuse_output_buffers = False
         self.ln_carry = True                        # LayerNorms carried between kernels as row statistics where the kernels allow (set_ln_carry)

@@ -75,6 +75,13 @@ typedef struct dcf_config {
                            * convolutions are k5 / stride 2 / padding 2 and the pyramid starts at T / stride.  0 reads as 1 */
   int32_t pool_only;      /* opt.model.vid_net.pool_only (video_net.py:98-111): a branch layer is one depthwise k3 MaskedConv1D
                            * (vid_net.branch.{i}.conv.weight, stride 1 at level 0, 2 above) instead of a TransformerEncoder */
+  /* ABI version 9 */
+  int32_t attn_mode;      /* arithmetic of the attention products QK^T / PV on the matrix cores (text->clip cross attention, the
+                           * fusion layers' attention half, the encoder's window attention): 0 = f16x3 (two fp16 planes per operand,
+                           * three products: the error of an fp32 FMA chain; default), 1 = ONE fp16 product per multiply-add
+                           * (11 significant bits per operand, fp32 accumulate -- what BASELINE configs[4] calls "bf16 MFMA
+                           * attention", with fp16's three extra bits; opt-in, NOT fp32-accurate: bench.py --attn-mode f16 prints
+                           * its delta against the fp32 oracle).  The projections around the products stay f16x3. */
 } dcf_config;
 
 int dcf_model_create(const dcf_config* cfg, dcf_model** out);

@@ -19,7 +19,7 @@ done
 cd $R && python3 - $i <<'PY' > gpurun_out/pmc_chain.json
 import csv, glob, json, re, sys
 csv.field_size_limit(1 << 30)
-fam = {'k_head_chain<288>': 'k_head_chain<288>', 'k_head_chain<256>': 'k_head_chain<256>', 'k_ffn_chain': 'k_ffn_chain', 'k_dec_chain': 'k_dec_chain',
+fam = {'k_head_chain<288>': 'k_head_chain<288>', 'k_head_chain<256>': 'k_head_chain<256>', 'k_ffn_chain': 'k_ffn_chain', 'k_ffn_pair': 'k_ffn_pair', 'k_dec_chain': 'k_dec_chain',
        'k_enc_qkv': 'k_enc_qkv', 'k_enc_attn': 'k_enc_attn', 'gemm_bf16s_kernel<1, 4, 4, 2, 1': 'gemm 128x256 k3', 'gemm_bf16s_kernel<1, 4, 2, 2, 2': 'gemm 64x256 channel-major'}
 out, refused = {}, []
 for i in range(int(sys.argv[1])):
