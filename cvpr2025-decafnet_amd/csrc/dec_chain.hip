@@ -96,7 +96,7 @@ __global__ void k_kv_image(const float* __restrict__ K, const float* __restrict_
 }
 
 // ---- the kernel -----------------------------------------------------------------------------------------------------------------
-template <int LK2>
+template <int LK2, bool SINGLE = false>
 __global__ __launch_bounds__(256, 1) void k_dec_chain(DecChainArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   float* ldf = reinterpret_cast<float*>(lds + 2 * STAGE);
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256, 1) void k_dec_chain(DecChainArgs p) {
         // beside the second product
         issue_piece(2 * hd + 2, 2 * ks);
         issue_piece(2 * hd + 2, 2 * ks + 1);
-        if (!p.attn_single) {                          // (uniform; dcf_config::attn_mode 1 keeps the hi x hi product alone)
+        if constexpr (!SINGLE) {                       // (dcf_config::attn_mode 1 keeps the hi x hi product alone: its own instantiation)
 #pragma unroll
           for (int kt = 0; kt < LK2; ++kt) S[kt] = mma(kf[set][kt][0], sl_[ks], S[kt]);
 #pragma unroll
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256, 1) void k_dec_chain(DecChainArgs p) {
         // (the rest of the next stage's pieces)
 #pragma unroll
         for (int i = 0; i < 8 / (2 * LK2); ++i) issue_piece(2 * hd + 2, 8 + st_ * (8 / (2 * LK2)) + i);
-        if (!p.attn_single) {
+        if constexpr (!SINGLE) {
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct) O[ct] = mma(vf[set][ct][0], pl[kt][q], O[ct]);
 #pragma unroll
@@ -553,10 +553,15 @@ int launch_dec_chain(const DecChainArgs& a, hipStream_t stream) {
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
     DCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_chain<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     DCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_chain<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    DCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_chain<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    DCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_chain<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set[dev] = true;
   }
   const unsigned grid = (unsigned)(a.B * ((a.T + WGROWS - 1) / WGROWS));
-  if (a.lk2 == 1) hipLaunchKernelGGL(k_dec_chain<1>, dim3(grid), dim3(256), LDS_BYTES, stream, a);
+  if (a.attn_single) {
+    if (a.lk2 == 1) hipLaunchKernelGGL((k_dec_chain<1, true>), dim3(grid), dim3(256), LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL((k_dec_chain<2, true>), dim3(grid), dim3(256), LDS_BYTES, stream, a);
+  } else if (a.lk2 == 1) hipLaunchKernelGGL(k_dec_chain<1>, dim3(grid), dim3(256), LDS_BYTES, stream, a);
   else hipLaunchKernelGGL(k_dec_chain<2>, dim3(grid), dim3(256), LDS_BYTES, stream, a);
   DCF_HIP(hipGetLastError());
   return 0;

@@ -280,6 +280,7 @@ __device__ unsigned long long dcf_ea_stamps[16];   // diagnostic build only (too
 #endif
 }  // namespace
 
+template <bool SINGLE>
 __global__ __launch_bounds__(256, 1) void k_enc_attn(EncAttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   float* ldf = reinterpret_cast<float*>(lds + 2 * STAGE);
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(256, 1) void k_enc_attn(EncAttnArgs p) {
     for (int e = 0; e < 16; ++e) { S[e] = 0.f; SH[e] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      if (!p.attn_single) {                            // (uniform; dcf_config::attn_mode 1 keeps the hi x hi product alone)
+      if constexpr (!SINGLE) {                         // (dcf_config::attn_mode 1 keeps the hi x hi product alone: its own instantiation)
         S = mma(kl[ks], qh[ks], S);
         SH = mma(hl[ks], qh[ks], SH);
         S = mma(kh[ks], ql[ks], S);
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(256, 1) void k_enc_attn(EncAttnArgs p) {
       for (int e = 0; e < 16; ++e) O[ct][e] = 0.f;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-      if (!p.attn_single) {
+      if constexpr (!SINGLE) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) O[ct] = mma(vl[ct][q], ph[q], O[ct]);
 #pragma unroll
@@ -610,11 +611,13 @@ int launch_enc_attn(const EncAttnArgs& a, hipStream_t stream) {
   int dev = 0;
   DCF_HIP(hipGetDevice(&dev));
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    DCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_enc_attn), hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS_BYTES));
+    DCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_enc_attn<false>), hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS_BYTES));
+    DCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_enc_attn<true>), hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS_BYTES));
     attr_set[dev] = true;
   }
   const unsigned grid = (unsigned)(a.B * ((a.T + AWG_ROWS - 1) / AWG_ROWS));
-  hipLaunchKernelGGL(k_enc_attn, dim3(grid), dim3(256), A_LDS_BYTES, stream, a);
+  if (a.attn_single) hipLaunchKernelGGL(k_enc_attn<true>, dim3(grid), dim3(256), A_LDS_BYTES, stream, a);
+  else hipLaunchKernelGGL(k_enc_attn<false>, dim3(grid), dim3(256), A_LDS_BYTES, stream, a);
   DCF_HIP(hipGetLastError());
   return 0;
 }
