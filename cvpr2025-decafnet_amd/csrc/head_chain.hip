@@ -56,11 +56,18 @@ __device__ __forceinline__ void split2_f16(float x0, float x1, float s, unsigned
 
 // one 1 KiB LDS-DMA piece (ffn_chain.hip): lane l copies the 16 bytes at sbase + voff to LDS byte lds_dst + 16 l
 __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigned lds_dst) {
+  // M0 is written and NOT restored: nothing else in these kernels reads it (gfx9+ LDS instructions do not; tools/isa_gate.py and
+  // tests/test_abi.py keep every other use of m0 out of the shipped objects).  DCF_GLDS_KEEP_M0 = the save / restore form
+  // (two more scalar instructions per request, ~2 % of a chain kernel's stage).
+#ifdef DCF_GLDS_KEEP_M0
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
                : "v"(voff), "s"(sbase), "s"(lds_dst)
                : "memory");
+#else
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+#endif
 }
 
 #ifdef DCF_HC_STAMP

@@ -4,6 +4,9 @@ fold epilogue (profiles/r04_pkfma_hazard.md); `-fno-slp-vectorize` (build.py) ke
 keeps it out whatever a future change or compiler does.  The broadcast in the other direction (`op_sel_hi:[..0..]`, the LOW dword
 into the high lane) is what the explicit f32x4 arithmetic of the kernels compiles to and is exact.
 
+Second rule (round 5): no instruction may mention M0 except `s_mov_b32 m0, sN` -- the LDS-DMA requests of the chain kernels set it and do not
+restore it, which is only sound while nothing else in the objects depends on it.
+
     python tools/isa_gate.py            # every object under cvpr2025-decafnet_amd/build/*.o; exit 1 on a hit
 """
 import glob
@@ -48,6 +51,8 @@ def scan(objs=None):
         txt = device_disassembly(o)
         packed = len(re.findall(r'v_pk_[a-z]+_f32\b', txt))
         hits = [l.strip() for l in txt.split('\n') if 'op_sel:[' in l and is_bad(l)]
+        # M0: the chain kernels' LDS-DMA requests write it and do not restore it (glds16), so nothing else may read or expect it
+        hits += [l.strip() for l in txt.split('\n') if re.search(r'\bm0\b', l) and not re.search(r's_mov_b32\s+m0,\s*s\d+', l)]
         report[os.path.relpath(o, ROOT)] = (packed, hits)
     return report
 
