@@ -144,6 +144,19 @@ __global__ __launch_bounds__(256) void k_xattn_mfma(XAttnArgs p) {
   float* Kr = reinterpret_cast<float*>(Vl + D * VP);         // [REM][D]    trailing keys, fp32 (vector-ALU path), pre-scaled
   float* Vr = Kr + (REM > 0 ? REM : 1) * D;                  // [REM][D]
   float* Ms = Vr + (REM > 0 ? REM : 1) * D;                  // [KT16 + REM] additive key mask (0 / -inf)
+  // Context rows leave through LDS where a head's slice of a row is at least two cache lines (d = 64 / 128): a lane's 16-byte piece
+  // of 16 different rows per store instruction (64 bytes per row: half a line, the other half by the next instruction) became whole
+  // rows per instruction.  tools/micro/qstream.hip, the kernel's grid and maps with no arithmetic at all: 56.9 us with the direct
+  // stores, 53.9 us with whole-row stores (4.71 -> 4.98 TB/s at BASELINE config 2); the same change on the LOAD side changes nothing.
+  // Per wave 16 rows x CH 16-byte chunks; chunk k of row r sits at slot (k + 2 (r % 8)) % CH of its row, so that the eight lanes
+  // an LDS cycle serves (rows r .. r + 7, same chunk) hit eight different bank groups.
+#ifdef DCF_XATTN_DIRECT_STORE        // (A/B builds of tools/: the direct 16-byte stores)
+  constexpr bool OSTAGE = false;
+#else
+  constexpr bool OSTAGE = D16 == 4 || D16 == 8;
+#endif
+  constexpr int CH = 4 * D16;                                // 16-byte chunks per row
+  unsigned char* Os = reinterpret_cast<unsigned char*>(Ms + ((KT16 + REM + 3) & ~3));   // [4 waves][16 rows][D] fp32, QT = 1
   const int C = p.C, Lk = p.Lk;
   const int head = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -156,6 +169,26 @@ __global__ __launch_bounds__(256) void k_xattn_mfma(XAttnArgs p) {
     const float m4 = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w)));
     nonfinite |= !(m4 <= 65504.f);       // also true for NaN
   };
+  constexpr int ROWS = 64 * QT;        // clip rows per workgroup iteration
+  const int n_groups = (p.T + ROWS - 1) / ROWS;
+  // Q fragments are fetched TWO row groups ahead (two statically indexed register sets, the loop is unrolled by two): a wave
+  // has nothing but its own requests in flight to cover the HBM latency with.
+  constexpr int QA = 2;                 // row groups of q in flight per wave (3: no faster, 12 more registers)
+  f32x4 qn_[QA][QT][D16];
+  auto fetch_q = [&](int grp, f32x4 (&qn)[QT][D16]) __attribute__((always_inline)) {
+    if (grp >= n_groups) return;
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      int tt = grp * ROWS + (wave * QT + t) * 16 + r;
+      tt = tt < p.T ? tt : p.T - 1;
+      const float* qp = p.Q + ((int64_t)b * p.T + tt) * C + (size_t)head * D + 4 * g;
+#pragma unroll
+      for (int c = 0; c < D16; ++c) qn[t][c] = *reinterpret_cast<const f32x4*>(qp + 16 * c);
+    }
+  };
+  // the first row groups' q are requested BEFORE the K / V staging: the staging's own round trips then overlap them
+#pragma unroll
+  for (int a = 0; a < QA; ++a) fetch_q(blockIdx.x + a * gridDim.x, qn_[a]);
   for (int i = tid; i < (KT16 + REM) * (D / 4); i += 256) {
     const int key = i / (D / 4), c4 = i % (D / 4);
     f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
@@ -181,23 +214,6 @@ __global__ __launch_bounds__(256) void k_xattn_mfma(XAttnArgs p) {
   for (int i = tid; i < KT16 + REM; i += 256) Ms[i] = (i < Lk && p.kvmask[(size_t)b * Lk + i]) ? 0.f : -INFINITY;
   __syncthreads();
 
-  constexpr int ROWS = 64 * QT;        // clip rows per workgroup iteration
-  const int n_groups = (p.T + ROWS - 1) / ROWS;
-  // Q fragments are fetched TWO row groups ahead (two statically indexed register sets, the loop is unrolled by two): a wave
-  // has nothing but its own requests in flight to cover the HBM latency with.
-  constexpr int QA = 2;                 // row groups of q in flight per wave (3: no faster, 12 more registers)
-  f32x4 qn_[QA][QT][D16];
-  auto fetch_q = [&](int grp, f32x4 (&qn)[QT][D16]) __attribute__((always_inline)) {
-    if (grp >= n_groups) return;
-#pragma unroll
-    for (int t = 0; t < QT; ++t) {
-      int tt = grp * ROWS + (wave * QT + t) * 16 + r;
-      tt = tt < p.T ? tt : p.T - 1;
-      const float* qp = p.Q + ((int64_t)b * p.T + tt) * C + (size_t)head * D + 4 * g;
-#pragma unroll
-      for (int c = 0; c < D16; ++c) qn[t][c] = *reinterpret_cast<const f32x4*>(qp + 16 * c);
-    }
-  };
   auto process = [&](int grp, f32x4 (&qn)[QT][D16]) __attribute__((always_inline)) {
     // ---- Q fragments: q[t][c] = Q[row_t][head*D + 16c + 4g .. +3], scaled, as two fp16 planes
     f32x4 q[QT][D16];
@@ -301,13 +317,26 @@ __global__ __launch_bounds__(256) void k_xattn_mfma(XAttnArgs p) {
 #pragma unroll
         for (int t = 0; t < QT; ++t) o[t] += sr[t][j] * vr;
       }
+      if constexpr (OSTAGE) {
+        static_assert(!OSTAGE || QT == 1, "staged context stores: one row tile per wave");
+        *reinterpret_cast<f32x4*>(Os + ((wave * 16 + r) * CH + ((4 * ct + g + 2 * (r & 7)) & (CH - 1))) * 16) = o[0];
+      } else {
 #pragma unroll
-      for (int t = 0; t < QT; ++t)
-        if (live[t]) *reinterpret_cast<f32x4*>(p.O + row[t] * C + (size_t)head * D + 4 * g + 16 * ct) = o[t];
+        for (int t = 0; t < QT; ++t)
+          if (live[t]) *reinterpret_cast<f32x4*>(p.O + row[t] * C + (size_t)head * D + 4 * g + 16 * ct) = o[t];
+      }
+    }
+    if constexpr (OSTAGE) {
+      // whole rows per store instruction: lane l of instruction i takes the 16 bytes at (64 i + l) * 16 of the wave's tile
+      const int t0 = grp * ROWS + wave * 16;
+#pragma unroll
+      for (int i = 0; i < D16; ++i) {
+        const int pos = 64 * i + lane, rr = pos / CH, sl = pos & (CH - 1), kc = (sl - 2 * (rr & 7)) & (CH - 1);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Os + (wave * 16 * CH + pos) * 16);
+        if (t0 + rr < p.T) *reinterpret_cast<f32x4*>(p.O + ((int64_t)b * p.T + t0 + rr) * C + (size_t)head * D + 4 * kc) = v;
+      }
     }
   };
-#pragma unroll
-  for (int a = 0; a < QA; ++a) fetch_q(blockIdx.x + a * gridDim.x, qn_[a]);
   for (int grp = blockIdx.x; grp < n_groups; grp += QA * gridDim.x) {
 #pragma unroll
     for (int a = 0; a < QA; ++a)
@@ -476,7 +505,9 @@ static int launch_xattn_mfma(const XAttnArgs& a, hipStream_t st) {
   // context stores 72 us; heads as the fastest grid index 66 us)
   constexpr int QT = D16 <= 2 ? 2 : 1;
   // two fp16 planes of K [16 nkt][D + 4] and of V^T [D][16 nkt + 4], fp32 rows of the trailing keys (K and V), the key mask
-  const size_t lds = (size_t)2 * 2 * (16 * nkt * (D + 4) + D * (16 * nkt + 4)) + ((size_t)2 * (rem > 0 ? rem : 1) * D + 16 * nkt + rem) * sizeof(float);
+  // (+ the staged context tile of the d = 64 / 128 instantiations: [4 waves][16 rows][D] fp32 behind the mask, 16-byte aligned)
+  const size_t lds = (size_t)2 * 2 * (16 * nkt * (D + 4) + D * (16 * nkt + 4)) + ((size_t)2 * (rem > 0 ? rem : 1) * D + ((16 * nkt + rem + 3) & ~3)) * sizeof(float) +
+                     ((D16 == 4 || D16 == 8) ? (size_t)4 * 16 * D * sizeof(float) : 0);
 #define XL(NKT_, REM_) hipLaunchKernelGGL((k_xattn_mfma<D16, NKT_, REM_, QT>), grid, dim3(256), lds, st, a)
   switch (nkt * 4 + rem) {
     case 0 * 4 + 1: XL(0, 1); break;
