@@ -557,6 +557,19 @@ def main():
                                        'frac': x['cold']['GBps'] / PEAK_HBM_GBS, 'warm_GBps': x['warm']['GBps'],
                                        'us_per_launch': x['cold']['us'], 'alg_bytes_per_clip': 8 * 1024,
                                        'workload': 'T=4096 E=1024 heads=16 Lk=33, 8 queries/launch, f16x3 split on MFMA 16x16x16 f16'}
+        if extras:
+            # the matrix rate this device sustains (bare MFMA loops on every CU): what a kernel that never idled its matrix pipes would reach
+            import ctypes as _ct
+            ncu, ns32, ns16 = _ct.c_int32(0), _ct.c_float(0.), _ct.c_float(0.)
+            pkg._lib.check(pkg._lib.lib().dcf_calib_mfma_rate(0, 1 << 15, _ct.byref(ncu), _ct.byref(ns32)))
+            pkg._lib.check(pkg._lib.lib().dcf_calib_mfma_rate(1, 1 << 16, _ct.byref(ncu), _ct.byref(ns16)))
+            dense = ncu.value * 4 * 2.0 * 32 * 32 * 16 / (ns32.value * 1e-9) / 1e12          # fp16 TFLOP/s, 32x32x16
+            result['mfma_sustained'] = {
+                'ns_per_mfma_32x32x16': ns32.value, 'ns_per_mfma_16x16x32': ns16.value, 'cus': ncu.value,
+                'clock_GHz_under_load': 32.0 / ns32.value, 'dense_f16_tflops': dense, 'f16x3_tflops': dense / 3.0,
+                'frac_of_sustained': result['roofline']['achieved'] / (dense / 3.0),
+                'note': 'dcf_calib_mfma_rate: bare v_mfma_f32_32x32x16_f16 loops, one wave per SIMD on every CU, right after the timed steps; '
+                        'frac_of_sustained = roofline.achieved / (that rate / 3 products); roofline.peak stays the nominal 2500 / 3'}
         result['stages'] = stages
         result['event_ms_per_step'] = tot_ms / args.steps
 
@@ -744,6 +757,8 @@ def main():
         chk = {}
         if 'xattn_config2' in result:
             chk['xattn_config2'] = {k: result['xattn_config2'][k] for k in ('frac', 'us_per_launch', 'achieved', 'unit')}
+        if 'mfma_sustained' in result:
+            chk['mfma_sustained'] = {k: result['mfma_sustained'][k] for k in ('clock_GHz_under_load', 'f16x3_tflops', 'frac_of_sustained')}
         if 'hbm_budget' in result:
             chk['hbm_bytes_per_clip'] = result['hbm_budget']['bytes_per_clip']
         if 'one_video_per_call' in result:

@@ -60,6 +60,7 @@ SIGNATURES = {
     'dcf_debug_copy': (i32, [vp, i32, c_f32p, i64, vp]),
     'dcf_graph_active': (i32, [vp]),
     'dcf_debug_set_option': (i32, [ctypes.c_char_p, i32]),
+    'dcf_calib_mfma_rate': (i32, [i32, i32, ctypes.POINTER(i32), ctypes.POINTER(f32)]),
     'dcf_model_set_graph_mode': (i32, [vp, i32]),
     'dcf_model_set_ln_carry': (i32, [vp, i32]),
     'dcf_profile_enable': (i32, [i32]),

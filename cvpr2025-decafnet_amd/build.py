@@ -16,7 +16,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libdecafnet_hip.so')
-SOURCES = ['engine.hip', 'gemm.hip', 'gemm_bf16s.hip', 'ffn_chain.hip', 'head_chain.hip', 'dec_chain.hip', 'enc_chain.hip', 'rowops.hip', 'attn.hip', 'score.hip', 'heads.hip', 'postproc.hip', 'loss.hip']
+SOURCES = ['engine.hip', 'gemm.hip', 'gemm_bf16s.hip', 'ffn_chain.hip', 'head_chain.hip', 'dec_chain.hip', 'enc_chain.hip', 'rowops.hip', 'attn.hip', 'score.hip', 'heads.hip', 'postproc.hip', 'loss.hip', 'calib.hip']
 ARCH = 'gfx950'
 FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
 

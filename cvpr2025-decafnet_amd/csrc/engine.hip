@@ -1988,7 +1988,7 @@ static int text_encode(dcf_model* m, const float* tokens, const uint8_t* token_m
 extern "C" {
 
 const char* dcf_last_error(void) { return dcf::g_err.c_str(); }
-int dcf_abi_version(void) { return 9; }
+int dcf_abi_version(void) { return 10; }
 
 int dcf_model_create(const dcf_config* cfg, dcf_model** out) {
   DCF_CHECK(cfg && out, "dcf_model_create: null argument");

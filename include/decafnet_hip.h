@@ -238,6 +238,13 @@ int dcf_model_set_graph_mode(dcf_model* m, int32_t mode);
  * per-model image).  value < 0 restores the built-in value.  Not a reference interface; results do not depend on it beyond
  * rounding.  ABI version 6 (the last two names: 8). */
 int dcf_debug_set_option(const char* name, int32_t value);
+/* Measurement aid (not a reference interface): the matrix rate THIS device sustains.  Runs bare fp16 MFMA loops (shape 0:
+ * v_mfma_f32_32x32x16_f16, shape 1: v_mfma_f32_16x16x32_f16; operands in registers, one wave per SIMD, one workgroup per CU,
+ * mfmas_per_wave MFMAs per wave, a few launches back to back on the NULL stream, synchronous) and returns the CU count and the
+ * nanoseconds one MFMA occupies a SIMD for.  Nominal: 32 (16) cycles at 2.4 GHz = 13.3 (6.7) ns; under load the part holds
+ * 1.5 - 1.75 GHz, which bounds every kernel of the dense family below ~0.7 of the nominal peak the roofline prices against.
+ * bench.py reports it as roofline.checks.mfma_sustained.  ABI version 10. */
+int dcf_calib_mfma_rate(int32_t shape, int32_t mfmas_per_wave, int32_t* n_cus, float* ns_per_mfma);
 
 /* --------------------------------------------------------------------------------------------
  * Proposal decoding: replaces Evaluator._collect_segments (libs/worker_v2.py:1131-1187).

@@ -1112,3 +1112,18 @@ def test_collect_with_ext_scores(L):
         assert n == len(wc)
         torch.testing.assert_close(scores[q, :n].cpu(), wc, rtol=1e-6, atol=1e-7)
         torch.testing.assert_close(segs[q, :n].cpu(), ws, rtol=1e-6, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_mfma_rate_calibration_is_sane(L):
+    """dcf_calib_mfma_rate (bench.py's roofline.checks.mfma_sustained): one 32x32x16 MFMA occupies a SIMD for 32 cycles, i.e. 13.3 ns at
+    the nominal 2.4 GHz and never less; under load the part holds 1.4 - 2.4 GHz.  The 16x16x32 shape is half of that."""
+    import ctypes
+    pkg, lib = L
+    ncu, ns32, ns16 = ctypes.c_int32(0), ctypes.c_float(0.), ctypes.c_float(0.)
+    pkg._lib.check(lib.dcf_calib_mfma_rate(0, 1 << 14, ctypes.byref(ncu), ctypes.byref(ns32)))
+    pkg._lib.check(lib.dcf_calib_mfma_rate(1, 1 << 15, ctypes.byref(ncu), ctypes.byref(ns16)))
+    assert ncu.value >= 64
+    assert 32 / 2.6 <= ns32.value <= 32 / 1.0, ns32.value
+    assert 16 / 2.6 <= ns16.value <= 16 / 1.0, ns16.value
+    assert lib.dcf_calib_mfma_rate(2, 1 << 14, ctypes.byref(ncu), ctypes.byref(ns32)) != 0      # unknown shape: an error, not a crash

@@ -19,10 +19,10 @@ __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigne
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
-template <int MODE, bool DMA>
-__global__ __launch_bounds__(MODE == 0 ? 256 : 512, 1) void k(const unsigned short* __restrict__ img, float* __restrict__ out) {
+template <int MODE, bool DMA, bool BAR = true, bool LDSR = true>
+__global__ __launch_bounds__(MODE == 1 ? 512 : 256, 1) void k(const unsigned short* __restrict__ img, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  constexpr int NWAVE = MODE == 0 ? 4 : 8, NPW = PIECES / NWAVE;
+  constexpr int NWAVE = MODE == 1 ? 8 : 4, NPW = PIECES / NWAVE;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned lane16 = (unsigned)lane * 16u;
@@ -40,21 +40,31 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 512, 1) void k(const unsigned sho
   };
 #pragma unroll
   for (int i = 0; i < NPW; ++i) issue_piece(0, 0, i);
+  f16x8 yh[8], yl[8];                                  // mode 2: the second 16-row tile's planes
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      yh[kk][e] = (_Float16)(0.29f * (float)((lane * 3 + kk * 7 + e * 5) % 23) - 3.1f);
+      yl[kk][e] = (_Float16)(0.0003f * (float)((lane * 11 + kk * 5 + e) % 13));
+    }
   f32x16 Z[3];
-  f32x4 Zs[2][3];
+  f32x4 Zs[2][3], Zt[2][3];
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) Z[t][e] = 0.f;
 #pragma unroll
-    for (int a = 0; a < 2; ++a) Zs[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < 2; ++a) { Zs[a][t] = f32x4{0.f, 0.f, 0.f, 0.f}; Zt[a][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   }
   for (int sp = 0; sp < NSTAGE / 2; ++sp) {
 #pragma unroll
     for (int HF = 0; HF < 2; ++HF) {
       const int s = 2 * sp + HF;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      if (BAR) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
       unsigned ab = lane16 + HF * STAGE;
       asm volatile("" : "+v"(ab));
       const unsigned char* buf = lds + ab;
@@ -65,8 +75,12 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 512, 1) void k(const unsigned sho
       auto frags = [&](int gq, int set) __attribute__((always_inline)) {
 #pragma unroll
         for (int tap = 0; tap < 3; ++tap) {
-          fa[set][tap][0] = *reinterpret_cast<const f16x8*>(buf + (2 * (tap * 8 + gq)) * 1024);
-          fa[set][tap][1] = *reinterpret_cast<const f16x8*>(buf + (2 * (tap * 8 + gq) + 1) * 1024);
+          if (LDSR) {
+            fa[set][tap][0] = *reinterpret_cast<const f16x8*>(buf + (2 * (tap * 8 + gq)) * 1024);
+            fa[set][tap][1] = *reinterpret_cast<const f16x8*>(buf + (2 * (tap * 8 + gq) + 1) * 1024);
+          } else {
+            fa[set][tap][0] = xh[(gq + tap) & 7]; fa[set][tap][1] = xl[(gq + 2 * tap) & 7];
+          }
         }
       };
       frags(0, 0);
@@ -90,6 +104,19 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 512, 1) void k(const unsigned sho
           Z[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][2][0], xl[kk], Z[2], 0, 0, 0);
 #pragma unroll
           for (int tap = 0; tap < 3; ++tap) Z[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][tap][0], xh[kk], Z[tap], 0, 0, 0);
+        } else if constexpr (MODE == 2) {
+          const int a = gq >> 2;
+#define M16(acc, A, B) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, acc, 0, 0, 0)
+#pragma unroll
+          for (int tap = 0; tap < 3; ++tap) { M16(Zs[a][tap], fa[set][tap][1], xh[kk]); M16(Zt[a][tap], fa[set][tap][1], yh[kk]); }
+          M16(Zs[a][0], fa[set][0][0], xl[kk]); M16(Zt[a][0], fa[set][0][0], yl[kk]);
+          __builtin_amdgcn_sched_barrier(0);
+          piece(1);
+          M16(Zs[a][1], fa[set][1][0], xl[kk]); M16(Zt[a][1], fa[set][1][0], yl[kk]);
+          M16(Zs[a][2], fa[set][2][0], xl[kk]); M16(Zt[a][2], fa[set][2][0], yl[kk]);
+#pragma unroll
+          for (int tap = 0; tap < 3; ++tap) { M16(Zs[a][tap], fa[set][tap][0], xh[kk]); M16(Zt[a][tap], fa[set][tap][0], yh[kk]); }
+#undef M16
         } else {
           const int a = gq >> 2;
 #pragma unroll
@@ -112,21 +139,21 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 512, 1) void k(const unsigned sho
 #pragma unroll
     for (int e = 0; e < 16; ++e) sum += Z[t][e];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) sum += Zs[a][t].x + Zs[a][t].y + Zs[a][t].z + Zs[a][t].w;
+    for (int a = 0; a < 2; ++a) sum += Zs[a][t].x + Zs[a][t].y + Zs[a][t].z + Zs[a][t].w + Zt[a][t].x + Zt[a][t].y + Zt[a][t].z + Zt[a][t].w;
   }
   out[(size_t)blockIdx.x * blockDim.x + tid] = sum;
 }
 
-template <int MODE, bool DMA>
+template <int MODE, bool DMA, bool BAR = true, bool LDSR = true>
 static void run(const char* name, const unsigned short* img, float* out, int grid) {
   const int lds = 2 * STAGE;
-  hipFuncSetAttribute(reinterpret_cast<const void*>(&k<MODE, DMA>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&k<MODE, DMA, BAR, LDSR>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  const int threads = MODE == 0 ? 256 : 512;
-  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((k<MODE, DMA>), dim3(grid), dim3(threads), lds, 0, img, out);
+  const int threads = MODE == 1 ? 512 : 256;
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((k<MODE, DMA, BAR, LDSR>), dim3(grid), dim3(threads), lds, 0, img, out);
   hipEventRecord(e0, 0);
   const int reps = 20;
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k<MODE, DMA>), dim3(grid), dim3(threads), lds, 0, img, out);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k<MODE, DMA, BAR, LDSR>), dim3(grid), dim3(threads), lds, 0, img, out);
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   if (hipGetLastError() != hipSuccess) printf("launch error\n");
@@ -145,8 +172,17 @@ int main() {
   for (int rep = 0; rep < 2; ++rep) {
     run<0, true>("4 waves x 32 rows (32x32x16), weight stream", img, out, 1024);
     run<1, true>("8 waves x 16 rows (16x16x32), weight stream", img, out, 1024);
+    run<2, true>("4 waves x 2 x 16 rows (16x16x32), weight stream", img, out, 1024);
+    run<2, false>("4 waves x 2 x 16 rows (16x16x32), NO weight stream", img, out, 1024);
+    run<2, false, false, false>("4 waves x 2 x 16 rows, MFMAs only", img, out, 1024);
     run<0, false>("4 waves x 32 rows, NO weight stream (timing only)", img, out, 1024);
     run<1, false>("8 waves x 16 rows, NO weight stream (timing only)", img, out, 1024);
+    run<0, true, false>("4 waves x 32 rows, stream, NO barrier / wait", img, out, 1024);
+    run<0, false, false>("4 waves x 32 rows, NO stream, NO barrier", img, out, 1024);
+    run<0, false, true, false>("4 waves x 32 rows, NO stream, NO fragment reads", img, out, 1024);
+    run<0, false, false, false>("4 waves x 32 rows, MFMAs only", img, out, 1024);
+    run<1, false, false, false>("8 waves x 16 rows, MFMAs only", img, out, 1024);
+    run<0, true, true, false>("4 waves x 32 rows, stream, NO fragment reads", img, out, 1024);
     printf("\n");
   }
   return 0;
