@@ -521,15 +521,15 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         (.., 1, Lq) / (.., Lq), text_cls (sum(text_size), D), text_size (bs,) queries per video (None: one per video).
         Video b is repeated for its text_size[b] queries (model.py:579-582), the text encoder runs inside (model.py:624).
         Returns what the reference returns: (fpn_logits1, fpn_logits2, fpn_offsets, fpn_masks), tuples over the L levels of
-        (B', T_l) / (B', T_l) / (B', T_l, 2) / (B', T_l) bool with B' = sum(text_size) rows in (video, query) order.
+        (B', T_l) / (B', T_l) / (B', T_l, 2) / (B', T_l) bool with B' = sum(text_size) rows in (video, query) order; the classes with
+        one classification head (PtTransformer, PtTransformerEarlyFusion: model.py:110-161, :300-373) return (fpn_logits, fpn_offsets,
+        fpn_masks) as theirs do.
         There is no backward pass and no random number stream here: every dropout / drop-path probability of ``opt`` must
         be 0, and the Dropout(0.5) the reference hard-codes into every layer of the refinement TCN (tcn.py:5,13;
         model.py:424-425 passes no dropout argument) is taken at p = 0 too -- the values are those of the reference's
         train()-mode forward with that module's dropout disabled.  The outputs carry no autograd graph; the reference's Trainer
         is out of scope."""
         assert mv_data is None
-        if self.MODEL_KIND != 0:
-            raise NotImplementedError('the training-mode forward is built for PtTransformerEarlyFusionIterative only (model.py:567-632)')
         mo = self.opt['model'] if isinstance(self.opt, dict) else self.opt.model
         for part in ('vid_net', 'text_net', 'fusion'):
             for key in ('attn_pdrop', 'proj_pdrop', 'path_pdrop', 'cdrop'):
@@ -575,17 +575,28 @@ class PtTransformerEarlyFusionIterative(nn.Module):
             pe = self._position_encoding(Tp, dev)
             _lib.check(lib.dcf_model_set_pe(eng.handle, _lib.ptr(pe), Tp), 'dcf_model_set_pe')
         S = lib.dcf_points_per_query(eng.handle, T)
-        logits1 = torch.empty(nq, S, device=dev, dtype=torch.float32)
         logits2 = torch.empty(nq, S, device=dev, dtype=torch.float32)
         offsets = torch.empty(nq, S, 2, device=dev, dtype=torch.float32)
         masks = torch.empty(nq, S, device=dev, dtype=torch.bool)
+        sizes_l = [(T // self.vid_net.stride) >> l for l in range(self.vid_net.arch[2])]
+        if self.MODEL_KIND != 0:
+            # PtTransformer (model.py:110-161) / PtTransformerEarlyFusion (model.py:300-373): one classification head, no refinement
+            # branch -- the training forward at p = 0 computes, per (video, query) row, exactly what the evaluation forward computes
+            # (the gate, vid_map, fusion, encoder and heads of model.py:83-147 / :320-362 do not depend on `eval`), so it runs the
+            # evaluation engine over the (video, query) rows and returns the reference's three tuples
+            _lib.check(lib.dcf_forward_eval_videos(eng.handle, bs, vptr, sptr, mptr_v, T, nqs, tptr, mptr, tlen, cptr, _lib.ptr(logits2),
+                                                   _lib.ptr(offsets), _lib.ptr(masks), _lib.current_stream()), 'dcf_forward_eval_videos')
+            self._last_inputs = (keep, pe, enc, enc_mask)
+            self._last_flat = (logits2, offsets, masks)
+            self._probe_numerics()
+            return tuple(logits2.split(sizes_l, 1)), tuple(offsets.split(sizes_l, 1)), tuple(masks.split(sizes_l, 1))
+        logits1 = torch.empty(nq, S, device=dev, dtype=torch.float32)
         _lib.check(lib.dcf_forward_train_videos(eng.handle, bs, vptr, sptr, mptr_v, T, nqs, tptr, mptr, tlen, cptr, _lib.ptr(logits1),
                                                 _lib.ptr(logits2), _lib.ptr(offsets), _lib.ptr(masks), _lib.current_stream()),
                    'dcf_forward_train_videos')
         self._last_inputs = (keep, pe, enc, enc_mask)
         self._last_flat = (logits2, offsets, masks)
         self._probe_numerics()
-        sizes_l = [(T // self.vid_net.stride) >> l for l in range(self.vid_net.arch[2])]
         return (tuple(logits1.split(sizes_l, 1)), tuple(logits2.split(sizes_l, 1)), tuple(offsets.split(sizes_l, 1)),
                 tuple(masks.split(sizes_l, 1)))
 
@@ -966,7 +977,8 @@ class PtTransformer(PtTransformerEarlyFusionIterative):
 class PtTransformerEarlyFusion(PtTransformerEarlyFusionIterative):
     """Drop-in for libs/modeling/model.py:163-373: early fusion like the iterative model (vid_map, XAttNFusion on the clip
     sequence, vid_net, optionally the fusion stack again on every pyramid level) but no refinement stage: ``cls_head`` and
-    ``reg_head`` predict from the E-wide pyramid (model.py:204-209).  Same forward signature; eval forward only."""
+    ``reg_head`` predict from the E-wide pyramid (model.py:204-209).  Same forward signature (eval, and the training-mode forward
+    values at dropout 0: ``_drop_forward``)."""
 
     MODEL_KIND = 2
 

@@ -611,6 +611,36 @@ def forward_eval_late_fusion(sd: SD, cfg, vid: Tensor, shallow_vid: Tensor, vid_
     return logits_list, offsets_list, masks_list
 
 
+def forward_train_single_head(sd: SD, cfg, kind: str, vid: Tensor, shallow_vid: Tensor, vid_masks: Tensor, tokens: Tensor, token_masks: Tensor,
+                              text_cls: Tensor, text_size: Sequence[int]):
+    """The training-mode forward (eval=False, every dropout probability 0) of the two classes with one classification head:
+    kind 'late' = PtTransformer._drop_forward (model.py:83-147), 'early2' / 'early1' = PtTransformerEarlyFusion._drop_forward with /
+    without the second fusion (model.py:320-362).  As in forward_train: video b is repeated text_size[b] times, every row is gated by
+    its own query's scores, the text batch is encoded (model.py:140-147, :349-362) and nothing mixes rows -- the rows are computed one
+    at a time with the evaluation restatements.  Returns (fpn_logits, fpn_offsets, fpn_masks): tuples over the levels of (B', T_l),
+    (B', T_l, 2), (B', T_l)."""
+    n_levels = cfg['vid_net']['arch'][2]
+    rows = [[] for _ in range(3)]
+    q = 0
+    for b, k in enumerate(text_size):
+        v, s, m = vid[b:b + 1], shallow_vid[b:b + 1], vid_masks[b:b + 1]
+        texts, tmasks = [], []
+        for i in range(q, q + k):
+            t, tm = encode_text(sd, cfg, tokens[i:i + 1], token_masks[i:i + 1])
+            texts.append(t)
+            tmasks.append(tm)
+        if kind == 'late':
+            lg, off, om = forward_eval_late_fusion(sd, cfg, v, s, m, texts, text_cls[q:q + k], tmasks)
+        else:
+            lg, off, om = forward_eval_early_fusion(sd, cfg, v, s, m, texts, text_cls[q:q + k], tmasks, second_fusion=kind == 'early2')
+        for i in range(k):
+            rows[0].append(lg[i])
+            rows[1].append(off[i])
+            rows[2].append(om[i])
+        q += k
+    return tuple(tuple(torch.cat([r[l] for r in part], 0) for l in range(n_levels)) for part in rows)
+
+
 def forward_eval_window(sd: SD, cfg, vid_w: Tensor, shallow_w: Tensor, mask_w: Tensor, text, text_masks, gate_w: Tensor,
                         pe_w=None):
     """The eval forward on a window of a longer video with an externally selected gate (NQ, Tw) and the

@@ -674,6 +674,57 @@ def gen_train():
     save('train.npz', out)
 
 
+@torch.no_grad()
+def gen_train_secondary():
+    """The training-mode forward (eval=False, train() mode, every dropout probability 0) of the two classes with one classification head:
+    PtTransformer (model.py:110-161) and PtTransformerEarlyFusion with and without the second fusion (model.py:300-373); two videos with
+    2 + 1 queries, padded text batch + text_size as the training collate delivers them (model.py:617-622).  One fixture, three cases."""
+    from libs.modeling.model import PtTransformer, PtTransformerEarlyFusion
+    cases = {
+        'late': dict(cls='PtTransformer', opt=dict(D=64, E=64, TE=32, text_in=32, n_levels=4, win=5, n_heads=4, sn=16, sratio=0.3, msf=True, norm=True,
+                                                   max_seq_len=256, text_layers=2, text_max_len=24), wseed=911, iseed=912),
+        'early': dict(cls='early2', opt=dict(D=64, E=64, TE=32, text_in=32, n_levels=4, win=5, n_heads=4, sn=8, sratio=0.3, msf=True, norm=True,
+                                             max_seq_len=256, text_layers=2, text_max_len=24), wseed=921, iseed=922),
+        'early_single': dict(cls='early1', opt=dict(D=64, E=64, TE=32, text_in=32, n_levels=3, win=5, n_heads=4, sn=8, sratio=0.5, msf=False, scat=True,
+                                                    norm=False, max_seq_len=256, text_layers=1, text_max_len=24), wseed=931, iseed=932),
+    }
+    out = dict(cases={k: dict(cls=c['cls'], opt_kwargs=c['opt'], wseed=c['wseed']) for k, c in cases.items()})
+    bs, T, lq, sizes = 2, 256, 7, [2, 1]
+    lens, tok_len = [256, 187], [7, 4, 6]
+    out['meta'] = dict(bs=bs, T=T, lq=lq, sizes=sizes)
+    for name, c in cases.items():
+        opt = make_opt(**c['opt'])
+        if c['cls'] == 'PtTransformer':
+            model = PtTransformer(opt.clone()).train()
+        else:
+            model = PtTransformerEarlyFusion(opt.clone(), second_fusion=c['cls'] == 'early2').train()
+        shapes = {k: list(v.shape) for k, v in model.state_dict().items()}
+        model.load_state_dict(synth.make_state_dict(shapes, c['wseed']))
+        g = torch.Generator().manual_seed(c['iseed'])
+        vid, shallow = torch.randn(bs, 64, T, generator=g), torch.randn(bs, 64, T, generator=g)
+        vid_masks = torch.stack([torch.arange(T) < n for n in lens])
+        vid, shallow = vid * vid_masks[:, None], shallow * vid_masks[:, None]
+        tokens = torch.randn(sum(sizes), 32, lq, generator=g)
+        token_masks = torch.stack([torch.arange(lq) < n for n in tok_len])[:, None]
+        tokens = tokens * token_masks
+        text_cls = torch.randn(sum(sizes), 64, generator=g)
+        mk = max(sizes)
+        text_pad, mask_pad = torch.zeros(bs, mk, 32, lq), torch.zeros(bs, mk, lq, dtype=torch.bool)
+        q = 0
+        for b, k in enumerate(sizes):
+            text_pad[b, :k], mask_pad[b, :k] = tokens[q:q + k], token_masks[q:q + k, 0]
+            q += k
+        out3 = model(vid, shallow, vid_masks, text_pad, text_cls, mask_pad, text_size=torch.tensor(sizes), eval=False)
+        assert len(out3) == 3
+        out[f'{name}/shapes'] = shapes
+        for key, val in (('vid', vid), ('shallow', shallow), ('vid_masks', vid_masks), ('tokens', tokens), ('token_masks', token_masks), ('text_cls', text_cls)):
+            out[f'{name}/{key}'] = val
+        for part, pn in zip(out3, ('logits', 'offsets', 'masks')):
+            for l, x in enumerate(part):
+                out[f'{name}/{pn}/l{l}'] = x
+    save('train_secondary.npz', out)
+
+
 # ------------------------------------------------------------------ G5: NMS known answers
 @torch.no_grad()
 def gen_nms(ext):
@@ -856,6 +907,8 @@ if __name__ == '__main__':
         gen_e2e_scale()
     if 'train' in which:
         gen_train()
+    if 'train2' in which:
+        gen_train_secondary()
     if 'postproc' in which:
         gen_postproc()
     if 'postproc_ext' in which or 'postproc' in which:

@@ -250,6 +250,29 @@ def test_training_forward_and_losses_match_reference():
     torch.testing.assert_close(R.ctr_iou_loss(off[pos], gt_offsets[pos], 'giou').mean(), g.t('loss/giou_mean'), **tol)
 
 
+@pytest.mark.parametrize('name', ['late', 'early', 'early_single'])
+def test_training_forward_of_the_single_head_classes_matches_reference(name):
+    """oracle forward_train_single_head against the reference's train()-mode forward of PtTransformer / PtTransformerEarlyFusion
+    (model.py:83-147, :320-362; tests/golden/train_secondary.npz: two videos, 2 + 1 queries, padded tokens)"""
+    g = Golden('train_secondary.npz')
+    case, meta = g.js('cases')[name], g.js('meta')
+    pkg = load_pkg()
+    kw = case['opt_kwargs']
+    sd = pkg.synth.make_state_dict(g.js(f'{name}/shapes'), case['wseed'])
+    opt = pkg.config.make_opt(**kw)
+    kind = 'late' if case['cls'] == 'PtTransformer' else case['cls']
+    out3 = R.forward_train_single_head(sd, opt.model, kind, g.t(f'{name}/vid'), g.t(f'{name}/shallow'), g.t(f'{name}/vid_masks'),
+                                       g.t(f'{name}/tokens'), g.t(f'{name}/token_masks'), g.t(f'{name}/text_cls'), meta['sizes'])
+    for part, pn in zip(out3, ('logits', 'offsets', 'masks')):
+        for l in range(kw['n_levels']):
+            want = g.t(f'{name}/{pn}/l{l}')
+            assert part[l].shape == want.shape
+            if pn == 'masks':
+                assert torch.equal(part[l], want)
+            else:
+                torch.testing.assert_close(part[l], want, rtol=1e-4, atol=1e-4)
+
+
 # ------------------------------------------------------------------ G5
 def test_nms_known_answers():
     g = Golden('nms_kat.npz')
