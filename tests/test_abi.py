@@ -116,7 +116,7 @@ def test_unsupported_switches_fail_loudly():
     with pytest.raises(RuntimeError, match='GPU'):   # ... and it runs on the MI355X only
         model(torch.zeros(1, 64, 128), torch.zeros(1, 64, 128), torch.ones(1, 128, dtype=torch.bool), torch.zeros(1, 32, 4), torch.zeros(1, 64),
               torch.ones(1, 1, 4, dtype=torch.bool))
-    with pytest.raises(NotImplementedError):          # the late-fusion model's training forward is not built
+    with pytest.raises(RuntimeError, match='GPU'):   # the single-head classes' training forward exists since round 5, on the GPU like the rest
         pkg.modeling.PtTransformer(pkg.config.make_opt(**kw))(torch.zeros(1, 64, 128), torch.zeros(1, 64, 128), torch.ones(1, 128, dtype=torch.bool),
                                                             torch.zeros(1, 32, 4), torch.zeros(1, 64), torch.ones(1, 1, 4, dtype=torch.bool))
     with pytest.raises(RuntimeError, match='GPU'):   # CPU tensors: no fallback
