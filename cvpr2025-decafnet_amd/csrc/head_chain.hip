@@ -479,7 +479,10 @@ __global__ __launch_bounds__(256, 1) void k_head_chain(HeadChainBatch batch) {
   if (bad && p.status) atomicOr(p.status, 1u);
 #ifdef DCF_HC_STAMP
   STAMP(6);
-  if (blockIdx.x == 1 && tid == 0)
+#ifndef DCF_HC_STAMP_WG
+#define DCF_HC_STAMP_WG 1              // (a later round: -DDCF_HC_STAMP_WG=1500)
+#endif
+  if (blockIdx.x == DCF_HC_STAMP_WG && blockIdx.y == 0 && tid == 0)
     for (int i = 0; i < 8; ++i) dcf_hc_stamps[i] = acc_[i];
 #endif
 }
