@@ -508,7 +508,11 @@ static int launch_xattn_mfma(const XAttnArgs& a, hipStream_t st) {
   // (+ the staged context tile of the d = 64 / 128 instantiations: [4 waves][16 rows][D] fp32 behind the mask, 16-byte aligned)
   const size_t lds = (size_t)2 * 2 * (16 * nkt * (D + 4) + D * (16 * nkt + 4)) + ((size_t)2 * (rem > 0 ? rem : 1) * D + ((16 * nkt + rem + 3) & ~3)) * sizeof(float) +
                      ((D16 == 4 || D16 == 8) ? (size_t)4 * 16 * D * sizeof(float) : 0);
-#define XL(NKT_, REM_) hipLaunchKernelGGL((k_xattn_mfma<D16, NKT_, REM_, QT>), grid, dim3(256), lds, st, a)
+  DCF_CHECK(lds <= 160 * 1024, "xattn: K / V planes of %d keys x %d channels (+ the staged context tile) need %zu bytes of LDS (> 160 KiB)", a.Lk, D, lds);
+  // (above the 64 KiB a launch gets by default the kernel's limit is raised first: d = 128 with the staged context tile, d = 256)
+#define XL(NKT_, REM_) do { \
+    if (lds > 64 * 1024) DCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_xattn_mfma<D16, NKT_, REM_, QT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((k_xattn_mfma<D16, NKT_, REM_, QT>), grid, dim3(256), lds, st, a); } while (0)
   switch (nkt * 4 + rem) {
     case 0 * 4 + 1: XL(0, 1); break;
     case 0 * 4 + 2: XL(0, 2); break;

@@ -448,7 +448,9 @@ def xattn_ref(q, k, v, kvmask, heads):
                                              (1, 100, 33, 1024, 16), (3, 40, 6, 32, 4),
                                              # head dims 128 and 64 with ragged ends: the context rows leave through the staged LDS tile
                                              # (whole rows per store; the last row group is partly beyond T)
-                                             (1, 130, 33, 512, 4), (2, 77, 20, 256, 2), (2, 1000, 48, 256, 4), (1, 17, 5, 128, 2)])
+                                             (1, 130, 33, 512, 4), (2, 77, 20, 256, 2), (2, 1000, 48, 256, 4), (1, 17, 5, 128, 2),
+                                             # 64 keys at head dims 128 / 256: 100 / 136 KB of LDS (the launch raises the kernel's limit)
+                                             (1, 90, 64, 512, 4), (1, 70, 64, 1024, 4)])
 def test_xattn_core(L, B, T, Lk, C, heads):
     pkg, lib = L
     g = torch.Generator().manual_seed(T + C)
