@@ -485,6 +485,20 @@ __global__ __launch_bounds__(256, WMAX > 0 && NCH == 1 ? 8 : 4) void k_local_att
     else if ((a).window <= 19) LOCAL_LAUNCH_W(NCH_, LPH_, 19, grid, st, a); \
     else LOCAL_LAUNCH_W(NCH_, LPH_, 0, grid, st, a); } while (0)
 
+// the dynamic-LDS limit of one instantiation on the current device, raised once per size (the attribute belongs to the device's copy
+// of the kernel; a forward under graph capture does not repeat the call)
+template <int D16, int NKT, int REM, int QT>
+static int xattn_raise_lds(size_t bytes) {
+  static size_t have[64] = {};
+  int dev = 0;
+  DCF_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || bytes > have[dev]) {
+    DCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_xattn_mfma<D16, NKT, REM, QT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (dev >= 0 && dev < 64) have[dev] = bytes;
+  }
+  return 0;
+}
+
 template <int D16>
 static int launch_xattn_mfma(const XAttnArgs& a, hipStream_t st) {
   // keys = 16 * nkt + rem: up to 2 trailing keys go to the vector ALU instead of a mostly empty MFMA tile
@@ -511,7 +525,7 @@ static int launch_xattn_mfma(const XAttnArgs& a, hipStream_t st) {
   DCF_CHECK(lds <= 160 * 1024, "xattn: K / V planes of %d keys x %d channels (+ the staged context tile) need %zu bytes of LDS (> 160 KiB)", a.Lk, D, lds);
   // (above the 64 KiB a launch gets by default the kernel's limit is raised first: d = 128 with the staged context tile, d = 256)
 #define XL(NKT_, REM_) do { \
-    if (lds > 64 * 1024) DCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_xattn_mfma<D16, NKT_, REM_, QT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    if (lds > 64 * 1024) { if (int rc_ = xattn_raise_lds<D16, NKT_, REM_, QT>(lds)) return rc_; } \
     hipLaunchKernelGGL((k_xattn_mfma<D16, NKT_, REM_, QT>), grid, dim3(256), lds, st, a); } while (0)
   switch (nkt * 4 + rem) {
     case 0 * 4 + 1: XL(0, 1); break;

@@ -65,30 +65,32 @@ extern "C" int dcf_calib_mfma_rate(int32_t shape, int32_t mfmas_per_wave, int32_
   DCF_HIP(hipGetDeviceProperties(&prop, dev));
   const int cus = prop.multiProcessorCount;
   float* out = nullptr;
-  DCF_HIP(hipMalloc((void**)&out, (size_t)cus * 256 * sizeof(float)));
-  hipEvent_t e0, e1;
-  DCF_HIP(hipEventCreate(&e0));
-  DCF_HIP(hipEventCreate(&e1));
-  const int rounds = mfmas_per_wave / 16;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  float ms = 0.f;
+  const int rounds = mfmas_per_wave / 16, reps = 4;
   auto launch = [&]() {
     if (shape == 0) hipLaunchKernelGGL(k_mfma_rate<false>, dim3(cus), dim3(256), 0, 0, out, rounds);
     else hipLaunchKernelGGL(k_mfma_rate<true>, dim3(cus), dim3(256), 0, 0, out, rounds);
   };
-  // the clock settles over the first launches: time the last of a few back-to-back ones
-  for (int i = 0; i < 6; ++i) launch();
-  DCF_HIP(hipEventRecord(e0, 0));
-  const int reps = 4;
-  for (int i = 0; i < reps; ++i) launch();
-  DCF_HIP(hipEventRecord(e1, 0));
-  DCF_HIP(hipEventSynchronize(e1));
-  float ms = 0.f;
-  DCF_HIP(hipEventElapsedTime(&ms, e0, e1));
-  const hipError_t err = hipGetLastError();
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
-  hipFree(out);
+  // (every step's status is kept so that the buffer and the events are released on any exit)
+  hipError_t err = hipMalloc((void**)&out, (size_t)cus * 256 * sizeof(float));
+  if (err == hipSuccess) err = hipEventCreate(&e0);
+  if (err == hipSuccess) err = hipEventCreate(&e1);
+  if (err == hipSuccess) {
+    // the clock settles over the first launches: time a few back-to-back ones behind them
+    for (int i = 0; i < 6; ++i) launch();
+    err = hipEventRecord(e0, 0);
+    for (int i = 0; i < reps; ++i) launch();
+    if (err == hipSuccess) err = hipEventRecord(e1, 0);
+    if (err == hipSuccess) err = hipEventSynchronize(e1);
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+    if (err == hipSuccess) err = hipGetLastError();
+  }
+  if (e0) hipEventDestroy(e0);
+  if (e1) hipEventDestroy(e1);
+  if (out) hipFree(out);
   DCF_HIP(err);
   *n_cus = cus;
-  *ns_per_mfma = ms * 1e6f / reps / (float)(rounds * 16);
+  *ns_per_mfma = ms * 1e6f / (float)reps / (float)(rounds * 16);
   return 0;
 }
