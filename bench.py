@@ -698,6 +698,7 @@ def main():
                 'cpu_oracle_nms_ms': 1e3 * t_cpu_nms,
                 'nms_index_match': bool(torch.equal(keep[0, :int(kc)].cpu(), ref_keep)),
                 'softnms_index_match': bool(torch.equal(inds[0, :int(oc)].cpu(), ref_soft)),
+                'softnms_dets_bitwise': bool(torch.equal(dets[0, :int(oc)].cpu(), d2[:len(ref_soft)])),      # (segment, decayed score) of every pick, bit for bit
                 'forward_collect_nms': {'value': vid_len * args.nq / t_e2e, 'unit': 'clips/s', 'ms_per_video': 1e3 * t_e2e,
                                         'ms_per_video_unpipelined': 1e3 * t_seq,
                                         'note': 'one video per call: forward + _collect_segments + batched_nms (soft-NMS, max_num_segs 5, voting 0.95) '
@@ -769,6 +770,7 @@ def main():
         if 'post' in result:
             chk['nms_index_match'] = result['post']['nms_index_match']
             chk['softnms_index_match'] = result['post']['softnms_index_match']
+            chk['softnms_dets_bitwise'] = result['post']['softnms_dets_bitwise']
         if 'parity' in result:
             chk['parity_max_abs_logit'] = result['parity']['max_abs_logit']
             chk['parity_max_abs_offset'] = result['parity']['max_abs_offset']

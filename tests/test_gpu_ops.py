@@ -895,7 +895,8 @@ def test_nms_known_answers(L):
             idx = nms.softnms(segs, scores, dets, c['iou_thresh'], c['sigma'], c['min_score'], method)
             assert torch.equal(idx, g.t(f'k{i}/soft{method}/idx')), (c, method)
             want = g.t(f'k{i}/soft{method}/dets')
-            torch.testing.assert_close(dets[:len(idx)], want, rtol=1e-6, atol=1e-7)
+            # bit for bit since round 5: the Gaussian weight is the reference C library's expf restated (postproc.hip expf_glibc)
+            assert torch.equal(dets[:len(idx)], want), (c, method, int((dets[:len(idx)] != want).sum()))
             if len(idx) < len(segs):
                 assert (dets[len(idx):] == -7.0).all()
 
@@ -913,7 +914,7 @@ def test_nms_known_answers_beyond_4096_candidates(L):
             dets = torch.full((len(segs), 3), -7.0)
             idx = nms.softnms(segs, scores, dets, c['iou_thresh'], c['sigma'], c['min_score'], method)
             assert torch.equal(idx, g.t(f'k{i}/soft{method}/idx')), (c, method)
-            torch.testing.assert_close(dets[:len(idx)], g.t(f'k{i}/soft{method}/dets'), rtol=1e-6, atol=1e-7)
+            assert torch.equal(dets[:len(idx)], g.t(f'k{i}/soft{method}/dets')), (c, method)
     # batched_nms over device tensors of that size (both modes), against the oracle's composition
     segs, scores = g.t('k1/segs'), g.t('k1/scores')
     for mode in ('nms', 'soft_nms'):
@@ -924,7 +925,7 @@ def test_nms_known_answers_beyond_4096_candidates(L):
         else:
             d = torch.zeros(len(segs), 3)
             nms_oracle.softnms(segs, scores, d, 0.5, 0.9, 0.001, 2)
-            torch.testing.assert_close(c.cpu(), d[:50, 2], rtol=1e-6, atol=1e-7)
+            assert torch.equal(c.cpu(), d[:50, 2])
 
 
 def test_nms_module_abi(L):
@@ -965,7 +966,7 @@ def test_nms_fuzz_vs_oracle(L):
             i1 = nms.softnms(segs, scores, d1, thr, 0.5, ms, method)
             i2 = nms_oracle.softnms(segs, scores, d2, thr, 0.5, ms, method)
             assert torch.equal(i1, i2), (trial, n, method)
-            torch.testing.assert_close(d1[:len(i1)], d2[:len(i2)], rtol=1e-6, atol=1e-7)
+            assert torch.equal(d1[:len(i1)], d2[:len(i2)]), (trial, n, method)       # (the oracle's expf is the host C library's)
 
 
 def test_nms_ties_are_stable(L):

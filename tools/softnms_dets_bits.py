@@ -1,0 +1,22 @@
+import sys, os
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
+sys.path.insert(0, os.path.join(os.environ.get('GRAFT_REPO_ROOT', '/root/repo'), 'tests'))
+import torch, importlib
+from conftest import Golden
+pkg = importlib.import_module('cvpr2025-decafnet_amd')
+tot = diff = 0; worst = 0
+for name in ('nms_kat.npz', 'nms_kat_big.npz'):
+    g = Golden(name)
+    for i, c in enumerate(g.js('cases')):
+        segs, scores = g.t(f'k{i}/segs'), g.t(f'k{i}/scores')
+        for method in (0, 1, 2):
+            key = f'k{i}/soft{method}/dets'
+            if key not in g: continue
+            dets = torch.full((len(segs), 3), -7.0)
+            idx = pkg.nms.softnms(segs, scores, dets, c['iou_thresh'], c['sigma'], c['min_score'], method)
+            want = g.t(key)
+            a = dets[:len(idx)].contiguous().view(torch.int32); b = want.contiguous().view(torch.int32)
+            d = (a - b).abs()
+            tot += d.numel(); diff += int((d != 0).sum()); worst = max(worst, int(d.max()) if d.numel() else 0)
+            if int((d != 0).sum()): print(name, i, method, 'differing', int((d != 0).sum()), 'of', d.numel(), 'max ulp', int(d.max()))
+print('total elements', tot, 'bitwise different', diff, 'worst ulp', worst)
