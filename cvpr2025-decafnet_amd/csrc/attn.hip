@@ -15,6 +15,8 @@
 //            lanes, the q.k dot product is a 4-FMA partial + log2(d/4) cross-lane adds, and the softmax
 //            is carried online (running max / running sum), so no score matrix is materialised.
 #include "attn.h"
+
+#include <cstdlib>
 #include "common.h"
 
 namespace dcf {
@@ -508,10 +510,15 @@ static int launch_xattn_mfma(const XAttnArgs& a, hipStream_t st) {
   // enough workgroups to fill the chip, few enough that K/V staging (2*Lk*d floats) is amortised
   int gx = n_groups;
   const int per = a.heads * a.B;
-  // 1024 workgroups = two rounds of the 512 resident ones (186 registers: 2 per CU).  Round 3, interleaved A/B on one box at
-  // BASELINE config 2: 1024 -> 66.3 - 70.7 us cold / 5.14 - 5.26 TB/s warm; 1536 -> 68.8 - 71.0 us / 4.95 - 4.99 TB/s; 512 and
-  // 2048 / 3072 slower; three row groups of q in flight instead of two: no change (profiles/r03_notes.md)
-  const int cap = (1024 + per - 1) / per;
+  // Workgroup count: 512 are resident (186 registers: 2 per CU).  Round 3, direct context stores, interleaved A/B on one box at BASELINE
+  // config 2: 1024 -> 66.3 - 70.7 us cold / 5.14 - 5.26 TB/s warm; 1536 -> 68.8 - 71.0 us; 512 and 2048 / 3072 slower; three row groups
+  // of q in flight instead of two: no change (profiles/r03_notes.md).  Round 5, with the context rows leaving as whole rows through LDS, the
+  // optimum moved: **768** (one and a half rounds: the second half round starts while the first is in mid-stream, so the K / V stagings and
+  // the ends of the workgroups no longer coincide) 64.0 - 66.6 us cold / 52.2 - 53.7 us warm against 71.8 - 72.4 / 56.5 - 57.5 us for 1024
+  // in six alternating runs on one box, 63.1 - 65.9 against 69.5 - 71.4 on another; 512 66 - 69, 640 67 - 70, 896 73 - 75, 1536 68 - 69,
+  // 2048 69, 384 75 us (profiles/r05_notes.md).
+  static const int wg_target = getenv("DCF_XATTN_WGS") ? atoi(getenv("DCF_XATTN_WGS")) : 768;      // (tools/: workgroup-count sweeps)
+  const int cap = (wg_target + per - 1) / per;
   if (gx > cap) gx = cap;
   dim3 grid(gx, a.heads, a.B);
   constexpr int D = 16 * D16;
