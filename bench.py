@@ -257,24 +257,45 @@ def spawn_ranks(args):
     exits with the worst child's return code.  The parent has touched no GPU at this point (importing torch does not
     initialise HIP), and it never exec()s: the children are ordinary subprocesses (train.py:42-46 is the reference's launch)."""
     import socket
-    with socket.socket() as s:                           # a free rendezvous port on the loopback interface
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
-    env0 = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(args.gpus),
-                LOCAL_WORLD_SIZE=str(args.gpus), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
-    procs = []
-    for r in range(args.gpus):
-        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
     import threading
-    chunks = []
-    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)   # rank 0 prints the ONE JSON line
-    reader.start()
+
+    def start():
+        # a free rendezvous port on the loopback interface.  The probe socket is closed before rank 0 binds the port (seconds later, once it
+        # has imported torch), so another process can take it in between: a run whose ranks die at the rendezvous is started once more
+        # on a fresh port (below) instead of failing the bench.
+        with socket.socket() as s:
+            s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        env0 = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(args.gpus),
+                    LOCAL_WORLD_SIZE=str(args.gpus), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs = []
+        for r in range(args.gpus):
+            env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+            # rank 0 prints the ONE JSON line on stdout; whatever another rank prints goes to stderr, not away
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=None))
+        chunks = []
+        reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
+        return procs, chunks, reader, time.time()
+
+    procs, chunks, reader, t_start = start()
+    retried = False
     failed_at = None
     while any(p.poll() is None for p in procs):          # a rank that dies leaves the others at a barrier: end them after a grace period
         if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
             failed_at = time.time()
+            if not retried and failed_at - t_start < 30:   # died before or at the rendezvous (the port was taken?): one fresh start
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+                for p in procs:
+                    p.wait()
+                sys.stderr.write('bench.py: a rank exited %.0f s after its start; starting the ranks once more on a new port\n' % (failed_at - t_start))
+                procs, chunks, reader, t_start = start()
+                retried, failed_at = True, None
+                continue
         if failed_at is not None and time.time() - failed_at > 60:
             for p in procs:
                 if p.poll() is None:

@@ -103,9 +103,10 @@ __global__ void k_permute3(const float* __restrict__ src, float* __restrict__ ds
 }
 
 // masks_out[b][off_l + t] = mask_all[start_l + b*T_l + t].  Last kernel of a forward: when the sticky numerics word of the
-// f16x3 GEMMs is raised (an operand left the fp16 range somewhere upstream, and a ReLU / max may have swallowed the
-// NaN since) the logits of the forward are overwritten with NaN, so that a caller who never asks dcf_numerics_status --
-// the reference's Evaluator -- sees invalid scores instead of plausible wrong ones.
+// f16x3 GEMMs is raised -- bit 0: an operand left the fp16 range somewhere upstream, and a ReLU / max may have swallowed the
+// NaN since; bit 1: a LayerNorm carried as one-pass row statistics met a row whose mean dwarfs its spread (common.h
+// LN_ILL_RATIO), its rstd is off by an unbounded amount -- the logits of the forward are overwritten with NaN, so that a
+// caller who never asks dcf_numerics_status -- the reference's Evaluator -- sees invalid scores instead of plausible wrong ones.
 __global__ void k_masks_out(const uint8_t* __restrict__ mask_all, uint8_t* __restrict__ out, const LevelTable* lt,
                             const unsigned* __restrict__ status, float* __restrict__ logits) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -117,7 +118,7 @@ __global__ void k_masks_out(const uint8_t* __restrict__ mask_all, uint8_t* __res
   const int b = rel / lt->T[l], t = rel - b * lt->T[l];
   const int64_t o = (int64_t)b * lt->S + lt->off[l] + t;
   out[o] = mask_all[r];
-  if (status && (status[0] & 1u)) logits[o] = __uint_as_float(0x7fc00000u);
+  if (status && (status[0] & 3u)) logits[o] = __uint_as_float(0x7fc00000u);
 }
 
 // out[b][off_l + t] = rows[start_l + b*T_l + t]: a per-point value of the pyramid from level-major to query-major order
@@ -1891,7 +1892,6 @@ static int forward(dcf_model* m, const VideoSet& vs, int T0, int nq,
       ra.w_out = m->tcn_out_w; ra.b_out = m->tcn_out_b;
       ra.host_frag = (!m->tcn_frag.empty() && debug_option("tcn_frag", 1) != 0) ? m->tcn_frag.data() : nullptr;
       ra.stack_layers = debug_option("tcn_stack", tcn_stack_env());          // (dcf_debug_set_option: 0 = layer by layer)
-  ra.stack_layers = debug_option("tcn_stack", tcn_stack_env());          // (dcf_debug_set_option: 0 = layer by layer)
       ra.bufA = b.tcnA; ra.bufB = b.tcnB; ra.F = b.F; ra.ldf = E + TCN_HID; ra.E = E;
       ra.B = B; ra.T0 = Tp; ra.n_levels = L; ra.n_layers = L;
       ra.f16 = m->gemm_terms == GEMM_F16X3; ra.status = m->status;
@@ -2542,6 +2542,9 @@ int dcf_op_ffn(const float* X, const float* ln_w, const float* ln_b, const float
   hipStream_t st = (hipStream_t)stream;
   DCF_CHECK(X && W1 && b1 && W2 && b2 && C && M > 0 && E % 64 == 0, "dcf_op_ffn: bad argument");
   DCF_CHECK(!chain || E == 256, "dcf_op_ffn: the one-kernel form exists for E = 256 only");
+  DCF_CHECK(chain >= 0 && chain <= 3, "dcf_op_ffn: chain = %d (0 .. 3)", chain);
+  // (the one-kernel form reads a row twice -- as X and, a tile later, as the residual -- and the retry below re-reads X after C is written)
+  DCF_CHECK(C != X, "dcf_op_ffn: C must not alias X");
   DCF_CHECK(!stats_out || chain || dcf::gemm_can_carry_stats(M, E, 4 * E, 1, dcf::GEMM_F16X3), "dcf_op_ffn: %d rows run on a kernel without row statistics", M);
   const int H = 4 * E, nterms = dcf::GEMM_F16X3;
   unsigned short *p1 = nullptr, *p2 = nullptr;
@@ -2570,14 +2573,22 @@ int dcf_op_ffn(const float* X, const float* ln_w, const float* ln_b, const float
     a.X = X; a.ldx = E; a.W1s = p1; a.b1 = fc_b; a.ln_s = fc_s; a.stats = stats; a.stats_slots = E / 64; a.W2s = p2; a.b2 = b2; a.ls = ls;
     a.R = X; a.ldr = E; a.rowmask = mask; a.C = C; a.ldc = E; a.stats_out = stats_out; a.stats_w = 64; a.M = M;
     a.variant = chain == 1 ? 0 : chain - 1;        // chain 2: the four-wave kernel, 3: the eight-wave kernel
-    unsigned* word = nullptr;                      // the sticky numerics word of this call (bit 1: common.h LN_ILL_RATIO)
-    DCF_HIP(hipMallocAsync((void**)&word, sizeof(unsigned), st));
-    DCF_HIP(hipMemsetAsync(word, 0, sizeof(unsigned), st));
-    a.status = word;
-    rc = dcf::launch_ffn_chain(a, st);
+    // the sticky numerics word of this call (bit 1: common.h LN_ILL_RATIO): only a folded LayerNorm can raise it, and only then
+    // does the call pay for the word and the wait; freed on every path below
+    unsigned* word = nullptr;
     unsigned flag = 0u;
-    if (rc == 0) { DCF_HIP(hipMemcpyAsync(&flag, word, sizeof(flag), hipMemcpyDeviceToHost, st)); DCF_HIP(hipStreamSynchronize(st)); }
-    DCF_HIP(hipFreeAsync(word, st));
+    if (ln_w) {
+      if (hipMallocAsync((void**)&word, sizeof(unsigned), st) != hipSuccess) { word = nullptr; rc = -1; dcf::set_error("dcf_op_ffn: hipMallocAsync failed"); }
+      if (rc == 0 && hipMemsetAsync(word, 0, sizeof(unsigned), st) != hipSuccess) { rc = -1; dcf::set_error("dcf_op_ffn: hipMemsetAsync failed"); }
+    }
+    a.status = word;
+    if (rc == 0) rc = dcf::launch_ffn_chain(a, st);
+    if (rc == 0 && word) {
+      if (hipMemcpyAsync(&flag, word, sizeof(flag), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        rc = -1; dcf::set_error("dcf_op_ffn: reading the numerics word failed");
+      }
+    }
+    if (word) (void)hipFreeAsync(word, st);
     if (rc == 0 && ln_w && (flag & 2u)) {
       // a row's mean dwarfs its spread: the folded one-pass statistics are not trustworthy for it -- what the engine does after
       // dcf_model_set_ln_carry(m, 0): the two-pass LayerNorm as its own launch, the same kernel on its output

@@ -901,18 +901,22 @@ __global__ __launch_bounds__(256) void k_tcn_stack(TcnStackArgs p) {
   if (bad && p.status) atomicOr(p.status, 1u);
 }
 
+// (timed and priced inside launch_refine's "refine_tcn" scope, which counts every layer of the branch)
 template <int NL>
-static void launch_tcn_stack_n(const TcnStackArgs& a, hipStream_t st) {
+static int launch_tcn_stack_n(const TcnStackArgs& a, hipStream_t st) {
   constexpr int VALID = TS_ROWS - 2 * ((1 << NL) - 1);
   const unsigned grid = (unsigned)(a.B * ((a.T0 + VALID - 1) / VALID));
-  const size_t lds = (size_t)2 * TS_ROWS * TS_PITCH * sizeof(float);
+  const size_t lds = (size_t)2 * TS_ROWS * TS_PITCH * sizeof(float);        // 72 KiB: above the 64 KiB a kernel gets without asking
   static bool attr_set[64] = {};
   int dev = 0;
-  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tcn_stack<NL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set[dev] = true;
+  DCF_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    DCF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tcn_stack<NL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   hipLaunchKernelGGL((k_tcn_stack<NL>), dim3(grid), dim3(256), lds, st, a);
+  DCF_HIP(hipGetLastError());
+  return 0;
 }
 
 // |w| * 2^8 must stay inside fp16 for the kernel above: raises *flag otherwise (checked once per model, like the GEMM weights)
@@ -1069,12 +1073,14 @@ int launch_refine(const RefineArgs& a, const LevelTable& lt, hipStream_t st) {
       TcnStackArgs sa{};
       sa.X = cur; sa.Y = nxt; sa.mask = a.mask_all; sa.B = a.B; sa.T0 = a.T0; sa.status = a.status;
       for (int i = 0; i < nl; ++i) { sa.frag[i] = fimg(i); sa.bd[i] = a.host_b_dil[i]; sa.bp[i] = a.host_b_pw[i]; sa.lnw[i] = a.host_ln_w[i]; sa.lnb[i] = a.host_ln_b[i]; }
+      int rc;
       switch (nl) {
-        case 2: launch_tcn_stack_n<2>(sa, st); break;
-        case 3: launch_tcn_stack_n<3>(sa, st); break;
-        case 4: launch_tcn_stack_n<4>(sa, st); break;
-        default: launch_tcn_stack_n<5>(sa, st); break;
+        case 2: rc = launch_tcn_stack_n<2>(sa, st); break;
+        case 3: rc = launch_tcn_stack_n<3>(sa, st); break;
+        case 4: rc = launch_tcn_stack_n<4>(sa, st); break;
+        default: rc = launch_tcn_stack_n<5>(sa, st); break;
       }
+      if (rc) return rc;                                // (the output buffer was not written: do not swap and carry on)
       float* t = cur; cur = nxt; nxt = t;
       first = nl;
     }

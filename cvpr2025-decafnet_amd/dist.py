@@ -59,9 +59,14 @@ def alignment(n_levels: int, win: int) -> int:
     return (2 ** (n_levels - 1)) * max(win // 2, 1)
 
 
-def receptive_field(n_levels: int, win: int, fusion_layers: int = 2, n_embd_convs: int = 2, n_stem: int = 0,
-                    head_layers: int = 2) -> int:
-    """Exact one-sided receptive field of an output position, in level-0 clips (the larger, LEFT reach; the right reach
+# the layer counts of BASELINE.md's probe configuration (and of every test fixture that does not say otherwise): for callers that plan
+# for THAT architecture without a model at hand; with a model, pass **arch_of(model)
+PROBE_ARCH = dict(fusion_layers=2, n_embd_convs=2, n_stem=0, head_layers=2)
+
+
+def receptive_field(n_levels: int, win: int, *, fusion_layers: int, n_embd_convs: int, n_stem: int, head_layers: int) -> int:
+    """(The layer counts have no defaults, like ``hybrid_halos``: a halo computed for another architecture is silently wrong.)
+    Exact one-sided receptive field of an output position, in level-0 clips (the larger, LEFT reach; the right reach
     is 2^(L-1) smaller because nearest upsampling reads the sample at or left of a clip).  Validated against a
     perturbation probe (tools/receptive_field.py); 2304 for L = 8, w = 9 (right reach 2176).
 

@@ -245,10 +245,25 @@ class GroundingEvaluator:
         ``window_ext``: padded external scores (NQ, T) on the device (worker_v2.py:1078-1081) or None."""
         return self.finish_proposals(self.launch_proposals(flat, T, data, window_ext))
 
+    def _own_carry(self, on=True):
+        """while predict / run are in charge, the model does not raise for the one-pass LayerNorm guard at its next call: the evaluator
+        repeats the affected videos (replicas made meanwhile inherit the setting)"""
+        self.model._carry_handled_by_caller = bool(on)
+
     def predict(self, data):
+        self._own_carry()
+        try:
+            return self._predict(data)
+        finally:
+            self._own_carry(False)
+
+    def _predict(self, data):
         flat, T = self.forward(data)
         res = self.generate_proposals(flat, T, data, self._window_ext)
-        self._check_numerics([self.model])          # the host has just synchronised for the proposals: 4 more bytes
+        if self._carry_tripped([self.model]):       # the host has just synchronised for the proposals: 4 more bytes
+            flat, T = self.forward(data)            # one-pass LayerNorm guard: the model runs two-pass launches now, the video is repeated
+            res = self.generate_proposals(flat, T, data, self._window_ext)
+            self._check_numerics([self.model])
         return res
 
     def run(self, dataset, counter: RecallCounter = None, n_streams: int = 1, batch_videos: int = 1):
@@ -256,6 +271,13 @@ class GroundingEvaluator:
         libs/data/dataset.py:977-994: vid, shallow_vid, text, text_cls, segment, fps, clip_stride, clip_size, duration).
         ``batch_videos > 1``: consecutive videos of the same padded length (every video up to max_vid_len is one) share a
         forward (``model.forward_videos``); same proposals, fewer and larger kernel launches."""
+        self._own_carry()
+        try:
+            return self._run(dataset, counter, n_streams, batch_videos)
+        finally:
+            self._own_carry(False)
+
+    def _run(self, dataset, counter, n_streams, batch_videos):
         counter = counter or RecallCounter(self.opt['eval'].get('ranks', (1, 5)), self.opt['eval'].get('iou_threshs', (0.3, 0.5)))
         if batch_videos > 1:
             pending = []                              # (data, args, T, ext)
@@ -265,15 +287,23 @@ class GroundingEvaluator:
                     return
                 T = pending[0][2]
                 t0 = time.perf_counter()
-                self.model.forward_videos([p[1] for p in pending])
+
+                def compute():
+                    self.model.forward_videos([p[1] for p in pending])
+                    logits, offsets, masks = self.model._last_flat
+                    q, out = 0, []
+                    for data, args, _, ext in pending:
+                        n = len(args[3])
+                        out.append(self.generate_proposals((logits[q:q + n], offsets[q:q + n], masks[q:q + n]), T, data, ext))
+                        q += n
+                    return out
+
+                results = compute()
+                if self._carry_tripped([self.model]):          # (the host has synchronised for the proposals) repeat the group
+                    results = compute()
                 self.time_dict['forward'].append(time.perf_counter() - t0)
-                logits, offsets, masks = self.model._last_flat
-                q = 0
-                for data, args, _, ext in pending:
-                    n = len(args[3])
-                    res = self.generate_proposals((logits[q:q + n], offsets[q:q + n], masks[q:q + n]), T, data, ext)
+                for res, (data, _, _, _) in zip(results, pending):
                     counter.update(res, data['segment'])
-                    q += n
                 pending.clear()
 
             for data in dataset:
@@ -287,15 +317,30 @@ class GroundingEvaluator:
         if n_streams <= 1:
             # one video per forward like the reference, software-pipelined by one video: the proposals of video i are waited for
             # after the forward of video i + 1 has been launched (same stream: its kernels run after video i's decode / NMS)
+            def launch(data):
+                flat, T = self.forward(data)
+                return self.launch_proposals(flat, T, data, self._window_ext)
+
             prev = None
             for data in dataset:
-                flat, T = self.forward(data)
-                handle = self.launch_proposals(flat, T, data, self._window_ext)
+                handle = launch(data)
                 if prev is not None:
-                    counter.update(self.finish_proposals(prev[0]), prev[1]['segment'])
+                    res = self.finish_proposals(prev[0])
+                    # the one-pass LayerNorm guard, without a wait: the probe of prev's forward has landed (its proposals have); if it
+                    # -- or the forward in flight behind it -- tripped, the model switches to two-pass launches and both are repeated
+                    if self.model.ln_carry_flag_nowait():
+                        torch.cuda.synchronize()
+                        self.finish_proposals(handle)          # (gives its pinned buffer back)
+                        self._carry_tripped([self.model])
+                        res = self.finish_proposals(launch(prev[1]))
+                        handle = launch(data)
+                    counter.update(res, prev[1]['segment'])
                 prev = (handle, data)
             if prev is not None:
-                counter.update(self.finish_proposals(prev[0]), prev[1]['segment'])
+                res = self.finish_proposals(prev[0])
+                if self._carry_tripped([self.model]):
+                    res = self.finish_proposals(launch(prev[1]))
+                counter.update(res, prev[1]['segment'])
             self._check_numerics([self.model])
             return counter
         # throughput mode: n_streams videos in flight, one model replica (shared parameters, own workspace) and one HIP
@@ -304,10 +349,18 @@ class GroundingEvaluator:
         group = []
 
         def finish():
-            for stream, flat, T, data, ext in group:
+            results = []
+            for stream, mdl, flat, T, data, ext in group:
                 with torch.cuda.stream(stream):
-                    res = self.generate_proposals(flat, T, data, ext)
-                counter.update(res, data['segment'])
+                    results.append(self.generate_proposals(flat, T, data, ext))
+            if self._carry_tripped([m for m, _ in lanes]):     # (every lane's host wait is behind us) repeat the group, two-pass LayerNorms
+                results = []
+                for stream, mdl, _, _, data, _ in group:
+                    with torch.cuda.stream(stream):
+                        flat, T = self.forward(data, mdl)
+                        results.append(self.generate_proposals(flat, T, data, self._window_ext))
+            for res, entry in zip(results, group):
+                counter.update(res, entry[4]['segment'])
             group.clear()
 
         for data in dataset:
@@ -315,13 +368,32 @@ class GroundingEvaluator:
             stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(stream):
                 flat, T = self.forward(data, mdl)
-            group.append((stream, flat, T, data, self._window_ext))
+            group.append((stream, mdl, flat, T, data, self._window_ext))
             if len(group) == n_streams:
                 finish()
         finish()
         torch.cuda.synchronize()
         self._check_numerics([m for m, _ in lanes])
         return counter
+
+    @staticmethod
+    def _carry_tripped(models):
+        """The one-pass LayerNorm guard (dcf_numerics_status & 16: a carried LayerNorm met a row whose mean dwarfs its spread; that forward's
+        logits were set to NaN) checked where the host has synchronised anyway.  True: EVERY model now runs the two-pass LayerNorm launches
+        (set_ln_carry(False)), the flags are reset, and the caller repeats the forwards since the last check -- the run goes on instead of
+        aborting.  The fp16-range bit still raises (nothing to fall back to but another gemm_mode)."""
+        tripped = False
+        for m in models:
+            st = m.numerics_status(reset=False) if hasattr(m, 'numerics_status') else 0
+            if st & 1:
+                m.numerics_status(reset=True)
+                raise RuntimeError("an activation left the fp16 operand range of the f16x3 GEMM mode: results are not valid; "
+                                   "set opt.model.gemm_mode = 'bf16x6'")
+            tripped = tripped or bool(st & 16)
+        if tripped:
+            for m in models:
+                m.acknowledge_ln_carry()
+        return tripped
 
     @staticmethod
     def _check_numerics(models):

@@ -624,9 +624,27 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         self.set_ln_carry(False)
         self.numerics_status(reset=True)
         raise RuntimeError("a LayerNorm carried between kernels as one-pass row statistics met a row whose mean dwarfs its spread "
-                           "(|mean| > 8 sigma) in an earlier forward of this model: its variance lost accuracy to cancellation.  The "
-                           "model now runs every LayerNorm as its own two-pass launch (set_ln_carry(False)); repeat the forward(s) "
-                           "since the last check.  The flag has been reset.")
+                           "(|mean| > 8 sigma) in an earlier forward of this model: its variance lost accuracy to cancellation and the "
+                           "logits of that forward were set to NaN.  The model now runs every LayerNorm as its own two-pass launch "
+                           "(set_ln_carry(False)); repeat the forward(s) since the last check.  The flag has been reset.  "
+                           "(GroundingEvaluator repeats them by itself.)")
+
+    def ln_carry_flag_nowait(self):
+        """True when the last completed numerics probe of this model (the 4-byte async copy every forward ends with) shows the one-pass
+        LayerNorm guard raised.  Never waits: the word is whatever the newest finished copy left in pinned memory, so a caller who has
+        synchronised with a forward's outputs sees that forward's flag (the word is sticky until reset)."""
+        eng = self._engine
+        return bool(eng is not None and eng.status_probe is not None and int(eng.status_probe[0][0]) & 2)
+
+    def acknowledge_ln_carry(self):
+        """The caller has seen numerics_status() & 16 (or ln_carry_flag_nowait()) and will REPEAT the affected forwards itself: switch to
+        the two-pass LayerNorm launches, reset the sticky word and disarm the pending probe (no exception at the next call)."""
+        self.set_ln_carry(False)
+        self.numerics_status(reset=True)
+        eng = self._engine
+        if eng is not None and eng.status_probe is not None:
+            eng.status_probe[0].zero_()
+            eng.status_probe[2] = False
 
     def graph_active(self):
         """dcf_graph_active: how the last forward was issued (0 eager launches, 1 HIP-graph replay, 2 capture + launch)"""
@@ -689,6 +707,8 @@ class PtTransformerEarlyFusionIterative(nn.Module):
         host, ev, _ = eng.status_probe
         if not ev.query():
             return
+        if (int(host[0]) & 3) == 2 and getattr(self, '_carry_handled_by_caller', False):
+            return                                  # GroundingEvaluator repeats the affected videos itself (evaluator._carry_tripped)
         eng.status_probe[2] = False
         if int(host[0]) & 2:
             self._ln_carry_tripped()

@@ -323,7 +323,7 @@ int dcf_op_linear_ln_carry(const float* A, const float* W1, const float* b1, con
  * ln_w / ln_b NULL = no LayerNorm in front; ls NULL = 1; mask NULL = all rows valid; stats_out (optional, (M, E / 64, 2)):
  * (sum, sum of squares) of every row written to C.  f16x3 operand split.  chain = 0: two GEMMs with the hidden activations in
  * memory; chain = 1 (E = 256 only): one kernel, the hidden activations stay in registers (csrc/ffn_chain.hip: the default kernel;
- * chain = 2: its four-wave form, chain = 3: its eight-wave producer / consumer form -- bit-identical results).  With a LayerNorm
+ * chain = 2: its four-wave form, chain = 3: its eight-wave producer / consumer form -- bit-identical results).  C must not alias X.  With a LayerNorm
  * in front the one-kernel form carries it as one-pass row statistics; if a row turns out ill-conditioned for that (dcf_numerics_status
  * bit 16) the call repeats itself with the LayerNorm as its own two-pass launch, as the engine does after dcf_model_set_ln_carry(m, 0). */
 int dcf_op_ffn(const float* X, const float* ln_w, const float* ln_b, const float* W1, const float* b1, const float* W2, const float* b2,

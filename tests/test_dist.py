@@ -159,7 +159,7 @@ def _worker(rank, world, port, outdir):
         torch.set_num_threads(2)
         pkg, opt, sd, inp, texts, tmasks = _setup()
         d = pkg.dist
-        halo = d.receptive_field(KW['n_levels'], KW['win'])
+        halo = d.receptive_field(KW['n_levels'], KW['win'], **d.PROBE_ARCH)
         plan = d.shard_plan(T, world, KW['n_levels'], KW['win'], halo)
         lo, hi, w_lo, w_hi = plan[rank]
         backend = OracleBackend(sd, opt.model)
@@ -179,7 +179,7 @@ def _worker_2d(rank, world, port, outdir, nq, hybrid=False):
         torch.set_num_threads(2)
         pkg, opt, sd, inp, texts, tmasks = _setup()
         d = pkg.dist
-        halo = d.receptive_field(KW['n_levels'], KW['win'])
+        halo = d.receptive_field(KW['n_levels'], KW['win'], **d.PROBE_ARCH)
         grid = d.shard_plan_2d(T, world, nq, KW['n_levels'], KW['win'], halo, hybrid_arch=ARCH if hybrid else None)
         assert (grid['hybrid'] is not None) == (hybrid and grid['t_shards'] > 1)
         groups = d.make_grid_groups(grid['t_shards'], grid['q_groups'])
@@ -198,7 +198,7 @@ def _worker_2d(rank, world, port, outdir, nq, hybrid=False):
 def test_shard_plan_2d_prefers_queries():
     """queries first, clips second: the rows a rank computes relative to an even share of T * NQ (BASELINE config 4 sizes)"""
     d = load_pkg().dist
-    rf = d.receptive_field(8, 9)
+    rf = d.receptive_field(8, 9, **d.PROBE_ARCH)
     want = {1: (8, 1, 1.5625), 2: (4, 2, 1.28125), 4: (2, 4, 1.0703125), 8: (1, 8, 1.0), 16: (1, 8, 1.0)}
     for nq, (ts, qs, factor) in want.items():
         g = d.shard_plan_2d(65536, 8, nq, 8, 9, rf)
@@ -259,9 +259,9 @@ def test_assign_units_balances():
 def test_shard_plan_alignment_and_cover():
     d = load_pkg().dist
     assert d.alignment(8, 9) == 512 and d.alignment(4, 5) == 16
-    rf = d.receptive_field(8, 9)
+    rf = d.receptive_field(8, 9, **d.PROBE_ARCH)
     assert rf == 2304                  # exact left reach; SURVEY 8e's probe saw the right reach, 2176 = rf - 2^(L-1)
-    assert d.receptive_field(4, 5) == 114 and d.receptive_field(5, 9, 1, 0, 0, 1) == 253    # tools/receptive_field.py probes
+    assert d.receptive_field(4, 5, **d.PROBE_ARCH) == 114 and d.receptive_field(5, 9, fusion_layers=1, n_embd_convs=0, n_stem=0, head_layers=1) == 253    # tools/receptive_field.py probes
     plan = d.shard_plan(65536, 8, 8, 9, rf)
     assert plan[0][0] == 0 and plan[-1][1] == 65536
     for (lo, hi, wl, wh), nxt in zip(plan, plan[1:] + [None]):

@@ -22,7 +22,7 @@ pkg = importlib.import_module('cvpr2025-decafnet_amd')
 def probe(L=8, win=9, fusion_layers=2, n_embd_convs=2, head_layers=2, E=32, D=32):
     torch.set_default_dtype(torch.float64)
     a = (2 ** (L - 1)) * max(win // 2, 1)
-    rf_guess = pkg.dist.receptive_field(L, win, fusion_layers, n_embd_convs, 0, head_layers)
+    rf_guess = pkg.dist.receptive_field(L, win, fusion_layers=fusion_layers, n_embd_convs=n_embd_convs, n_stem=0, head_layers=head_layers)
     T = -(-(2 * rf_guess + 4 * a) // a) * a
     kw = dict(D=D, E=E, TE=32, text_in=32, n_levels=L, win=win, n_heads=4, sn=60, sratio=0.3, msf=True, norm=True,
               max_seq_len=T, text_layers=1, text_max_len=24, fusion_layers=fusion_layers, n_embd_convs=n_embd_convs,

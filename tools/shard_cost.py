@@ -46,7 +46,7 @@ def main():
     gate = be.gate(be.scores(sh[0], cls), mask[0])
     t_full = timeit(lambda: model(vid, sh, mask, texts, cls, tmasks, eval=True))
     # recompute windows
-    plan = d.shard_plan(T, world, L, win, d.receptive_field(L, win))
+    plan = d.shard_plan(T, world, L, win, d.receptive_field(L, win, **d.arch_of(model)))
     lo, hi, w_lo, w_hi = plan[rank]
     vw, sw, mw, gw = vid[0][:, w_lo:w_hi].contiguous(), sh[0][:, w_lo:w_hi].contiguous(), mask[0][w_lo:w_hi].contiguous(), gate[:, w_lo:w_hi].contiguous()
     t_win = timeit(lambda: be.forward_window(vw, sw, mw, texts, tmasks, gw, T, w_lo))
