@@ -86,9 +86,9 @@ extern "C" int dcf_calib_mfma_rate(int32_t shape, int32_t mfmas_per_wave, int32_
     if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
     if (err == hipSuccess) err = hipGetLastError();
   }
-  if (e0) hipEventDestroy(e0);
-  if (e1) hipEventDestroy(e1);
-  if (out) hipFree(out);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (out) (void)hipFree(out);
   DCF_HIP(err);
   *n_cus = cus;
   *ns_per_mfma = ms * 1e6f / (float)reps / (float)(rounds * 16);

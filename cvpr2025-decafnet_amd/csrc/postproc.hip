@@ -717,7 +717,7 @@ __device__ __forceinline__ MaxPos wave_best(MaxPos b) {
 #ifndef DCF_SOFTNMS_THREADS
 #define DCF_SOFTNMS_THREADS 256
 #endif
-constexpr int SNT = DCF_SOFTNMS_THREADS, SNW = SNT / 64;      // soft NMS: a pick is four barriers and a handful of LDS round trips -- four waves synchronise faster than sixteen
+constexpr int SNT = DCF_SOFTNMS_THREADS, SNW = SNT / 64;      // soft NMS: a pick is two barriers and a handful of LDS round trips -- four waves synchronise faster than sixteen
 template <bool BIG>
 __global__ __launch_bounds__(SNT) void k_softnms(SoftNmsArgs p, unsigned char* scratch, size_t scratch_per_q) {
   __shared__ float s_x1[BIG ? 1 : NMS_CAP], s_x2[BIG ? 1 : NMS_CAP], s_sc[BIG ? 1 : NMS_CAP], s_ar[BIG ? 1 : NMS_CAP];
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(SNT) void k_softnms(SoftNmsArgs p, unsigned char* s
   __shared__ int s_wave[SNW + 1];
   __shared__ float s_v[SNW];
   __shared__ int s_p[SNW];
-  __shared__ int s_dead, s_cnt;
+  __shared__ int s_dead2[2], s_cnt2[2];                  // per pick parity: "a score fell below min_score", length of the overlap list
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int n = p.counts ? min(p.counts[q], p.n_max) : p.n_max;
   const float* segs = p.segs + (size_t)q * p.stride * 2;
@@ -752,20 +752,71 @@ __global__ __launch_bounds__(SNT) void k_softnms(SoftNmsArgs p, unsigned char* s
   int nsegs = n;
   const int iters = p.max_iters > 0 ? p.max_iters : n;
   int i = 0;
-  // Four barriers per pick (it was five, with a twelve-step ds_bpermute butterfly, a one-thread section and the exp in four waves of five):
-  //   [A] the waves' best (score, position) -- a DPP reduction per wave -- are in LDS; EVERY thread reduces the SNW partials, so all know
-  //       the pick `mp`; every thread reads the picked segment (slot mp) and the one it changes places with (slot i);
-  //   [B] thread 0 writes the swap and the detection, the others look at the segments behind i -- the thread that meets position mp works on
-  //       the values of slot i it read before [B] (the slot's content after the swap) -- and list those the pick overlaps;
-  //   [B2] the listed segments are decayed; s_dead is raised if a score fell below min_score;
-  //   [C] the scores are in place for the next pick; s_dead decides (uniformly) whether the pruning pass runs.
-  for (; i < nsegs && i < iters; ++i) {
-    // ---- argmax over [i, nsegs)
-    MaxPos best{0.f, -1};
-    for (int pos = i + tid; pos < nsegs; pos += SNT) best = better(best, MaxPos{sc[pos], pos});
+  // TWO barriers per pick (round 5: four; round 4: five with a twelve-step ds_bpermute butterfly):
+  //   [A] the waves' best (score, position) over [i, nsegs) are in LDS -- every thread folded them together while it DECAYED the scores for
+  //       the previous pick (each score is looked at then anyway), so a pick needs no pass of its own over the scores; EVERY thread reduces the
+  //       SNW partials, so all know the pick `mp`; every thread reads the picked segment (slot mp) and the one it changes places with (slot i);
+  //       the threads then look at the segments behind i -- the thread that meets position mp works on the values of slot i it read above
+  //       (the slot's content after the swap) -- and list those the pick overlaps (counter of this pick's parity);
+  //   [B] every thread has read slots i and mp: thread 0 writes the swap and the detection; the listed segments are decayed; the flag of this
+  //       pick's parity is raised if a score fell below min_score; the waves publish their best for the next pick.
+  // The counter / flag of the OTHER parity are cleared behind [B] (their readers are past [A]).  A raised flag sends the next iteration
+  // through the pruning pass first (uniformly), which moves segments: the partial maxima are then taken again.
+  auto publish_best = [&](MaxPos best) __attribute__((always_inline)) {
     best = wave_best(best);
     if (lane == 0) { s_v[w] = best.v; s_p[w] = best.pos; }
+  };
+  {
+    MaxPos best{0.f, -1};
+    for (int pos = tid; pos < nsegs; pos += SNT) best = better(best, MaxPos{sc[pos], pos});
+    publish_best(best);
+  }
+  if (tid == 0) { s_dead2[0] = s_dead2[1] = 0; s_cnt2[0] = s_cnt2[1] = 0; }
+  int dead_cnt = 0;                                      // scores of this thread's share that fell below min_score in the last decay
+  for (;;) {
     __syncthreads();                                                                      // [A]
+    const int cur = i & 1, prv = cur ^ 1;
+    if (i > 0 && s_dead2[prv]) {                         // uniform: the decay behind pick i - 1 left scores below min_score
+      int n_dead;
+      block_exscan<SNW>(dead_cnt, s_wave, n_dead);
+      // ---- emulate the sequential "swap with the last segment" pruning (nms_cpu.cpp:157-165):
+      // survivors keep their slots; the k-th dead slot (left to right) inside the new range is
+      // filled by the k-th surviving segment counted from the right end of the old range.
+      const int first = i;
+      const int n_alive = (nsegs - first) - n_dead;
+      const int new_n = first + n_alive;
+      // each thread owns a contiguous run of positions so that prefix counts are ordered
+      const int span = nsegs - first;
+      const int per = (span + SNT - 1) / SNT;
+      const int lo = first + tid * per, hi = min(lo + per, nsegs);
+      int c_dead_left = 0, c_alive_right = 0;
+      for (int pos = lo; pos < hi; ++pos) {
+        const bool dead = sc[pos] < p.min_score;
+        if (pos < new_n) c_dead_left += dead; else c_alive_right += !dead;
+      }
+      int tot_d, tot_a;
+      int pd = block_exscan<SNW>(c_dead_left, s_wave, tot_d);
+      int pa = block_exscan<SNW>(c_alive_right, s_wave, tot_a);
+      for (int pos = lo; pos < hi; ++pos) {
+        if (pos < new_n && sc[pos] < p.min_score) slot[pd++] = pos;
+      }
+      __syncthreads();
+      for (int pos = lo; pos < hi; ++pos) {
+        if (pos >= new_n && !(sc[pos] < p.min_score)) {
+          // rank from the right = tot_a - 1 - (rank from the left)
+          const int dst = slot[tot_a - 1 - pa];
+          ++pa;
+          x1[dst] = x1[pos]; x2[dst] = x2[pos]; sc[dst] = sc[pos]; ar[dst] = ar[pos]; ind[dst] = ind[pos];
+        }
+      }
+      __syncthreads();
+      nsegs = new_n;
+      MaxPos best{0.f, -1};                              // segments moved: the partial maxima over [i, nsegs) again
+      for (int pos = i + tid; pos < nsegs; pos += SNT) best = better(best, MaxPos{sc[pos], pos});
+      publish_best(best);
+      __syncthreads();
+    }
+    if (!(i < nsegs && i < iters)) break;                // (uniform)
     MaxPos bb{s_v[0], s_p[0]};
 #pragma unroll
     for (int k = 1; k < SNW; ++k) bb = better(bb, MaxPos{s_v[k], s_p[k]});
@@ -775,31 +826,34 @@ __global__ __launch_bounds__(SNT) void k_softnms(SoftNmsArgs p, unsigned char* s
     const int iind = ind[mp];
     const float ox1 = x1[i], ox2 = x2[i], osc = sc[i], oar = ar[i];
     const int oind = ind[i];
-    if (tid == 0) { s_dead = 0; s_cnt = 0; }
-    __syncthreads();                                                                      // [B]
-    if (tid == 0) {
-      dets[i * 3 + 0] = ix1; dets[i * 3 + 1] = ix2; dets[i * 3 + 2] = isc;
-      x1[i] = ix1; x2[i] = ix2; sc[i] = isc; ar[i] = ia; ind[i] = iind;
-      if (mp != i) { x1[mp] = ox1; x2[mp] = ox2; ar[mp] = oar; ind[mp] = oind; }         // (its score: by the thread that decays position mp)
-    }
     // ---- decay every later segment (nms_cpu.cpp:137-155).  Without overlap the weight is exactly 1 -- exp(-0) for the Gaussian, below
     // any positive threshold for the other two -- and score * 1 is the score: only the segments the pick touches need the division and
     // the double-precision exp.  They are few (tens of 2 000) but scattered, so four of five waves would run the exp for a lane or
-    // two: their positions go to a list (`slot`, free outside the pruning pass) and ceil(count / 64) waves work it off behind [B2].
-    int dead_cnt = 0;
+    // two: their positions go to a list (`slot`, free outside the pruning pass) and ceil(count / 64) waves work it off behind [B].
+    dead_cnt = 0;
+    bool fix_mp = false;
+    MaxPos best{0.f, -1};                                // this thread's share of the NEXT pick's argmax, over [i + 1, nsegs)
     for (int pos = i + 1 + tid; pos < nsegs; pos += SNT) {
       const bool moved = pos == mp;                      // this slot now holds what slot i held
       const float px1 = moved ? ox1 : x1[pos], px2 = moved ? ox2 : x2[pos], psc = moved ? osc : sc[pos];
       const float inter = fmaxf(0.f, fminf(ix2, px2) - fmaxf(ix1, px1));
       if (inter > 0.f || (p.method != 2 && !(p.iou_thresh > 0.f))) {
-        slot[atomicAdd(&s_cnt, 1)] = pos;
+        slot[atomicAdd(&s_cnt2[cur], 1)] = pos;
       } else {
-        if (moved) sc[pos] = psc;
+        fix_mp = fix_mp || moved;                        // (written behind [B]: thread 0 still reads the pick's score from that slot)
         dead_cnt += psc < p.min_score;
+        best = better(best, MaxPos{psc, pos});
       }
     }
-    __syncthreads();                                                                      // [B2]
-    const int n_touch = s_cnt;
+    __syncthreads();                                                                      // [B]
+    if (fix_mp) sc[mp] = osc;
+    if (tid == 0) {
+      dets[i * 3 + 0] = ix1; dets[i * 3 + 1] = ix2; dets[i * 3 + 2] = isc;
+      x1[i] = ix1; x2[i] = ix2; sc[i] = isc; ar[i] = ia; ind[i] = iind;
+      if (mp != i) { x1[mp] = ox1; x2[mp] = ox2; ar[mp] = oar; ind[mp] = oind; }         // (its score: by the thread that decays position mp)
+      s_cnt2[prv] = 0; s_dead2[prv] = 0;
+    }
+    const int n_touch = s_cnt2[cur];
     for (int k = tid; k < n_touch; k += SNT) {
       const int pos = slot[k];
       const bool moved = pos == mp;
@@ -817,44 +871,11 @@ __global__ __launch_bounds__(SNT) void k_softnms(SoftNmsArgs p, unsigned char* s
       const float s_ = psc * weight;
       sc[pos] = s_;
       dead_cnt += s_ < p.min_score;
+      best = better(best, MaxPos{s_, pos});
     }
-    if (dead_cnt) s_dead = 1;
-    __syncthreads();                                                                      // [C]
-    if (!s_dead) continue;                               // uniform
-    int n_dead;
-    block_exscan<SNW>(dead_cnt, s_wave, n_dead);
-    // ---- emulate the sequential "swap with the last segment" pruning (nms_cpu.cpp:157-165):
-    // survivors keep their slots; the k-th dead slot (left to right) inside the new range is
-    // filled by the k-th surviving segment counted from the right end of the old range.
-    const int first = i + 1;
-    const int n_alive = (nsegs - first) - n_dead;
-    const int new_n = first + n_alive;
-    // each thread owns a contiguous run of positions so that prefix counts are ordered
-    const int span = nsegs - first;
-    const int per = (span + SNT - 1) / SNT;
-    const int lo = first + tid * per, hi = min(lo + per, nsegs);
-    int c_dead_left = 0, c_alive_right = 0;
-    for (int pos = lo; pos < hi; ++pos) {
-      const bool dead = sc[pos] < p.min_score;
-      if (pos < new_n) c_dead_left += dead; else c_alive_right += !dead;
-    }
-    int tot_d, tot_a;
-    int pd = block_exscan<SNW>(c_dead_left, s_wave, tot_d);
-    int pa = block_exscan<SNW>(c_alive_right, s_wave, tot_a);
-    for (int pos = lo; pos < hi; ++pos) {
-      if (pos < new_n && sc[pos] < p.min_score) slot[pd++] = pos;
-    }
-    __syncthreads();
-    for (int pos = lo; pos < hi; ++pos) {
-      if (pos >= new_n && !(sc[pos] < p.min_score)) {
-        // rank from the right = tot_a - 1 - (rank from the left)
-        const int dst = slot[tot_a - 1 - pa];
-        ++pa;
-        x1[dst] = x1[pos]; x2[dst] = x2[pos]; sc[dst] = sc[pos]; ar[dst] = ar[pos]; ind[dst] = ind[pos];
-      }
-    }
-    __syncthreads();
-    nsegs = new_n;
+    if (dead_cnt) s_dead2[cur] = 1;
+    publish_best(best);
+    ++i;
   }
   const int n_out = (p.max_iters > 0) ? min(i, nsegs) : nsegs;
   for (int k = tid; k < n_out; k += SNT) out[k] = (long long)ind[k];
