@@ -421,3 +421,19 @@ def test_text_identity():
             close(lg[q][l], g.t(f'model/q{q}/l{l}/logits'), atol=1e-4, rtol=1e-4)
             close(of[q][l], g.t(f'model/q{q}/l{l}/offsets'), atol=1e-4, rtol=1e-4)
             assert torch.equal(mk[q][l], g.t(f'model/q{q}/l{l}/mask'))
+
+
+def test_c_oracle_is_clean_under_the_sanitizers():
+    """oracle/nms_ref.c under AddressSanitizer + UBSan (`make -C oracle sanitize`: san_fuzz.c runs NMS and the three soft-NMS methods over
+    random candidate sets of every small size, heavy overlaps, equal scores and scores below the pruning threshold, on exact-size buffers).
+    The HIP kernels' indices are compared with this code bit for bit, so an out-of-bounds read in it would be a wrong checker; GPU
+    sanitizers are not available on this pool."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None and shutil.which('cc') is None:
+        pytest.skip('no C compiler')
+    r = subprocess.run(['make', '-C', os.path.join(ROOT, 'oracle'), 'sanitize'], capture_output=True, text=True, timeout=300)
+    if r.returncode != 0 and ('cannot find -lasan' in r.stderr or 'libasan' in r.stderr or 'unrecognized' in r.stderr):
+        pytest.skip('the sanitizer runtimes are not installed here')
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert 'san_fuzz ok' in r.stdout
