@@ -670,7 +670,8 @@ __device__ const unsigned long long expf_tab[32] = {
     0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
     0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
     0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
-__device__ __forceinline__ float expf_glibc(float x) {
+template <typename Tab>
+__device__ __forceinline__ float expf_glibc(float x, Tab tab) {      // tab: expf_tab, or a copy of it nearer by
   const double xd = (double)x;
   const unsigned abstop = (__float_as_uint(x) >> 20) & 0x7ffu;
   if (abstop >= 0x42bu) return (float)exp(xd);          // |x| >= 88, inf, NaN: the library's special cases (not reached by -ovr^2 / sigma for sigma > 0.012)
@@ -681,7 +682,7 @@ __device__ __forceinline__ float expf_glibc(float x) {
   const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
   kd -= shift;
   const double r = z - kd;
-  unsigned long long t = expf_tab[ki & 31ull];
+  unsigned long long t = tab[ki & 31ull];
   t += ki << 47;
   const double s = __longlong_as_double((long long)t);
   z = __builtin_fma(c0, r, c1);
@@ -692,40 +693,50 @@ __device__ __forceinline__ float expf_glibc(float x) {
   return (float)y;
 }
 
-struct MaxPos { float v; int pos; };
-__device__ __forceinline__ MaxPos better(MaxPos a, MaxPos b) {
-  // first maximum wins: larger value, or equal value at the lower position (nms_cpu.cpp:107-113)
-  if (b.pos >= 0 && (a.pos < 0 || b.v > a.v || (b.v == a.v && b.pos < a.pos))) return b;
-  return a;
+// The arg-max of soft NMS as ONE unsigned 64-bit maximum: high word = the score's bits mapped so that unsigned order is float order
+// (-0 counted as +0, as the reference's `>` does), low word = ~position, so the larger key is the larger score and, between equal scores,
+// the LOWER position -- "first maximum wins" (nms_cpu.cpp:107-113).  0 = no candidate (below the key of any score that is not a NaN).
+// Branch-free: the struct-and-`if` form of this compiled to a dozen exec-mask branches per position (profiles/r06_notes.md section 5).
+__device__ __forceinline__ unsigned long long snms_key(float v, int pos) {
+  unsigned b = __float_as_uint(v);
+  b = v == 0.f ? 0u : b;
+  const unsigned srt = b ^ ((unsigned)((int)b >> 31) | 0x80000000u);
+  return ((unsigned long long)srt << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)pos);
 }
-
-// the wave's best (value, position) in every lane: the DPP steps of wave_max (common.h) on the pair
+__device__ __forceinline__ int snms_pos(unsigned long long key) { return (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)); }
+__device__ __forceinline__ unsigned long long umax64(unsigned long long a, unsigned long long b) { return a > b ? a : b; }
 template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ MaxPos dpp_mp(MaxPos a) {
-  return MaxPos{dpp_self<CTRL, ROW_MASK>(a.v), __builtin_amdgcn_update_dpp(a.pos, a.pos, CTRL, ROW_MASK, 0xf, false)};
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long k) {         // lanes not written keep their own value
+  const int lo = (int)(unsigned)(k & 0xFFFFFFFFull), hi = (int)(unsigned)(k >> 32);
+  const unsigned l2 = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+  const unsigned h2 = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+  return ((unsigned long long)h2 << 32) | l2;
 }
-__device__ __forceinline__ MaxPos wave_best(MaxPos b) {
-  b = better(b, dpp_mp<DPP_XOR1>(b));
-  b = better(b, dpp_mp<DPP_XOR2>(b));
-  b = better(b, dpp_mp<DPP_HALF_MIRROR>(b));
-  b = better(b, dpp_mp<DPP_MIRROR>(b));
-  b = better(b, dpp_mp<DPP_BCAST15, 0xA>(b));
-  b = better(b, dpp_mp<DPP_BCAST31, 0xC>(b));
-  return MaxPos{__int_as_float(__builtin_amdgcn_readlane(__float_as_int(b.v), 63)), __builtin_amdgcn_readlane(b.pos, 63)};
+// the wave's largest key in every lane: the DPP steps of wave_max (common.h)
+__device__ __forceinline__ unsigned long long wave_max_key(unsigned long long k) {
+  k = umax64(k, dpp_u64<DPP_XOR1>(k));
+  k = umax64(k, dpp_u64<DPP_XOR2>(k));
+  k = umax64(k, dpp_u64<DPP_HALF_MIRROR>(k));
+  k = umax64(k, dpp_u64<DPP_MIRROR>(k));
+  k = umax64(k, dpp_u64<DPP_BCAST15, 0xA>(k));
+  k = umax64(k, dpp_u64<DPP_BCAST31, 0xC>(k));
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k & 0xFFFFFFFFull), 63);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
 }
 
-#ifndef DCF_SOFTNMS_THREADS
-#define DCF_SOFTNMS_THREADS 256
-#endif
-constexpr int SNT = DCF_SOFTNMS_THREADS, SNW = SNT / 64;      // soft NMS: a pick is two barriers and a handful of LDS round trips -- four waves synchronise faster than sixteen
-template <bool BIG>
+// SNT threads: a pick is two barriers, a handful of LDS round trips and one pass over the positions behind it -- four waves synchronise
+// faster than sixteen, sixteen pass over 4 096 positions faster than four: launch_softnms picks 256 / 512 / 1024 by the candidate count
+// (tools/softnms_time.py, same box: n = 512 0.69 / 0.73 / 0.73 ms, n = 2 000 3.39 / 3.00 / 3.05, n = 4 096 8.07 / 6.18 / 5.89).
+template <bool BIG, int SNT>
 __global__ __launch_bounds__(SNT) void k_softnms(SoftNmsArgs p, unsigned char* scratch, size_t scratch_per_q) {
+  constexpr int SNW = SNT / 64;
   __shared__ float s_x1[BIG ? 1 : NMS_CAP], s_x2[BIG ? 1 : NMS_CAP], s_sc[BIG ? 1 : NMS_CAP], s_ar[BIG ? 1 : NMS_CAP];
   __shared__ int s_ind[BIG ? 1 : NMS_CAP];
   __shared__ int s_slot[BIG ? 1 : NMS_CAP];
   __shared__ int s_wave[SNW + 1];
-  __shared__ float s_v[SNW];
-  __shared__ int s_p[SNW];
+  __shared__ unsigned long long s_key[SNW];              // the waves' best (score, position) keys for the coming pick
+  __shared__ unsigned long long s_tab[32];               // expf_tab in LDS: the look-up sits in the dependent chain of every decay
   __shared__ int s_dead2[2], s_cnt2[2];                  // per pick parity: "a score fell below min_score", length of the overlap list
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int n = p.counts ? min(p.counts[q], p.n_max) : p.n_max;
@@ -744,6 +755,7 @@ __global__ __launch_bounds__(SNT) void k_softnms(SoftNmsArgs p, unsigned char* s
   } else {
     x1 = s_x1; x2 = s_x2; sc = s_sc; ar = s_ar; ind = s_ind; slot = s_slot;
   }
+  if (tid < 32) s_tab[tid] = expf_tab[tid];
   for (int i = tid; i < n; i += SNT) {
     const float l = segs[2 * i], r = segs[2 * i + 1];
     x1[i] = l; x2[i] = r; sc[i] = scores[i]; ar[i] = (r - l) + 1e-6f; ind[i] = i;
@@ -753,26 +765,31 @@ __global__ __launch_bounds__(SNT) void k_softnms(SoftNmsArgs p, unsigned char* s
   const int iters = p.max_iters > 0 ? p.max_iters : n;
   int i = 0;
   // TWO barriers per pick (round 5: four; round 4: five with a twelve-step ds_bpermute butterfly):
-  //   [A] the waves' best (score, position) over [i, nsegs) are in LDS -- every thread folded them together while it DECAYED the scores for
-  //       the previous pick (each score is looked at then anyway), so a pick needs no pass of its own over the scores; EVERY thread reduces the
-  //       SNW partials, so all know the pick `mp`; every thread reads the picked segment (slot mp) and the one it changes places with (slot i);
+  //   [A] the waves' best (score, position) keys over [i, nsegs) are in LDS -- every thread folded them together while it DECAYED the scores
+  //       for the previous pick (each score is looked at then anyway), so a pick needs no pass of its own over the scores; EVERY thread reduces
+  //       the SNW keys, so all know the pick `mp`; every thread reads the picked segment (slot mp) and the one it changes places with (slot i);
   //       the threads then look at the segments behind i -- the thread that meets position mp works on the values of slot i it read above
   //       (the slot's content after the swap) -- and list those the pick overlaps (counter of this pick's parity);
   //   [B] every thread has read slots i and mp: thread 0 writes the swap and the detection; the listed segments are decayed; the flag of this
   //       pick's parity is raised if a score fell below min_score; the waves publish their best for the next pick.
   // The counter / flag of the OTHER parity are cleared behind [B] (their readers are past [A]).  A raised flag sends the next iteration
-  // through the pruning pass first (uniformly), which moves segments: the partial maxima are then taken again.
-  auto publish_best = [&](MaxPos best) __attribute__((always_inline)) {
-    best = wave_best(best);
-    if (lane == 0) { s_v[w] = best.v; s_p[w] = best.pos; }
+  // through the pruning pass first (uniformly), which moves segments: the keys are then taken again.
+  // The passes over the positions are branch-free (keys, selects, one `if` around the list entry): written with an `if` per case and a
+  // (score, position) struct, a pick spent 1.25 of its 3.3 us (n = 2 000, four waves) in the exec-mask branches of the scan and 0.5 us in
+  // the wave reduction of the pairs (profiles/r06_notes.md section 5; several positions per trip, ballots instead of the atomic, a list
+  // per wave, the segment carried in the list entry and a move-only path for a single pruned segment were each measured slower or equal).
+  auto publish_best = [&](unsigned long long best) __attribute__((always_inline)) {
+    best = wave_max_key(best);
+    if (lane == 0) s_key[w] = best;
   };
   {
-    MaxPos best{0.f, -1};
-    for (int pos = tid; pos < nsegs; pos += SNT) best = better(best, MaxPos{sc[pos], pos});
+    unsigned long long best = 0;
+    for (int pos = tid; pos < nsegs; pos += SNT) best = umax64(best, snms_key(sc[pos], pos));
     publish_best(best);
   }
   if (tid == 0) { s_dead2[0] = s_dead2[1] = 0; s_cnt2[0] = s_cnt2[1] = 0; }
   int dead_cnt = 0;                                      // scores of this thread's share that fell below min_score in the last decay
+  const bool all_touch = p.method != 2 && !(p.iou_thresh > 0.f);
   for (;;) {
     __syncthreads();                                                                      // [A]
     const int cur = i & 1, prv = cur ^ 1;
@@ -811,16 +828,16 @@ __global__ __launch_bounds__(SNT) void k_softnms(SoftNmsArgs p, unsigned char* s
       }
       __syncthreads();
       nsegs = new_n;
-      MaxPos best{0.f, -1};                              // segments moved: the partial maxima over [i, nsegs) again
-      for (int pos = i + tid; pos < nsegs; pos += SNT) best = better(best, MaxPos{sc[pos], pos});
+      unsigned long long best = 0;                       // segments moved: the keys over [i, nsegs) again
+      for (int pos = i + tid; pos < nsegs; pos += SNT) best = umax64(best, snms_key(sc[pos], pos));
       publish_best(best);
       __syncthreads();
     }
     if (!(i < nsegs && i < iters)) break;                // (uniform)
-    MaxPos bb{s_v[0], s_p[0]};
+    unsigned long long bb = s_key[0];
 #pragma unroll
-    for (int k = 1; k < SNW; ++k) bb = better(bb, MaxPos{s_v[k], s_p[k]});
-    const int mp = bb.pos;
+    for (int k = 1; k < SNW; ++k) bb = umax64(bb, s_key[k]);
+    const int mp = snms_pos(bb);
     // the pick (slot mp) and the segment that moves into its slot (slot i): nms_cpu.cpp:115-133
     const float ix1 = x1[mp], ix2 = x2[mp], isc = sc[mp], ia = ar[mp];
     const int iind = ind[mp];
@@ -832,18 +849,35 @@ __global__ __launch_bounds__(SNT) void k_softnms(SoftNmsArgs p, unsigned char* s
     // two: their positions go to a list (`slot`, free outside the pruning pass) and ceil(count / 64) waves work it off behind [B].
     dead_cnt = 0;
     bool fix_mp = false;
-    MaxPos best{0.f, -1};                                // this thread's share of the NEXT pick's argmax, over [i + 1, nsegs)
-    for (int pos = i + 1 + tid; pos < nsegs; pos += SNT) {
-      const bool moved = pos == mp;                      // this slot now holds what slot i held
-      const float px1 = moved ? ox1 : x1[pos], px2 = moved ? ox2 : x2[pos], psc = moved ? osc : sc[pos];
-      const float inter = fmaxf(0.f, fminf(ix2, px2) - fmaxf(ix1, px1));
-      if (inter > 0.f || (p.method != 2 && !(p.iou_thresh > 0.f))) {
-        slot[atomicAdd(&s_cnt2[cur], 1)] = pos;
-      } else {
-        fix_mp = fix_mp || moved;                        // (written behind [B]: thread 0 still reads the pick's score from that slot)
-        dead_cnt += psc < p.min_score;
-        best = better(best, MaxPos{psc, pos});
+    unsigned long long best = 0;                         // this thread's share of the NEXT pick's argmax, over [i + 1, nsegs)
+    // (SCAN_U positions per trip, their LDS reads going out unconditionally from clamped positions, then the selects, then the list
+    // entries: measured with 1 / 2 / 3 / 4 / 8 -- one position per trip is the fastest at every thread count, and this form of it is 7 %
+    // faster than a plain `for (pos...; pos < nsegs; ...)` with the reads inside)
+    constexpr int SCAN_U = 1;
+    for (int base = i + 1 + tid; base < nsegs; base += SCAN_U * SNT) {
+      float qx1[SCAN_U], qx2[SCAN_U], qsc[SCAN_U];
+      bool touch[SCAN_U];
+#pragma unroll
+      for (int u = 0; u < SCAN_U; ++u) {
+        const int pos = min(base + u * SNT, nsegs - 1);
+        qx1[u] = x1[pos]; qx2[u] = x2[pos]; qsc[u] = sc[pos];
       }
+#pragma unroll
+      for (int u = 0; u < SCAN_U; ++u) {
+        const int pos = base + u * SNT;
+        const bool valid = pos < nsegs;
+        const bool moved = pos == mp;                    // this slot now holds what slot i held
+        const float px1 = moved ? ox1 : qx1[u], px2 = moved ? ox2 : qx2[u], psc = moved ? osc : qsc[u];
+        const float inter = fmaxf(0.f, fminf(ix2, px2) - fmaxf(ix1, px1));
+        touch[u] = valid & ((inter > 0.f) | all_touch);
+        const bool keep = valid & !touch[u];             // untouched: the score stays, it competes for the next pick as it is
+        fix_mp = fix_mp | (keep & moved);                // (written behind [B]: thread 0 still reads the pick's score from that slot)
+        dead_cnt += (int)(keep & (psc < p.min_score));
+        best = umax64(best, keep ? snms_key(psc, pos) : 0ull);
+      }
+#pragma unroll
+      for (int u = 0; u < SCAN_U; ++u)
+        if (touch[u]) slot[atomicAdd(&s_cnt2[cur], 1)] = base + u * SNT;
     }
     __syncthreads();                                                                      // [B]
     if (fix_mp) sc[mp] = osc;
@@ -866,12 +900,12 @@ __global__ __launch_bounds__(SNT) void k_softnms(SoftNmsArgs p, unsigned char* s
       if (p.method == 0) { if (ovr >= p.iou_thresh) weight = 0.f; }
       else if (p.method == 1) { if (ovr >= p.iou_thresh) weight = 1.f - ovr; }
       else if (p.method == 2) {
-        weight = expf_glibc(-(ovr * ovr) / p.sigma);        // std::exp(float) of the reference's C library, bit for bit
+        weight = expf_glibc(-(ovr * ovr) / p.sigma, s_tab);  // std::exp(float) of the reference's C library, bit for bit
       }
       const float s_ = psc * weight;
       sc[pos] = s_;
-      dead_cnt += s_ < p.min_score;
-      best = better(best, MaxPos{s_, pos});
+      dead_cnt += (int)(s_ < p.min_score);
+      best = umax64(best, snms_key(s_, pos));
     }
     if (dead_cnt) s_dead2[cur] = 1;
     publish_best(best);
@@ -889,14 +923,16 @@ int launch_softnms(const SoftNmsArgs& a, int nq, hipStream_t st) {
   DCF_CHECK(a.stride >= a.n_max, "softnms: stride < n_max");
   ProfScope prof("softnms_1d", st, 0.0, 0.0);
   if (a.n_max <= NMS_CAP) {
-    hipLaunchKernelGGL(k_softnms<false>, dim3(nq), dim3(SNT), 0, st, a, (unsigned char*)nullptr, (size_t)0);
+    if (a.n_max <= 768) hipLaunchKernelGGL((k_softnms<false, 256>), dim3(nq), dim3(256), 0, st, a, (unsigned char*)nullptr, (size_t)0);
+    else if (a.n_max <= 3072) hipLaunchKernelGGL((k_softnms<false, 512>), dim3(nq), dim3(512), 0, st, a, (unsigned char*)nullptr, (size_t)0);
+    else hipLaunchKernelGGL((k_softnms<false, 1024>), dim3(nq), dim3(1024), 0, st, a, (unsigned char*)nullptr, (size_t)0);
     DCF_HIP(hipGetLastError());
     return 0;
   }
   const size_t per_q = (softnms_big_scratch(a.n_max) + 255) & ~(size_t)255;
   unsigned char* scratch = nullptr;
   DCF_HIP(hipMallocAsync((void**)&scratch, per_q * nq, st));
-  hipLaunchKernelGGL(k_softnms<true>, dim3(nq), dim3(SNT), 0, st, a, scratch, per_q);
+  hipLaunchKernelGGL((k_softnms<true, 1024>), dim3(nq), dim3(1024), 0, st, a, scratch, per_q);
   const hipError_t e = hipGetLastError();
   DCF_HIP(hipFreeAsync(scratch, st));
   DCF_HIP(e);

@@ -1007,6 +1007,30 @@ def test_nms_fuzz_vs_oracle(L):
             assert torch.equal(d1[:len(i1)], d2[:len(i2)]), (trial, n, method)       # (the oracle's expf is the host C library's)
 
 
+def test_softnms_ties_and_pruning_fuzz_vs_oracle(L):
+    """Quantised scores and segments: decayed scores tie again and again, and fall below min_score one at a time or several at once --
+    the order of the picks then hangs on the positions the reference's swap-with-last pruning (nms_cpu.cpp:157-165) leaves behind, which
+    both pruning paths of k_softnms (one dead segment: the move alone; several: the scans) have to reproduce."""
+    pkg, lib = L
+    nms = pkg.nms
+    g = torch.Generator().manual_seed(99)
+    for trial in range(36):
+        n = int(torch.randint(2, 900, (1,), generator=g)) if trial < 33 else (2000, 4096, 4100)[trial - 33]
+        levels = (4, 16, 64)[trial % 3]
+        c = torch.randint(0, 12 + n // 8, (n,), generator=g).float() * 2.0
+        ln = torch.randint(1, 6, (n,), generator=g).float() * 2.0
+        segs = torch.stack((c - ln / 2, c + ln / 2), -1).contiguous()
+        scores = (torch.randint(1, levels + 1, (n,), generator=g).float() / levels).contiguous()
+        thr = (0.1, 0.3, 0.5)[trial % 3]
+        for method in (0, 1, 2):
+            for ms in (0.001, 0.2, 0.45):
+                d1, d2 = torch.zeros(n, 3), torch.zeros(n, 3)
+                i1 = nms.softnms(segs, scores, d1, thr, 0.5, ms, method)
+                i2 = nms_oracle.softnms(segs, scores, d2, thr, 0.5, ms, method)
+                assert torch.equal(i1, i2), (trial, n, method, ms)
+                assert torch.equal(d1[:len(i1)], d2[:len(i2)]), (trial, n, method, ms)
+
+
 def test_nms_ties_are_stable(L):
     """all scores equal: our definition = lowest index first (documented deviation from at::sort)"""
     pkg, _ = L
